@@ -1,0 +1,115 @@
+// nbci_common.h — shared device/host helpers for the NDT1 hot-path kernels (gfx950 only).
+//
+// Everything in csrc/ is written for MI355X (gfx950, wave64). No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace nbci {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---- error plumbing (thread-local last error string; C-ABI returns int status) ----
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define NBCI_OK 0
+#define NBCI_EINVAL (-1)
+#define NBCI_ESHAPE (-2)
+#define NBCI_EALIGN (-3)
+#define NBCI_EWORKSPACE (-4)
+#define NBCI_EHIP (-5)
+
+#define NBCI_CHECK_HIP(expr)                                                      \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess)                                                     \
+            return ::nbci::fail(NBCI_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define NBCI_REQUIRE(cond, code, msg)                    \
+    do {                                                 \
+        if (!(cond)) return ::nbci::fail((code), (msg)); \
+    } while (0)
+
+// ---- bf16 <-> f32 (plain casts: hipcc emits v_cvt_pk_bf16_f32, NaN-preserving) ----
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+
+// ---- stateless counter RNG -------------------------------------------------------
+// One 32-bit draw per (seed, site, element index). "site" separates the dropout /
+// noise call sites of one train step; the backward pass regenerates the same bits.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint32_t seed, uint32_t site, uint32_t idx) {
+    uint32_t h = mix32(idx ^ (seed * 0x9E3779B9U + 0x85EBCA6BU));
+    h = mix32(h ^ (site * 0xC2B2AE35U + 0x27D4EB2FU));
+    return h;
+}
+// keep-mask for dropout probability p: threshold = floor(p * 2^32); keep iff draw >= threshold
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0.0) return 0u;
+    if (t >= 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+__device__ __forceinline__ float rng_uniform01(uint32_t u) {  // (0,1]
+    return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+// standard normal via Box-Muller from two draws
+__device__ __forceinline__ float rng_normal(uint32_t seed, uint32_t site, uint32_t idx) {
+    uint32_t a = rng_u32(seed, site, idx);
+    uint32_t b = rng_u32(seed ^ 0x5bd1e995U, site + 0x1000193U, idx);
+    float u1 = rng_uniform01(a), u2 = rng_uniform01(b);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
+// ---- wave64 reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activation ids shared by GEMM epilogues and elementwise kernels
+enum Act { ACT_NONE = 0, ACT_SOFTSIGN = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    switch (act) {
+        case ACT_SOFTSIGN: return x / (1.0f + fabsf(x));
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+// derivative wrt the pre-activation x
+__device__ __forceinline__ float act_bwd(int act, float x) {
+    switch (act) {
+        case ACT_SOFTSIGN: { float d = 1.0f + fabsf(x); return 1.0f / (d * d); }
+        case ACT_GELU: {
+            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+        default: return 1.0f;
+    }
+}
+
+}  // namespace nbci
