@@ -1,0 +1,247 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference; never on the GPU box, never from
+the test-suite). Nothing from the reference is copied: the fixtures are inputs and the
+reference's outputs on them (SURVEY.md §8c, Appendix B recipe).
+
+    python tests/golden/make_golden.py
+"""
+import inspect
+import json
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+os.chdir(REF)  # reference configs are cwd-relative (ndt1.py:17)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+import transformers  # noqa: E402,F401
+import scipy.signal  # noqa: E402
+import scipy.signal.windows  # noqa: E402
+
+scipy.signal.gaussian = scipy.signal.windows.gaussian  # ndt1.py:87 vs SciPy >= 1.13
+
+
+# editdistance is not installed: exact integer Levenshtein stand-in (eval_bci.py:6,14)
+class _ED:
+    @staticmethod
+    def eval(a, b):
+        a, b = list(a), list(b)
+        prev = list(range(len(b) + 1))
+        for i, x in enumerate(a, 1):
+            cur = [i] + [0] * len(b)
+            for j, y in enumerate(b, 1):
+                cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y))
+            prev = cur
+        return prev[-1]
+
+
+sys.modules["editdistance"] = _ED
+
+from utils.config_utils import update_config  # noqa: E402
+from models.ndt1 import NDT1, create_context_mask  # noqa: E402
+from data_utils.datasets import pad_collate_fn, SpikingDatasetForDecoding  # noqa: E402
+from utils.eval_bci import format_ctc, word_error_count  # noqa: E402
+
+PAD = {k: dict(dim=0, side="right", value=0, truncate=None, min_length=None)
+       for k in ("spikes", "spikes_mask", "spikes_timestamp", "targets", "targets_mask")}
+
+
+def build(over, seed=1):
+    cfg = update_config("configs/ndt1.yaml", over)
+    torch.manual_seed(seed)
+    return NDT1(cfg, method_name="ctc", vocab_size=over.get("_vocab", 41), blank_id=0, zero_infinity=True)
+
+
+def det(over):
+    """same model config but every stochastic op off (parity is defined in this mode)."""
+    o = json.loads(json.dumps(over))
+    e = o.setdefault("encoder", {})
+    e.setdefault("smooth_and_noise", {})["noise"] = False
+    e.setdefault("embedder", {})["dropout"] = 0.0
+    e.setdefault("transformer", {})["dropout"] = 0.0
+    return o
+
+
+def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0):
+    g = np.random.default_rng(seed)
+    rows = []
+    for L, S in zip(lens, tgt_lens):
+        rows.append({"spikes": g.standard_normal((L, n_ch)).astype(np.float32),
+                     "phonemes_idx": g.integers(1, vocab, (S,)).astype(np.int64)})
+    ds = SpikingDatasetForDecoding(rows, targets_name="phonemes_idx")
+    items = [ds[i] for i in range(len(ds))]
+    names = list(inspect.signature(model.forward).parameters)
+    batch, unused = pad_collate_fn(items, model_inputs=names, pad_dict=PAD)
+    return rows, batch, unused
+
+
+def sample_idx(n, k=64):
+    return np.unique(np.linspace(0, n - 1, min(n, k)).astype(np.int64))
+
+
+def summarise(t):
+    a = t.detach().double().reshape(-1).numpy()
+    idx = sample_idx(a.size)
+    return {"sum": float(a.sum()), "abssum": float(np.abs(a).sum()), "idx": idx, "val": a[idx].astype(np.float32)}
+
+
+def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2):
+    over = dict(over)
+    over["_vocab"] = vocab
+    ov = {k: v for k, v in over.items() if k != "_vocab"}
+    model = build({**det(ov), "_vocab": vocab})
+    rows, batch, unused = make_batch(model, lens, n_ch, tgt_lens, vocab)
+    fx = {}
+    for k, v in batch.items():
+        fx["in_" + k] = v.numpy()
+    inter = {}
+
+    def hook(nm):
+        def f(mod, inp, out):
+            inter[nm] = out
+        return f
+
+    enc = model.encoder
+    hs = [enc.smooth_and_noise.register_forward_hook(hook("smooth")),
+          enc.embedder.register_forward_hook(hook("embed")),
+          enc.out_norm.register_forward_hook(hook("out_norm"))]
+    for i, lyr in enumerate(enc.layers):
+        hs.append(lyr.register_forward_hook(hook(f"layer{i}")))
+    # --- eval forward
+    model.eval()
+    with torch.no_grad():
+        out = model(**{k: v.clone() for k, v in batch.items()})
+    fx["eval_loss"] = out.loss.numpy()
+    fx["eval_preds"] = out.preds.numpy()
+    fx["n_examples"] = out.n_examples.numpy()
+    fx["smooth"] = inter["smooth"].numpy() if full else inter["smooth"].numpy()[:, ::7, ::5]
+    fx["embed_x"] = inter["embed"][0].numpy() if full else inter["embed"][0].numpy()[:, :, ::37]
+    fx["token_mask"] = inter["embed"][1].numpy()
+    fx["token_ts"] = inter["embed"][2].numpy()
+    fx["token_lens"] = enc.embedder.get_stacked_lens(batch["spikes_lengths"]).numpy()
+    for i in range(len(enc.layers)):
+        lo = inter[f"layer{i}"].numpy()
+        fx[f"layer{i}_out"] = lo if full else lo[:, :, ::37]
+    fx["out_norm"] = inter["out_norm"].numpy() if full else inter["out_norm"].numpy()[:, :, ::37]
+    # argmax path + margins + decode + PER through the reference's own metric code
+    path = out.preds.argmax(-1)
+    top2 = out.preds.topk(2, -1).values
+    fx["argmax"] = path.numpy()
+    fx["margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    vocab_list = [str(i) for i in range(vocab)]
+    dec = [format_ctc(p, vocab_list, 0) for p in path]
+    tg = [[str(int(x)) for x in r["phonemes_idx"]] for r in rows]
+    errs, n = word_error_count([" ".join(d) for d in dec], [" ".join(t) for t in tg])
+    fx["per_errors"], fx["per_tokens"] = np.int64(errs), np.int64(n)
+    fx["decoded_flat"] = np.array([int(x) for d in dec for x in d], np.int64)
+    fx["decoded_lens"] = np.array([len(d) for d in dec], np.int64)
+    for h in hs:
+        h.remove()
+    # --- train-mode forward/backward (stochastic ops off) + AdamW/OneCycle steps
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=100, max_lr=1e-3, pct_start=0.0, div_factor=25)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for s in range(steps):
+        fx[f"lr_step{s}"] = np.float64(opt.param_groups[0]["lr"])
+        fx[f"beta1_step{s}"] = np.float64(opt.param_groups[0]["betas"][0])
+        out = model(**{k: v.clone() for k, v in batch.items()})
+        out.loss.backward()
+        if s == 0:
+            fx["train_loss"] = out.loss.detach().numpy()
+            for k, p in model.named_parameters():
+                if full:
+                    fx["grad:" + k] = p.grad.numpy().copy()
+                else:
+                    sm = summarise(p.grad)
+                    fx["gsum:" + k] = np.array([sm["sum"], sm["abssum"]])
+                    fx["gidx:" + k], fx["gval:" + k] = sm["idx"], sm["val"]
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        fx[f"loss_step{s}"] = out.loss.detach().numpy()
+    for k, v in model.state_dict().items():
+        if full:
+            fx["w0:" + k] = sd0[k].numpy()
+            fx["w2:" + k] = v.numpy()
+        else:
+            a, b = summarise(sd0[k]), summarise(v)
+            fx["w0sum:" + k] = np.array([a["sum"], a["abssum"]])
+            fx["w0idx:" + k], fx["w0val:" + k] = a["idx"], a["val"]
+            fx["w2val:" + k] = b["val"]
+    fx["config_json"] = np.array(json.dumps(ov))
+    fx["lens"] = np.array(lens)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(name, "loss", float(fx["eval_loss"]), "train_loss", float(fx["train_loss"]), "params",
+          sum(p.numel() for p in model.parameters()), "token_lens", fx["token_lens"], "PER", errs, n)
+
+
+def tiny(**extra):
+    enc = {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+           "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}
+    for k, v in extra.items():
+        enc.setdefault(k, {}).update(v)
+    return {"encoder": enc}
+
+
+def ctc_cases():
+    torch.manual_seed(0)
+    fx = {}
+    cases = [  # (T, V, targets, in_len, tgt_len)
+        ("basic", 12, 6, [[1, 2, 3], [2, 2, 4]], [12, 10], [3, 3]),
+        ("repeat_infeasible", 5, 5, [[1, 1, 1], [1, 2, 0]], [5, 5], [3, 2]),       # 1,1,1 needs 5 frames: feasible edge
+        ("too_short", 4, 5, [[1, 1, 1], [3, 0, 0]], [4, 2], [3, 1]),                # first infeasible -> zero_infinity
+        ("empty_target", 6, 4, [[0, 0], [2, 0]], [6, 3], [0, 1]),
+        ("long", 40, 41, [list(range(1, 16)), [5] * 15], [40, 33], [15, 15]),
+    ]
+    for nm, T, V, tg, il, tl in cases:
+        lp = torch.randn(len(tg), T, V).log_softmax(-1).requires_grad_(True)
+        loss = torch.nn.CTCLoss(reduction="none", blank=0, zero_infinity=True)(
+            lp.transpose(0, 1), torch.tensor(tg), torch.tensor(il), torch.tensor(tl))
+        loss.sum().backward()
+        fx[nm + "_lp"] = lp.detach().numpy(); fx[nm + "_targets"] = np.array(tg); fx[nm + "_il"] = np.array(il)
+        fx[nm + "_tl"] = np.array(tl); fx[nm + "_loss"] = loss.detach().numpy(); fx[nm + "_grad"] = lp.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "ctc_cases.npz"), **fx)
+    print("ctc_cases", {k: v.tolist() for k, v in fx.items() if k.endswith("_loss")})
+
+
+def metric_cases():
+    """format_ctc / word_error_count on hand-made paths (A blank A, repeated blanks, pad frames)."""
+    vocab = [str(i) for i in range(41)]
+    paths = [[3, 0, 3, 3, 0, 0, 5, 5, 0, 3], [0, 0, 0, 0], [7, 7, 7, 7], [1, 2, 1, 2, 0, 2, 0, 1], [4, 0, 0, 0, 0, 0, 0, 0]]
+    tgts = [[3, 3, 5, 3], [1, 2], [7], [1, 2, 1, 2, 2, 1], [4, 9]]
+    fx = {"paths_flat": np.array([x for p in paths for x in p]), "paths_len": np.array([len(p) for p in paths]),
+          "tgts_flat": np.array([x for t in tgts for x in t]), "tgts_len": np.array([len(t) for t in tgts])}
+    dec = [format_ctc(torch.tensor(p), vocab, 0) for p in paths]
+    fx["dec_flat"] = np.array([int(x) for d in dec for x in d]); fx["dec_len"] = np.array([len(d) for d in dec])
+    per = []
+    for d, t in zip(dec, tgts):
+        e, n = word_error_count(" ".join(d), " ".join(str(x) for x in t))
+        per.append((e, n))
+    fx["per"] = np.array(per)
+    np.savez_compressed(os.path.join(OUT, "metric_cases.npz"), **fx)
+    print("metric_cases", per)
+
+
+def misc_cases():
+    fx = {}
+    for f, b in ((-2, -2), (-1, -1), (0, -2), (3, 2), (-2, 0), (0, 0), (5, -1)):
+        fx[f"ctx_{f}_{b}"] = create_context_mask(f, b, 24).numpy()
+    np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
+
+
+if __name__ == "__main__":
+    run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
+    run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
+    run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
+    run_case("g_c1", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}, [100, 70], [10, 6], 64)
+    run_case("g_c2", {}, [600, 450], [60, 40], 256)
+    ctc_cases()
+    metric_cases()
+    misc_cases()
