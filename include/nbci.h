@@ -61,9 +61,10 @@ const char* nbci_last_error(void);
  *     rpb ? (r / rpb) * gstride + (r % rpb) * ld : r * ld
  * so overlapping sliding windows (nn.Unfold, ndt1.py:138) are a view, never materialised.
  * Batch z (0 <= z < batch) adds (z / zdiv) * zs1 + (z % zdiv) * zs2.
- * Epilogue order: acc*alpha (+bias[n]) -> [store C2 = pre-activation] -> act -> dropout ->
- * (+residual[m][n]) -> (+beta*C) -> store C.   splitk > 1: C(f32) += partial via atomics;
- * then only alpha is honoured and the caller zero-fills C first.
+ * Epilogue order: acc*alpha (+bias[n]) -> [store C2 = pre-activation] -> (+residual if
+ * residual_first) -> act -> (*act'(gate)) -> dropout -> (+residual) -> (+beta*C) -> store C.
+ * The dropout draw for an element is rng(seed, site, element offset inside C).
+ * splitk > 1: C(f32) += partial via atomics; then only alpha is honoured.
  */
 typedef struct nbci_operand {
     const void* ptr;
@@ -95,9 +96,131 @@ typedef struct nbci_gemm_desc {
     uint32_t seed, site;   /* dropout stream id */
     const float* residual; /* f32 [M][ldr] or NULL */
     int64_t ldr;
+    const int64_t* residual_rows; /* optional gather: residual row index per output row (nn.Embedding add, ndt1.py:189) */
+    int32_t residual_first;       /* 1: residual is added BEFORE act/dropout */
+    const void* gate;             /* optional [M][ldg] in in_dtype: result *= act'(gate) (GELU/softsign backward) */
+    int64_t ldg;
+    int32_t gate_act;
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * Single kernels (also used on their own by the tests). "dtype" arguments take NBCI_F32 /
+ * NBCI_BF16 and name the activation dtype feeding the GEMMs.
+ */
+
+/* SmoothAndNoise.forward, models/ndt1.py:92-107: depthwise gaussian taps along T ('same',
+ * zero padded) + white / per-trial offset noise (sd = 0 disables). spikes f32 (B,T,N). */
+int nbci_smooth_noise(const float* spikes, void* out, int32_t out_dtype, int32_t B, int32_t T, int32_t N,
+                      const float* taps, int32_t ntaps, float white_sd, float offset_sd, uint32_t seed,
+                      nbci_stream_t stream);
+
+/* nn.LayerNorm(H) forward/backward (ndt1.py:309,311,402). backward: dx (+)= LN'(dy), dw/db += */
+int nbci_layernorm_fwd(const float* x, const float* w, const float* b, void* y, int32_t y_dtype, float* mean,
+                       float* rstd, int32_t M, int32_t H, nbci_stream_t stream);
+int nbci_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                       float* dx, float* dw, float* db, int32_t M, int32_t H, int32_t accumulate_dx,
+                       nbci_stream_t stream);
+
+/* masked softmax + attention-prob dropout of F.scaled_dot_product_attention (ndt1.py:289) with the
+ * mask of ndt1.py:435-437 computed from token validity + context span instead of a (B,T',T') tensor */
+int nbci_softmax_fwd(const float* S, void* P, void* Pd, int32_t p_dtype, const int32_t* token_mask, int32_t B,
+                     int32_t n_heads, int32_t Tp, int32_t ldS, int32_t ldP, int32_t ctx_forward,
+                     int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream);
+int nbci_softmax_bwd(const float* dPd, const void* P, void* dS, int32_t p_dtype, int32_t B, int32_t n_heads,
+                     int32_t Tp, int32_t ldS, int32_t ldP, float drop_p, uint32_t seed, uint32_t site,
+                     nbci_stream_t stream);
+
+/* nn.LogSoftmax(-1) of the decoder (ndt1.py:499) + argmax path (main.py:69) */
+int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V,
+                    nbci_stream_t stream);
+
+/* nn.CTCLoss(reduction="none", blank, zero_infinity) forward + gradient wrt logits (ndt1.py:517,581).
+ * preds (B,Tp,V) f32 log-probs; in_lens int32 (B); targets int64 (B,S); alpha_ws >= nbci_ctc_workspace_floats.
+ * dlogits (B*Tp, ldd) in d_dtype, may be NULL (loss only). */
+int64_t nbci_ctc_workspace_floats(int32_t B, int32_t Tp, int32_t S);
+int nbci_ctc(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int32_t B,
+             int32_t Tp, int32_t V, int32_t S, int32_t blank, int32_t zero_infinity, float* loss, float* alpha_ws,
+             void* dlogits, int32_t d_dtype, int32_t ldd, float grad_scale, nbci_stream_t stream);
+
+/* format_ctc + word_error_count (utils/eval_bci.py:11-48, main.py:68-74), integer exact.
+ * decoded (B,Tp) int32 padded -1, dec_lens (B), errors (B,2) = {edit distance, target tokens};
+ * scratch int32 B*2*(S+2). */
+int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int32_t B, int32_t Tp, int32_t S,
+             int32_t blank, int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch,
+             nbci_stream_t stream);
+
+/* torch.optim.AdamW step over a flat buffer (models/trainer.py:229,340); bc1/bc2 = 1 - beta^t.
+ * p_lp: optional bf16 shadow of p refreshed in the same pass. g is multiplied by grad_scale first
+ * (1/world_size turns an all-reduce SUM into DDP's mean). */
+int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+               float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
+               nbci_stream_t stream);
+
+int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * NDT1-CTC model level. Replaces NeuralEncoder.forward + NDT1.forward(ctc) and their autograd
+ * graph (models/ndt1.py:408-450, 523-589), i.e. what Trainer.train calls at trainer.py:336-339.
+ */
+typedef struct nbci_ndt1_config { /* configs/ndt1.yaml, flattened */
+    int32_t n_channels, input_dim, stack_size, stack_stride, hidden, n_layers, n_heads, inter, vocab, max_F;
+    float smooth_sd;                 /* <= 0: no smoothing */
+    int32_t noise;
+    float white_noise_sd, constant_offset_sd;
+    int32_t embed_act, mlp_act;      /* NBCI_ACT_* */
+    float embed_dropout, dropout;
+    int32_t use_rope;
+    float rope_theta;
+    int32_t context_forward, context_backward;
+    int32_t pos;
+    int32_t blank_id, zero_infinity;
+    int32_t dtype;                   /* NBCI_F32: exact-f32 parity path; NBCI_BF16: bf16 MFMA, f32 accumulate */
+} nbci_ndt1_config;
+
+typedef struct nbci_ndt1_io {
+    int32_t B, T, S;                    /* batch, padded bins, padded target length (0 if no targets) */
+    const float* spikes;                /* (B,T,N) f32, as pad_collate_fn lays it out (datasets.py:236-272) */
+    const int64_t* spikes_mask;         /* (B,T) */
+    const int64_t* spikes_timestamp;    /* (B,T) */
+    const int64_t* spikes_lengths;      /* (B) */
+    const int64_t* targets;             /* (B,S) or NULL */
+    const int64_t* targets_lengths;     /* (B) */
+    const float* rope_cos;              /* (max_F, head) f32 tables when use_rope */
+    const float* rope_sin;
+    int32_t train;                      /* module.training: enables noise + dropout */
+    int32_t want_grad;                  /* also produce d loss / d logits for nbci_ndt1_backward */
+    uint32_t seed;                      /* per-step RNG stream */
+    float grad_scale;                   /* loss scale (1/gradient_accumulation_steps, trainer.py:339) */
+    float* preds;                       /* out (B,T',V) f32 log-probs */
+    float* loss;                        /* out (B) per-sample CTC loss (sum it for NDT1Output.loss) */
+    int32_t* argmax;                    /* out (B,T') greedy path or NULL */
+    void* hidden_out;                   /* out (B,T',H) encoder output in cfg.dtype, or NULL */
+    void* workspace;
+    int64_t workspace_bytes;
+} nbci_ndt1_io;
+
+typedef void* nbci_ndt1_plan;
+
+int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out);
+void nbci_ndt1_plan_destroy(nbci_ndt1_plan plan);
+/* flat parameter buffer: total elements, number of tensors / segments, per-tensor placement.
+ * Names are the reference's state-dict keys; segment 0 = embedder, 1..L = layers, L+1 = head. */
+int64_t nbci_ndt1_param_count(nbci_ndt1_plan plan);
+int32_t nbci_ndt1_num_params(nbci_ndt1_plan plan);
+int32_t nbci_ndt1_num_segments(nbci_ndt1_plan plan);
+int nbci_ndt1_param_info(nbci_ndt1_plan plan, int32_t index, char* name, int32_t name_cap, int64_t* offset,
+                         int64_t* numel, int32_t* rows, int32_t* cols, int32_t* segment);
+int nbci_ndt1_segment_range(nbci_ndt1_plan plan, int32_t seg, int64_t* begin, int64_t* end);
+int64_t nbci_ndt1_workspace_bytes(nbci_ndt1_plan plan, int32_t B, int32_t T, int32_t S);
+int32_t nbci_ndt1_tokens(nbci_ndt1_plan plan, int32_t T);
+int nbci_ndt1_forward(nbci_ndt1_plan plan, const float* params, const void* params_lp, const nbci_ndt1_io* io,
+                      nbci_stream_t stream);
+/* backward over segments seg_hi..seg_lo (descending); gradients ACCUMULATE into grads (flat, f32) */
+int nbci_ndt1_backward(nbci_ndt1_plan plan, const float* params, const void* params_lp, const nbci_ndt1_io* io,
+                       float* grads, int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,9 @@ class GemmDesc(C.Structure):
                 ("batch", C.c_int32), ("zdiv", C.c_int32), ("splitk", C.c_int32),
                 ("alpha", C.c_float), ("beta", C.c_float), ("bias", C.c_void_p),
                 ("act", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
-                ("residual", C.c_void_p), ("ldr", C.c_int64)]
+                ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
+                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32)]
 
 
 _lib = None

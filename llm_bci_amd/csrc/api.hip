@@ -1,12 +1,10 @@
 // api.hip — extern "C" surface of libnbci.so (see include/nbci.h).
-#include "nbci_common.h"
-#include "../../include/nbci.h"
+#include "kernels.h"
 
 namespace nbci {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
-int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream);
 }  // namespace nbci
 
 extern "C" {
@@ -17,6 +15,50 @@ const char* nbci_last_error(void) { return nbci::g_last_error.c_str(); }
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream) {
     if (!d) return nbci::fail(NBCI_EINVAL, "nbci_gemm: null desc");
     return nbci::gemm_launch(*d, (hipStream_t)stream);
+}
+
+int nbci_smooth_noise(const float* spikes, void* out, int32_t out_dtype, int32_t B, int32_t T, int32_t N, const float* taps,
+                      int32_t ntaps, float white_sd, float offset_sd, uint32_t seed, nbci_stream_t stream) {
+    return nbci::smooth_noise_launch(spikes, out, out_dtype, B, T, N, taps, ntaps, white_sd, offset_sd, seed, (hipStream_t)stream);
+}
+int nbci_layernorm_fwd(const float* x, const float* w, const float* b, void* y, int32_t y_dtype, float* mean, float* rstd,
+                       int32_t M, int32_t H, nbci_stream_t stream) {
+    return nbci::layernorm_fwd_launch(x, w, b, y, y_dtype, mean, rstd, M, H, (hipStream_t)stream);
+}
+int nbci_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, float* dx,
+                       float* dw, float* db, int32_t M, int32_t H, int32_t accumulate_dx, nbci_stream_t stream) {
+    return nbci::layernorm_bwd_launch(dy, x, w, mean, rstd, dx, dw, db, M, H, accumulate_dx, (hipStream_t)stream);
+}
+int nbci_softmax_fwd(const float* S, void* P, void* Pd, int32_t p_dtype, const int32_t* token_mask, int32_t B, int32_t n_heads,
+                     int32_t Tp, int32_t ldS, int32_t ldP, int32_t ctx_forward, int32_t ctx_backward, float drop_p,
+                     uint32_t seed, uint32_t site, nbci_stream_t stream) {
+    return nbci::softmax_fwd_launch(S, P, Pd, p_dtype, token_mask, B, n_heads, Tp, ldS, ldP, ctx_forward, ctx_backward, drop_p,
+                                    seed, site, (hipStream_t)stream);
+}
+int nbci_softmax_bwd(const float* dPd, const void* P, void* dS, int32_t p_dtype, int32_t B, int32_t n_heads, int32_t Tp,
+                     int32_t ldS, int32_t ldP, float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream) {
+    return nbci::softmax_bwd_launch(dPd, P, dS, p_dtype, B, n_heads, Tp, ldS, ldP, drop_p, seed, site, (hipStream_t)stream);
+}
+int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V, nbci_stream_t stream) {
+    return nbci::logsoftmax_launch(logits, ldl, preds, argmax, M, V, (hipStream_t)stream);
+}
+int64_t nbci_ctc_workspace_floats(int32_t B, int32_t Tp, int32_t S) { return (int64_t)nbci::ctc_alpha_floats(B, Tp, S); }
+int nbci_ctc(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int32_t B, int32_t Tp,
+             int32_t V, int32_t S, int32_t blank, int32_t zero_infinity, float* loss, float* alpha_ws, void* dlogits,
+             int32_t d_dtype, int32_t ldd, float grad_scale, nbci_stream_t stream) {
+    return nbci::ctc_launch(preds, targets, in_lens, tgt_lens, B, Tp, V, S, blank, zero_infinity, loss, alpha_ws, dlogits, d_dtype,
+                            ldd, grad_scale, (hipStream_t)stream);
+}
+int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int32_t B, int32_t Tp, int32_t S, int32_t blank,
+             int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, nbci_stream_t stream) {
+    return nbci::per_launch(argmax, targets, tgt_lens, B, Tp, S, blank, decoded, dec_lens, errors, scratch, (hipStream_t)stream);
+}
+int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, float bc1, float bc2, float grad_scale, nbci_stream_t stream) {
+    return nbci::adamw_launch(p, g, m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream);
+}
+int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream) {
+    return nbci::cast_launch(in, out, out_dtype, n, (hipStream_t)stream);
 }
 
 }  // extern "C"

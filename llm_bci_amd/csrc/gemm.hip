@@ -62,6 +62,10 @@ struct GemmK {
     int act;
     float drop_scale; unsigned drop_thr; unsigned seed, site;
     const float* residual; long long ldr;
+    const long long* residual_rows;  // optional gather: residual row for output row m
+    int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
+    const void* gate; long long ldg; int gate_act;  // v *= act'(gate[m][n]) (gate in the input dtype)
+    int gate_bf16;
     int cvec;  // vector C/residual accesses legal
 };
 
@@ -317,18 +321,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
                     else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = v[e]; }
                 }
             }
+            if (d.residual && d.residual_first) {
+                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+                const float* r = d.residual + rr * d.ldr + n;
+                if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+            }
             if (d.act != ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
             }
+            if (d.gate) {
+                const long long gi = (long long)m * d.ldg + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < d.N) {
+                        const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
+                        v[e] *= act_bwd(d.gate_act, gv);
+                    }
+                }
+            }
             if (d.drop_thr) {
-                const unsigned idx = (unsigned)(((long long)z * d.M + m) * d.N + n);
+                // dropout stream index = element offset inside C (so a head-batched GEMM that writes
+                // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
+                const unsigned idx = (unsigned)cidx;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     v[e] = (rng_u32(d.seed, d.site, idx + e) >= d.drop_thr) ? v[e] * d.drop_scale : 0.f;
             }
-            if (d.residual) {
-                const float* r = d.residual + (long long)m * d.ldr + n;
+            if (d.residual && !d.residual_first) {
+                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+                const float* r = d.residual + rr * d.ldr + n;
                 if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
                 else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
             }
@@ -385,7 +408,7 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     const int splitk = d.splitk > 1 ? d.splitk : 1;
     NBCI_REQUIRE(!(splitk > 1 && batch > 1), NBCI_EINVAL, "gemm: splitk and batch are exclusive");
     NBCI_REQUIRE(!(splitk > 1 && d.c_dtype != NBCI_F32), NBCI_EINVAL, "gemm: splitk needs f32 C");
-    NBCI_REQUIRE(!(splitk > 1 && (d.bias || d.act || d.residual || d.C2 || d.drop_p > 0.f)), NBCI_EINVAL,
+    NBCI_REQUIRE(!(splitk > 1 && (d.bias || d.act || d.residual || d.C2 || d.gate || d.drop_p > 0.f)), NBCI_EINVAL,
                  "gemm: splitk supports alpha only");
     NBCI_REQUIRE(!(d.beta != 0.f && d.c_dtype != NBCI_F32), NBCI_EINVAL, "gemm: beta needs f32 C");
     NBCI_REQUIRE(d.drop_p >= 0.f && d.drop_p < 1.f, NBCI_EINVAL, "gemm: drop_p out of [0,1)");
@@ -413,6 +436,8 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     k.drop_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
     k.seed = d.seed; k.site = d.site;
     k.residual = d.residual; k.ldr = d.ldr;
+    k.residual_rows = (const long long*)d.residual_rows; k.residual_first = d.residual_first;
+    k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16;
     // vector epilogue: 4 consecutive n at 16-byte (f32) / 8-byte (bf16) alignment
     bool cvec = (d.ldc % 4 == 0) && (d.czs1 % 4 == 0) && (d.czs2 % 4 == 0) && (((uintptr_t)d.C) % 16 == 0);
     if (d.C2) cvec = cvec && (((uintptr_t)d.C2) % 16 == 0);

@@ -1,0 +1,71 @@
+// kernels.h — internal launch API of the non-GEMM kernels (all HBM-bound, wave64, gfx950).
+// "act dtype" = dtype of activations that feed GEMMs: NBCI_F32 (parity path) or NBCI_BF16.
+#pragma once
+#include "nbci_common.h"
+#include "../../include/nbci.h"
+
+namespace nbci {
+
+int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream);
+
+// models/ndt1.py:92-107 — depthwise gaussian smoothing along T ('same', zero padded) + train noise
+int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, int T, int N, const float* taps,
+                        int ntaps, float white_sd, float offset_sd, uint32_t seed, hipStream_t s);
+
+// models/ndt1.py:181-183,207-208 — token mask (prod over window), first-T' timestamps, stacked lens
+int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp,
+                      int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s);
+
+// nn.LayerNorm (eps 1e-5, affine) forward: x f32 (M,H) -> y act dtype, saves mean/rstd
+int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean,
+                         float* rstd, int M, int H, hipStream_t s);
+// backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
+int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s);
+
+// masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437),
+// writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP
+int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int32_t* tmask, int B, int nh, int Tp,
+                       int ldS, int ldP, int ctx_fwd, int ctx_bwd, float drop_p, uint32_t seed, uint32_t site,
+                       hipStream_t s);
+// dS = P * (dP - sum(dP*P)) with dP = dPd * keepmask; dPd f32 (ld = ldS), dS act dtype (ld = ldP)
+int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, int B, int nh, int Tp, int ldS,
+                       int ldP, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+
+// out(act dtype) = in(f32) * keepmask(site)   (p = 0: plain cast)
+int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float drop_p, uint32_t seed,
+                    uint32_t site, hipStream_t s);
+// out[n] += sum_m in[m][n]  (bias gradients)
+int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s);
+
+// stack backward: dy[b,t,c] = sum_j dwin[b,j,(t - stride*j)*D + c]; dpre = dy * act'(y) -> act dtype
+int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype, int B, int T, int Tp, int D,
+                          int size, int stride, int act, hipStream_t s);
+// dpos[tts[row]][:] += dx[row][:] * keepmask  (nn.Embedding backward + embed dropout)
+int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
+                   uint32_t site, hipStream_t s);
+
+// RoPE on the q and k thirds of a packed (M, 3H) qkv buffer, in place (ndt1.py:62-71); inverse = backward
+int rope_launch(void* qkv, int dtype, const int64_t* tts, const float* cos_t, const float* sin_t, int M, int H,
+                int nh, int inverse, hipStream_t s);
+
+// log-softmax over V of logits (M, ldl) f32 -> preds (M, V) f32 contiguous, argmax path int32 (M)
+int logsoftmax_launch(const float* logits, int ldl, float* preds, int32_t* argmax, int M, int V, hipStream_t s);
+// CTC (torch.nn.CTCLoss(reduction="none", blank, zero_infinity), ndt1.py:517,581)
+// alpha_ws: f32 workspace B * Tp * (2*S+1). dlogits (B*Tp, ldd) act dtype = grad_scale * (softmax - occupancy)
+int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens,
+               int B, int Tp, int V, int S, int blank, int zero_infinity, float* loss, float* alpha_ws,
+               void* dlogits, int d_dtype, int ldd, float grad_scale, hipStream_t s);
+size_t ctc_alpha_floats(int B, int Tp, int S);
+
+// greedy decode (reference's format_ctc, utils/eval_bci.py:41-48) + Levenshtein vs targets (main.py:68-74)
+int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int B, int Tp, int S,
+               int blank, int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, hipStream_t s);
+
+// fused AdamW over a flat buffer (torch.optim.AdamW semantics; models/trainer.py:229,340)
+int adamw_launch(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s);
+
+int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s);
+
+}  // namespace nbci

@@ -1,0 +1,798 @@
+// kernels.hip — every non-GEMM kernel of the NDT1-CTC train step. All are HBM/latency-bound:
+// wave64 shuffles for row reductions, 16-byte accesses where layout allows, no LDS staging
+// beyond small cross-wave reductions. See kernels.h for the reference lines each replaces.
+#include "kernels.h"
+#include <algorithm>
+
+namespace nbci {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, long long i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, long long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long long i) { return bf2f(p[i]); }
+template <typename T> __device__ __forceinline__ void stf(T* p, long long i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long long i, float v) { p[i] = f2bf(v); }
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+#define DISPATCH_DTYPE(dt, T, ...)                                   \
+    do {                                                             \
+        if ((dt) == NBCI_BF16) { using T = bf16_t; __VA_ARGS__; }    \
+        else { using T = float; __VA_ARGS__; }                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// smoothing + noise
+// ------------------------------------------------------------------------------------------
+constexpr int SM_TCHUNK = 32;
+constexpr int SM_MAXTAPS = 64;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void smooth_noise_kernel(const float* __restrict__ in, TO* __restrict__ out, int B,
+                                                           int T, int N, const float* __restrict__ taps, int ntaps,
+                                                           float white_sd, float offset_sd, uint32_t seed) {
+    __shared__ float stap[SM_MAXTAPS];
+    if (threadIdx.x < ntaps) stap[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= (long long)B * N) return;
+    const int b = (int)(col / N), n = (int)(col % N);
+    const int half = (ntaps - 1) / 2;
+    const int t0 = blockIdx.y * SM_TCHUNK;
+    const float* src = in + (long long)b * T * N + n;
+    float off = 0.f;
+    if (offset_sd != 0.f) off = offset_sd * rng_normal(seed, 2u, (uint32_t)(b * N + n));
+    for (int t = t0; t < min(T, t0 + SM_TCHUNK); ++t) {
+        float acc = 0.f;
+        if (ntaps > 0) {
+            for (int i = 0; i < ntaps; ++i) {
+                const int tt = t + i - half;
+                if (tt >= 0 && tt < T) acc += stap[i] * src[(long long)tt * N];
+            }
+        } else {
+            acc = src[(long long)t * N];
+        }
+        const long long o = ((long long)b * T + t) * N + n;
+        if (white_sd != 0.f) acc += white_sd * rng_normal(seed, 1u, (uint32_t)o);
+        acc += off;
+        stf<TO>(out, o, acc);
+    }
+}
+
+int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, int T, int N, const float* taps,
+                        int ntaps, float white_sd, float offset_sd, uint32_t seed, hipStream_t s) {
+    NBCI_REQUIRE(ntaps <= SM_MAXTAPS, NBCI_ESHAPE, "smooth: too many taps (max 64)");
+    dim3 grid((unsigned)(((long long)B * N + 255) / 256), (T + SM_TCHUNK - 1) / SM_TCHUNK);
+    DISPATCH_DTYPE(out_dtype, TO,
+                   hipLaunchKernelGGL((smooth_noise_kernel<TO>), grid, dim3(256), 0, s, spikes, (TO*)out, B, T, N, taps,
+                                      ntaps, white_sd, offset_sd, seed));
+    return check_launch("smooth_noise");
+}
+
+// ------------------------------------------------------------------------------------------
+// token prep
+// ------------------------------------------------------------------------------------------
+__global__ void token_prep_kernel(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp,
+                                  int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * Tp) {
+        const int b = i / Tp, j = i % Tp;
+        int64_t prod = 1;
+        for (int r = 0; r < size; ++r) prod *= mask[(long long)b * T + j * stride + r];
+        tmask[i] = prod != 0 ? 1 : 0;
+        tts[i] = ts[(long long)b * T + j];
+    }
+    if (i < B) {
+        // (1 + (len - size) / stride) in floating point, truncating cast (ndt1.py:208)
+        const double v = 1.0 + ((double)lens[i] - (double)size) / (double)stride;
+        tlens[i] = (int32_t)v;
+    }
+}
+
+int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp, int size,
+                      int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s) {
+    const int n = max(B * Tp, B);
+    hipLaunchKernelGGL(token_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, ts, lens, B, T, Tp, size, stride,
+                       tmask, tts, tlens);
+    return check_launch("token_prep");
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm
+// ------------------------------------------------------------------------------------------
+template <int NV, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, TO* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long long)row * H;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        v[k] = (c < H) ? *(const float4*)(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    const float mu = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < H) {
+            const float a = v[k].x - mu, bb = v[k].y - mu, cc = v[k].z - mu, dd = v[k].w - mu;
+            q += a * a + bb * bb + cc * cc + dd * dd;
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < H) {
+            const float4 ww = *(const float4*)(w + c), bv = *(const float4*)(b + c);
+            const long long o = (long long)row * H + c;
+            stf<TO>(y, o + 0, (v[k].x - mu) * rs * ww.x + bv.x);
+            stf<TO>(y, o + 1, (v[k].y - mu) * rs * ww.y + bv.y);
+            stf<TO>(y, o + 2, (v[k].z - mu) * rs * ww.z + bv.z);
+            stf<TO>(y, o + 3, (v[k].w - mu) * rs * ww.w + bv.w);
+        }
+    }
+}
+
+template <typename TO>
+static void ln_fwd_dispatch(int nv, dim3 g, hipStream_t s, const float* x, const float* w, const float* b, TO* y,
+                            float* mean, float* rstd, int M, int H) {
+    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
+    else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
+    else hipLaunchKernelGGL((ln_fwd_kernel<16, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
+}
+
+int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
+                         int M, int H, hipStream_t s) {
+    NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "layernorm: hidden must be a multiple of 4 and <= 4096");
+    const int nv = (H + 255) / 256;
+    dim3 g((M + 3) / 4);
+    DISPATCH_DTYPE(y_dtype, TO, ln_fwd_dispatch<TO>(nv, g, s, x, w, b, (TO*)y, mean, rstd, M, H));
+    return check_launch("layernorm_fwd");
+}
+
+constexpr int LNB_ROWS = 32;  // rows per block in the backward
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dw, float* __restrict__ db, int M, int H,
+                                                     int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][NV*256]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 gw[NV], gb[NV], ww[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gb[k] = gw[k];
+        ww[k] = (c < H) ? *(const float4*)(w + c) : gw[k];
+    }
+    const float invH = 1.0f / (float)H;
+    const int r0 = blockIdx.x * LNB_ROWS;
+    for (int r = r0 + wv; r < min(M, r0 + LNB_ROWS); r += 4) {
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[NV], dh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            if (c < H) {
+                const float4 xv = *(const float4*)(x + (long long)r * H + c);
+                const float4 dv = *(const float4*)(dy + (long long)r * H + c);
+                xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                dh[k] = make_float4(dv.x * ww[k].x, dv.y * ww[k].y, dv.z * ww[k].z, dv.w * ww[k].w);
+                s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
+                s2 += dh[k].x * xh[k].x + dh[k].y * xh[k].y + dh[k].z * xh[k].z + dh[k].w * xh[k].w;
+                gw[k].x += dv.x * xh[k].x; gw[k].y += dv.y * xh[k].y; gw[k].z += dv.z * xh[k].z; gw[k].w += dv.w * xh[k].w;
+                gb[k].x += dv.x; gb[k].y += dv.y; gb[k].z += dv.z; gb[k].w += dv.w;
+            }
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            if (c < H) {
+                float4 o = make_float4(rs * (dh[k].x - s1 - xh[k].x * s2), rs * (dh[k].y - s1 - xh[k].y * s2),
+                                       rs * (dh[k].z - s1 - xh[k].z * s2), rs * (dh[k].w - s1 - xh[k].w * s2));
+                float4* p = (float4*)(dx + (long long)r * H + c);
+                if (accumulate) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                *p = o;
+            }
+        }
+    }
+    // cross-wave reduce of the per-column partials, then one atomic per column per block
+    const int W = NV * 256;
+    if (wv > 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            *(float4*)(red + ((wv - 1) * 2 + 0) * W + (k * 64 + lane) * 4) = gw[k];
+            *(float4*)(red + ((wv - 1) * 2 + 1) * W + (k * 64 + lane) * 4) = gb[k];
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            if (c < H) {
+                float4 a = gw[k], bsum = gb[k];
+                for (int o = 0; o < 3; ++o) {
+                    const float4 a2 = *(const float4*)(red + (o * 2 + 0) * W + c);
+                    const float4 b2 = *(const float4*)(red + (o * 2 + 1) * W + c);
+                    a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+                    bsum.x += b2.x; bsum.y += b2.y; bsum.z += b2.z; bsum.w += b2.w;
+                }
+                atomicAdd(dw + c + 0, a.x); atomicAdd(dw + c + 1, a.y); atomicAdd(dw + c + 2, a.z); atomicAdd(dw + c + 3, a.w);
+                atomicAdd(db + c + 0, bsum.x); atomicAdd(db + c + 1, bsum.y); atomicAdd(db + c + 2, bsum.z); atomicAdd(db + c + 3, bsum.w);
+            }
+        }
+    }
+}
+
+int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s) {
+    NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
+    const int nv = (H + 255) / 256;
+    dim3 g((M + LNB_ROWS - 1) / LNB_ROWS);
+#define LNB(NVV)                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 3 * 2 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
+                       rstd, dx, dw, db, M, H, accumulate_dx)
+    if (nv <= 1) LNB(1);
+    else if (nv <= 4) LNB(4);
+    else LNB(8);
+#undef LNB
+    return check_launch("layernorm_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// masked softmax (+ attention-prob dropout) forward / backward, one wave per (b, head, query) row
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ctx_allowed(int i, int j, int f, int bk) {
+    // create_context_mask (ndt1.py:30-41): allowed iff j - i <= f' and i - j <= b' (-2 => unbounded)
+    if (f >= -1 && j - i > f) return false;
+    if (bk >= -1 && i - j > bk) return false;
+    return true;
+}
+
+template <int NV, typename TP>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, TP* __restrict__ P,
+                                                          TP* __restrict__ Pd, const int32_t* __restrict__ tmask,
+                                                          int rows, int nh, int Tp, int ldS, int ldP, int cf, int cb,
+                                                          unsigned thr, float dscale, uint32_t seed, uint32_t site) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int i = row % Tp, bh = row / Tp, b = bh / nh;
+    const float* sr = S + (long long)row * ldS;
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = k * 64 + lane;
+        float val = -INFINITY;
+        if (j < Tp) {
+            const bool ok = (j == i) || (ctx_allowed(i, j, cf, cb) && tmask[b * Tp + j] != 0);
+            if (ok) val = sr[j];
+        }
+        v[k] = val;
+        mx = fmaxf(mx, val);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = (v[k] == -INFINITY) ? 0.f : expf(v[k] - mx);
+        sum += v[k];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    TP* pr = P + (long long)row * ldP;
+    TP* pdr = Pd + (long long)row * ldP;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = k * 64 + lane;
+        if (j < ldP) {
+            float p = (j < Tp) ? v[k] * inv : 0.f;
+            stf<TP>(pr, j, p);
+            if (thr && j < Tp) {
+                const unsigned idx = (unsigned)((long long)row * Tp + j);
+                p = (rng_u32(seed, site, idx) >= thr) ? p * dscale : 0.f;
+            }
+            stf<TP>(pdr, j, p);
+        }
+    }
+}
+
+int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int32_t* tmask, int B, int nh, int Tp,
+                       int ldS, int ldP, int ctx_fwd, int ctx_bwd, float drop_p, uint32_t seed, uint32_t site,
+                       hipStream_t s) {
+    NBCI_REQUIRE(ldP <= 1024 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 1024 tokens");
+    const int rows = B * nh * Tp;
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    dim3 g((rows + 3) / 4);
+    DISPATCH_DTYPE(p_dtype, TP, {
+        if (ldP <= 256)
+            hipLaunchKernelGGL((softmax_fwd_kernel<4, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
+                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, seed, site);
+        else
+            hipLaunchKernelGGL((softmax_fwd_kernel<16, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
+                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, seed, site);
+    });
+    return check_launch("softmax_fwd");
+}
+
+template <int NV, typename TP>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dPd, const TP* __restrict__ P,
+                                                          TP* __restrict__ dS, int rows, int Tp, int ldS, int ldP,
+                                                          unsigned thr, float dscale, uint32_t seed, uint32_t site) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float p[NV], dp[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = k * 64 + lane;
+        p[k] = 0.f; dp[k] = 0.f;
+        if (j < Tp) {
+            p[k] = ldf<TP>(P, (long long)row * ldP + j);
+            float g = dPd[(long long)row * ldS + j];
+            if (thr) {
+                const unsigned idx = (unsigned)((long long)row * Tp + j);
+                g = (rng_u32(seed, site, idx) >= thr) ? g * dscale : 0.f;
+            }
+            dp[k] = g;
+            dot += g * p[k];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = k * 64 + lane;
+        if (j < ldP) stf<TP>(dS, (long long)row * ldP + j, (j < Tp) ? p[k] * (dp[k] - dot) : 0.f);
+    }
+}
+
+int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, int B, int nh, int Tp, int ldS, int ldP,
+                       float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(ldP <= 1024 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 1024 tokens");
+    const int rows = B * nh * Tp;
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    dim3 g((rows + 3) / 4);
+    DISPATCH_DTYPE(p_dtype, TP, {
+        if (ldP <= 256)
+            hipLaunchKernelGGL((softmax_bwd_kernel<4, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
+                               ldP, thr, dscale, seed, site);
+        else
+            hipLaunchKernelGGL((softmax_bwd_kernel<16, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
+                               ldP, thr, dscale, seed, site);
+    });
+    return check_launch("softmax_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// dropout-cast, cast, colsum
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n,
+                                                       unsigned thr, float dscale, uint32_t seed, uint32_t site) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 v = *(const float4*)(in + i);
+            if (thr) {
+                v.x = (rng_u32(seed, site, (unsigned)i + 0) >= thr) ? v.x * dscale : 0.f;
+                v.y = (rng_u32(seed, site, (unsigned)i + 1) >= thr) ? v.y * dscale : 0.f;
+                v.z = (rng_u32(seed, site, (unsigned)i + 2) >= thr) ? v.z * dscale : 0.f;
+                v.w = (rng_u32(seed, site, (unsigned)i + 3) >= thr) ? v.w * dscale : 0.f;
+            }
+            stf<TO>(out, i, v.x); stf<TO>(out, i + 1, v.y); stf<TO>(out, i + 2, v.z); stf<TO>(out, i + 3, v.w);
+        } else {
+            for (long long e = i; e < n; ++e) {
+                float v = in[e];
+                if (thr) v = (rng_u32(seed, site, (unsigned)e) >= thr) ? v * dscale : 0.f;
+                stf<TO>(out, e, v);
+            }
+        }
+    }
+}
+
+int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float drop_p, uint32_t seed, uint32_t site,
+                    hipStream_t s) {
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const long long blocks = std::min<long long>(2048, (n / 4 + 255) / 256 + 1);
+    DISPATCH_DTYPE(out_dtype, TO,
+                   hipLaunchKernelGGL((dropcast_kernel<TO>), dim3((unsigned)blocks), dim3(256), 0, s, in, (TO*)out,
+                                      (long long)n, thr, dscale, seed, site));
+    return check_launch("dropcast");
+}
+
+int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s) {
+    return dropcast_launch(in, out, out_dtype, n, 0.f, 0, 0, s);
+}
+
+constexpr int CS_ROWS = 256;  // rows per block
+
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, long long ld, int M, int N,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rq = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * CS_ROWS;
+    float acc = 0.f;
+    if (c < N)
+        for (int r = r0 + rq; r < min(M, r0 + CS_ROWS); r += 4) acc += ldf<TI>(in, (long long)r * ld + c);
+    red[rq][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rq == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s) {
+    dim3 g((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS);
+    DISPATCH_DTYPE(in_dtype, TI,
+                   hipLaunchKernelGGL((colsum_kernel<TI>), g, dim3(256), 0, s, (const TI*)in, (long long)ld, M, N, out));
+    return check_launch("colsum");
+}
+
+// ------------------------------------------------------------------------------------------
+// stack backward: col2im over the overlapping windows fused with the embed activation gradient
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_bwd_from_output(int act, float y) {
+    switch (act) {
+        case ACT_SOFTSIGN: { const float d = 1.0f - fabsf(y); return d * d; }  // y = x/(1+|x|) => 1/(1+|x|) = 1-|y|
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_actgrad_kernel(const T* __restrict__ dwin, const T* __restrict__ y,
+                                                             T* __restrict__ dpre, int B, int Tt, int Tp, int D, int size,
+                                                             int stride, int act) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * Tt * D;
+    if (i >= total) return;
+    const int c = (int)(i % D);
+    const int t = (int)((i / D) % Tt);
+    const int b = (int)(i / ((long long)D * Tt));
+    int jmax = t / stride;
+    if (jmax > Tp - 1) jmax = Tp - 1;
+    int jmin = (t - size + 1 + stride - 1);
+    jmin = jmin > 0 ? jmin / stride : 0;
+    float acc = 0.f;
+    for (int j = jmin; j <= jmax; ++j) {
+        const int r = t - stride * j;  // 0 <= r < size
+        acc += ldf<T>(dwin, ((long long)b * Tp + j) * ((long long)size * D) + (long long)r * D + c);
+    }
+    stf<T>(dpre, i, acc * act_bwd_from_output(act, ldf<T>(y, i)));
+}
+
+int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype, int B, int T, int Tp, int D, int size,
+                          int stride, int act, hipStream_t s) {
+    NBCI_REQUIRE(act != ACT_GELU, NBCI_EINVAL, "embed activation gelu is not supported (needs the pre-activation)");
+    const long long total = (long long)B * T * D;
+    DISPATCH_DTYPE(dtype, TT,
+                   hipLaunchKernelGGL((col2im_actgrad_kernel<TT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                      (const TT*)dwin, (const TT*)y, (TT*)dpre, B, T, Tp, D, size, stride, act));
+    return check_launch("col2im_actgrad");
+}
+
+__global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tts,
+                                                      float* __restrict__ dpos, int M, int H, unsigned thr, float dscale,
+                                                      uint32_t seed, uint32_t site) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), c = (int)(i % H);
+    float v = dx[i];
+    if (thr) v = (rng_u32(seed, site, (unsigned)i) >= thr) ? v * dscale : 0.f;
+    if (v != 0.f) atomicAdd(dpos + tts[row] * H + c, v);
+}
+
+int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
+                   uint32_t site, hipStream_t s) {
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const long long total = (long long)M * H;
+    hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, tts, dpos, M, H, thr,
+                       dscale, seed, site);
+    return check_launch("posgrad");
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE (optional; off in configs/ndt1.yaml:60)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ tts,
+                                                   const float* __restrict__ cos_t, const float* __restrict__ sin_t, int M,
+                                                   int H, int nh, int inverse) {
+    const int hd = H / nh, half = hd / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)M * 2 * nh * half;  // q and k thirds
+    if (i >= total) return;
+    const int d = (int)(i % half);
+    const int h = (int)((i / half) % nh);
+    const int which = (int)((i / ((long long)half * nh)) % 2);
+    const int row = (int)(i / ((long long)half * nh * 2));
+    const long long pos = tts[row];
+    const float c1 = cos_t[pos * hd + d], s1 = sin_t[pos * hd + d];
+    const float c2 = cos_t[pos * hd + d + half], s2 = sin_t[pos * hd + d + half];
+    const long long o = (long long)row * 3 * H + (long long)which * H + h * hd + d;
+    const float x1 = ldf<T>(qkv, o), x2 = ldf<T>(qkv, o + half);
+    float o1, o2;
+    if (!inverse) { o1 = x1 * c1 - x2 * s1; o2 = x2 * c2 + x1 * s2; }
+    else { o1 = x1 * c1 + x2 * s2; o2 = x2 * c2 - x1 * s1; }
+    stf<T>(qkv, o, o1);
+    stf<T>(qkv, o + half, o2);
+}
+
+int rope_launch(void* qkv, int dtype, const int64_t* tts, const float* cos_t, const float* sin_t, int M, int H, int nh,
+                int inverse, hipStream_t s) {
+    const long long total = (long long)M * nh * (H / nh);
+    DISPATCH_DTYPE(dtype, TT,
+                   hipLaunchKernelGGL((rope_kernel<TT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (TT*)qkv,
+                                      tts, cos_t, sin_t, M, H, nh, inverse));
+    return check_launch("rope");
+}
+
+// ------------------------------------------------------------------------------------------
+// head: log-softmax + argmax; CTC; greedy decode + edit distance
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_kernel(const float* __restrict__ logits, int ldl,
+                                                         float* __restrict__ preds, int32_t* __restrict__ argmax, int M,
+                                                         int V) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* lr = logits + (long long)row * ldl;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) {
+        const float v = lr[j];
+        if (v > mx) { mx = v; am = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    float sum = 0.f;
+    for (int j = lane; j < V; j += 64) sum += expf(lr[j] - mx);
+    const float lse = logf(wave_sum(sum));
+    for (int j = lane; j < V; j += 64) preds[(long long)row * V + j] = (lr[j] - mx) - lse;
+    if (argmax && lane == 0) argmax[row] = am;
+}
+
+int logsoftmax_launch(const float* logits, int ldl, float* preds, int32_t* argmax, int M, int V, hipStream_t s) {
+    hipLaunchKernelGGL(logsoftmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, ldl, preds, argmax, M, V);
+    return check_launch("logsoftmax");
+}
+
+__device__ __forceinline__ float log_add3(float a, float b, float c) {
+    const float m = fmaxf(fmaxf(a, b), c);
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+size_t ctc_alpha_floats(int B, int Tp, int S) { return (size_t)B * Tp * (2 * (size_t)S + 1); }
+
+// One workgroup per sample. alpha is kept in global memory (B, Tp, 2S+1); beta lives in LDS.
+template <typename TD>
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ preds, const int64_t* __restrict__ targets,
+                                                  const int32_t* __restrict__ in_lens, const int64_t* __restrict__ tgt_lens,
+                                                  int Tp, int V, int S, int blank, int zero_inf, float* __restrict__ loss,
+                                                  float* __restrict__ alpha_ws, TD* __restrict__ dlogits, int ldd,
+                                                  float grad_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Lmax = 2 * S + 1;
+    float* buf0 = sm;                 // [Lmax]
+    float* buf1 = sm + Lmax;          // [Lmax]
+    float* occ = sm + 2 * Lmax;       // [V]
+    int* ext = (int*)(sm + 2 * Lmax + V);  // [Lmax]
+    __shared__ float s_nll;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int Tb = in_lens[b];
+    if (Tb > Tp) Tb = Tp;
+    if (Tb < 0) Tb = 0;
+    int Sb = (int)tgt_lens[b];
+    if (Sb > S) Sb = S;
+    const int L = 2 * Sb + 1;
+    const float* lp = preds + (long long)b * Tp * V;
+    float* aw = alpha_ws + (long long)b * Tp * Lmax;
+    for (int s = tid; s < L; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * S + (s >> 1)] : blank;
+    __syncthreads();
+    // ---- alpha
+    float* prev = buf0; float* cur = buf1;
+    if (Tb > 0) {
+        for (int s = tid; s < L; s += 256) {
+            const float v = (s < 2) ? lp[ext[s]] : -INFINITY;
+            prev[s] = v; aw[s] = v;
+        }
+        __syncthreads();
+        for (int t = 1; t < Tb; ++t) {
+            for (int s = tid; s < L; s += 256) {
+                const float a0 = prev[s];
+                const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+                const float a2 = (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+                const float v = log_add3(a0, a1, a2) + lp[(long long)t * V + ext[s]];
+                cur[s] = v; aw[(long long)t * Lmax + s] = v;
+            }
+            __syncthreads();
+            float* tmp = prev; prev = cur; cur = tmp;
+        }
+    }
+    if (tid == 0) {
+        float ll;
+        if (Tb > 0) {
+            const float a = prev[L - 1], c = L > 1 ? prev[L - 2] : -INFINITY;
+            const float m = fmaxf(a, c);
+            ll = (m == -INFINITY) ? -INFINITY : m + logf(expf(a - m) + expf(c - m));
+        } else {
+            ll = (Sb == 0) ? 0.f : -INFINITY;
+        }
+        s_nll = -ll;
+    }
+    __syncthreads();
+    const float nll = s_nll;
+    const bool finite = nll < INFINITY;
+    if (tid == 0) loss[b] = finite ? nll : (zero_inf ? 0.f : INFINITY);
+    if (!dlogits) return;
+    // rows beyond the input length (and whole infeasible samples) get zero gradient
+    const int tz = finite ? Tb : 0;
+    for (long long i = tid + (long long)tz * ldd; i < (long long)Tp * ldd; i += 256) stf<TD>(dlogits, (long long)b * Tp * ldd + i, 0.f);
+    if (!finite || Tb == 0) return;
+    // ---- beta + occupancy
+    prev = buf0; cur = buf1;
+    __syncthreads();
+    for (int t = Tb - 1; t >= 0; --t) {
+        for (int c = tid; c < V; c += 256) occ[c] = 0.f;
+        for (int s = tid; s < L; s += 256) {
+            float v;
+            if (t == Tb - 1) {
+                v = (s >= L - 2) ? lp[(long long)t * V + ext[s]] : -INFINITY;
+            } else {
+                const float b0 = prev[s];
+                const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+                const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != ext[s]) ? prev[s + 2] : -INFINITY;
+                v = log_add3(b0, b1, b2) + lp[(long long)t * V + ext[s]];
+            }
+            cur[s] = v;
+        }
+        __syncthreads();
+        for (int s = tid; s < L; s += 256) {
+            const float ab = aw[(long long)t * Lmax + s] + cur[s];
+            if (ab > -INFINITY) {
+                const float g = expf(ab - lp[(long long)t * V + ext[s]] + nll);  // posterior of state s at t
+                atomicAdd(&occ[ext[s]], g);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < ldd; c += 256) {
+            const float v = (c < V) ? (expf(lp[(long long)t * V + c]) - occ[c]) * grad_scale : 0.f;
+            stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
+        }
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
+    }
+}
+
+int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int B, int Tp,
+               int V, int S, int blank, int zero_infinity, float* loss, float* alpha_ws, void* dlogits, int d_dtype,
+               int ldd, float grad_scale, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (2 * S + 1) + V + (2 * S + 1)) * sizeof(float);
+    NBCI_REQUIRE(lds <= 60000, NBCI_ESHAPE, "ctc: target too long for the LDS-resident recursion");
+    NBCI_REQUIRE(blank >= 0 && blank < V, NBCI_EINVAL, "ctc: blank id out of range");
+    DISPATCH_DTYPE(d_dtype, TD,
+                   hipLaunchKernelGGL((ctc_kernel<TD>), dim3(B), dim3(256), lds, s, preds, targets, in_lens, tgt_lens, Tp, V,
+                                      S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale));
+    return check_launch("ctc");
+}
+
+// greedy decode with the reference's collapse rule + token Levenshtein; one lane per sample
+__global__ void per_kernel(const int32_t* __restrict__ argmax, const int64_t* __restrict__ targets,
+                           const int64_t* __restrict__ tgt_lens, int B, int Tp, int S, int blank,
+                           int32_t* __restrict__ decoded, int32_t* __restrict__ dec_lens, int32_t* __restrict__ errors,
+                           int32_t* __restrict__ scratch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int32_t* dec = decoded + (long long)b * Tp;
+    int n = 0, last = -1;
+    for (int t = 0; t < Tp; ++t) {
+        const int idx = argmax[(long long)b * Tp + t];
+        if (idx != last && idx != blank) { dec[n++] = idx; last = idx; }  // `last` only moves on emission
+    }
+    dec_lens[b] = n;
+    for (int t = n; t < Tp; ++t) dec[t] = -1;
+    // " ".join([]).split(" ") == [""]: an empty side counts as ONE empty token (id -1)
+    int nt = (int)tgt_lens[b];
+    if (nt > S) nt = S;
+    const int na = n > 0 ? n : 1, nb = nt > 0 ? nt : 1;
+    int32_t* prev = scratch + (long long)b * 2 * (S + 2);
+    int32_t* cur = prev + (S + 2);
+    for (int j = 0; j <= nb; ++j) prev[j] = j;
+    for (int i = 1; i <= na; ++i) {
+        const int x = n > 0 ? dec[i - 1] : -1;
+        cur[0] = i;
+        for (int j = 1; j <= nb; ++j) {
+            const int y = nt > 0 ? (int)targets[(long long)b * S + j - 1] : -1;
+            int v = prev[j] + 1;
+            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+            const int sub = prev[j - 1] + (x != y ? 1 : 0);
+            if (sub < v) v = sub;
+            cur[j] = v;
+        }
+        int32_t* tmp = prev; prev = cur; cur = tmp;
+    }
+    errors[2 * b] = prev[nb];
+    errors[2 * b + 1] = nb;
+}
+
+int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int B, int Tp, int S, int blank,
+               int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(per_kernel, dim3((B + 63) / 64), dim3(64), 0, s, argmax, targets, tgt_lens, B, Tp, S, blank, decoded,
+                       dec_lens, errors, scratch);
+    return check_launch("per");
+}
+
+// ------------------------------------------------------------------------------------------
+// fused AdamW over the flat parameter buffer
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ plp, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float inv_bc1,
+                                                    float inv_sqrt_bc2, float gscale) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 pv = *(float4*)(p + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+        float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w},
+              v2[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= (1.0f - lr * wd);
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gr;
+            v2[e] = b2 * v2[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(v2[e]) * inv_sqrt_bc2 + eps;
+            pp[e] -= (lr * inv_bc1) * (mm[e] / denom);
+        }
+        *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *(float4*)(v + i) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+        if (plp) { bf16x4 o = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])}; *(bf16x4*)(plp + i) = o; }
+    }
+}
+
+int adamw_launch(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s) {
+    NBCI_REQUIRE(n % 4 == 0, NBCI_ESHAPE, "adamw: flat buffer length must be a multiple of 4");
+    NBCI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                 NBCI_EALIGN, "adamw: buffers must be 16-byte aligned");
+    const long long blocks = std::min<long long>(2048, (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
+                       (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
+    return check_launch("adamw");
+}
+
+}  // namespace nbci

@@ -1,0 +1,613 @@
+// ndt1.hip — host-side orchestration of the NDT1-CTC forward/backward on one stream.
+//
+// Replaces the Python layer loop of the reference (models/ndt1.py:408-450 NeuralEncoder.forward,
+// :523-589 NDT1.forward ctc branch) and its autograd graph. All launches go to the caller's
+// stream; nothing here synchronises or allocates (the plan owns one tiny device buffer for the
+// smoothing taps, created in nbci_ndt1_plan_create).
+//
+// Memory: parameters live in ONE flat f32 buffer (plus a bf16 shadow in bf16 mode) laid out
+// [embed | layer 0 | ... | layer L-1 | head] so each backward segment's gradients are one
+// contiguous range = one RCCL bucket. Activations saved for backward live in the caller's
+// workspace (size from nbci_ndt1_workspace_bytes).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "kernels.h"
+
+namespace nbci {
+
+struct PInfo {
+    std::string name;
+    int64_t off, numel;
+    int rows, cols, seg;
+};
+
+struct LayerOff {
+    int64_t ln1w, ln1b, qw, kw, vw, qb, kb, vb, ow, ob, ln2w, ln2b, upw, upb, dnw, dnb;
+};
+
+struct Plan {
+    nbci_ndt1_config c;
+    std::vector<PInfo> params;
+    std::vector<LayerOff> L;
+    int64_t embw, embb, stkw, stkb, pos, onw, onb, decw, decb;
+    int64_t total;
+    std::vector<std::pair<int64_t, int64_t>> seg;  // [begin,end) per segment
+    float* d_taps;
+    int ntaps;
+};
+
+constexpr int64_t PALIGN = 8;  // elements: 32 B in f32, 16 B in bf16
+
+static int64_t add_param(Plan& p, int64_t& cur, const std::string& name, int rows, int cols, int seg) {
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    const int64_t off = cur;
+    const int64_t n = (int64_t)rows * (cols > 0 ? cols : 1);
+    p.params.push_back({name, off, n, rows, cols, seg});
+    cur += n;
+    return off;
+}
+
+static void build_layout(Plan& p) {
+    const auto& c = p.c;
+    int64_t cur = 0;
+    const int H = c.hidden, I = c.inter, D = c.input_dim;
+    p.embw = add_param(p, cur, "encoder.embedder.embed_spikes.weight", D, c.n_channels, 0);
+    p.embb = add_param(p, cur, "encoder.embedder.embed_spikes.bias", D, 0, 0);
+    p.stkw = add_param(p, cur, "encoder.embedder.stack_projection.weight", H, D * c.stack_size, 0);
+    p.stkb = add_param(p, cur, "encoder.embedder.stack_projection.bias", H, 0, 0);
+    p.pos = c.pos ? add_param(p, cur, "encoder.embedder.embed_pos.weight", c.max_F, H, 0) : -1;
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    p.seg.push_back({0, cur});
+    for (int l = 0; l < c.n_layers; ++l) {
+        const int64_t begin = cur;
+        const std::string pre = "encoder.layers." + std::to_string(l) + ".";
+        LayerOff o;
+        o.ln1w = add_param(p, cur, pre + "ln1.weight", H, 0, l + 1);
+        o.ln1b = add_param(p, cur, pre + "ln1.bias", H, 0, l + 1);
+        // query/key/value are contiguous so the three projections run as ONE [3H][H] GEMM
+        o.qw = add_param(p, cur, pre + "attn.query.weight", H, H, l + 1);
+        o.kw = add_param(p, cur, pre + "attn.key.weight", H, H, l + 1);
+        o.vw = add_param(p, cur, pre + "attn.value.weight", H, H, l + 1);
+        o.qb = add_param(p, cur, pre + "attn.query.bias", H, 0, l + 1);
+        o.kb = add_param(p, cur, pre + "attn.key.bias", H, 0, l + 1);
+        o.vb = add_param(p, cur, pre + "attn.value.bias", H, 0, l + 1);
+        o.ow = add_param(p, cur, pre + "attn.out_proj.weight", H, H, l + 1);
+        o.ob = add_param(p, cur, pre + "attn.out_proj.bias", H, 0, l + 1);
+        o.ln2w = add_param(p, cur, pre + "ln2.weight", H, 0, l + 1);
+        o.ln2b = add_param(p, cur, pre + "ln2.bias", H, 0, l + 1);
+        o.upw = add_param(p, cur, pre + "mlp.up_proj.weight", I, H, l + 1);
+        o.upb = add_param(p, cur, pre + "mlp.up_proj.bias", I, 0, l + 1);
+        o.dnw = add_param(p, cur, pre + "mlp.down_proj.weight", H, I, l + 1);
+        o.dnb = add_param(p, cur, pre + "mlp.down_proj.bias", H, 0, l + 1);
+        cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+        p.L.push_back(o);
+        p.seg.push_back({begin, cur});
+    }
+    const int64_t begin = cur;
+    const int hs = c.n_layers + 1;
+    p.onw = add_param(p, cur, "encoder.out_norm.weight", H, 0, hs);
+    p.onb = add_param(p, cur, "encoder.out_norm.bias", H, 0, hs);
+    p.decw = add_param(p, cur, "decoder.0.weight", c.vocab, H, hs);
+    p.decb = add_param(p, cur, "decoder.0.bias", c.vocab, 0, hs);
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    p.seg.push_back({begin, cur});
+    p.total = cur;
+}
+
+// ---- workspace carve -----------------------------------------------------------------------
+struct LayerWS {
+    size_t x_in, mean1, rstd1, h1, qkv, P, Pd, ad, x_mid, mean2, rstd2, h2, u, g;
+};
+struct WS {
+    size_t xs, y, tmask, tts, tlens;
+    std::vector<LayerWS> L;
+    size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
+    size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
+    size_t dx, dtmp, dA, dB, dqkv, dS, dwin, dpre;
+    size_t bytes;
+    int Tp, M, ldS, ldP, vpad;
+};
+
+static size_t bump(size_t& cur, size_t bytes) {
+    cur = (cur + 255) / 256 * 256;
+    const size_t o = cur;
+    cur += bytes;
+    return o;
+}
+
+static int carve(const Plan& p, int B, int T, int S, WS& w) {
+    const auto& c = p.c;
+    NBCI_REQUIRE(T >= c.stack_size, NBCI_ESHAPE, "ndt1: sequence shorter than the stacking window");
+    const int Tp = 1 + (T - c.stack_size) / c.stack_stride;
+    NBCI_REQUIRE(Tp <= c.max_F && Tp <= 1024, NBCI_ESHAPE, "ndt1: more tokens than max_F / 1024");
+    const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
+    const size_t M = (size_t)B * Tp, H = c.hidden, I = c.inter, D = c.input_dim;
+    w.Tp = Tp; w.M = (int)M;
+    w.ldS = (Tp + 3) / 4 * 4;
+    w.ldP = (Tp + 7) / 8 * 8;
+    w.vpad = (c.vocab + 7) / 8 * 8;
+    size_t cur = 0;
+    w.xs = bump(cur, (size_t)B * T * c.n_channels * es);
+    w.y = bump(cur, (size_t)B * T * D * es);
+    w.tmask = bump(cur, M * 4);
+    w.tts = bump(cur, M * 8);
+    w.tlens = bump(cur, (size_t)B * 4);
+    w.L.resize(c.n_layers);
+    const size_t nP = (size_t)B * c.n_heads * Tp * w.ldP;
+    for (auto& l : w.L) {
+        l.x_in = bump(cur, M * H * 4);
+        l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
+        l.h1 = bump(cur, M * H * es);
+        l.qkv = bump(cur, M * 3 * H * es);
+        l.P = bump(cur, nP * es);
+        l.Pd = bump(cur, nP * es);
+        l.ad = bump(cur, M * H * es);
+        l.x_mid = bump(cur, M * H * 4);
+        l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
+        l.h2 = bump(cur, M * H * es);
+        l.u = bump(cur, M * I * es);
+        l.g = bump(cur, M * I * es);
+    }
+    w.x_last = bump(cur, M * H * 4);
+    w.mean_o = bump(cur, M * 4); w.rstd_o = bump(cur, M * 4);
+    w.xo = bump(cur, M * H * es);
+    w.logits = bump(cur, M * w.vpad * 4);
+    w.alpha = bump(cur, ctc_alpha_floats(B, Tp, S > 0 ? S : 1) * 4);
+    w.dlogits = bump(cur, M * w.vpad * es);
+    w.argmax = bump(cur, M * 4);
+    w.scores = bump(cur, (size_t)B * c.n_heads * Tp * w.ldS * 4);
+    w.dx = bump(cur, M * H * 4);
+    w.dtmp = bump(cur, M * H * 4);
+    w.dA = bump(cur, M * H * es);
+    w.dB = bump(cur, M * std::max(H, I) * es);
+    w.dqkv = bump(cur, M * 3 * H * es);
+    w.dS = bump(cur, nP * es);
+    w.dwin = bump(cur, M * (size_t)c.stack_size * D * es);
+    w.dpre = bump(cur, (size_t)B * T * D * es);
+    w.bytes = (cur + 255) / 256 * 256;
+    return NBCI_OK;
+}
+
+// ---- small helpers for describing GEMMs ------------------------------------------------------
+static nbci_operand op(const void* base, size_t es, int64_t elem_off, int64_t ld, int kmajor, int rpb = 0,
+                       int64_t gstride = 0, int64_t zs1 = 0, int64_t zs2 = 0) {
+    nbci_operand o;
+    o.ptr = (const char*)base + elem_off * (int64_t)es;
+    o.ld = ld; o.kmajor = kmajor; o.rpb = rpb; o.gstride = gstride; o.zs1 = zs1; o.zs2 = zs2;
+    return o;
+}
+
+static nbci_gemm_desc gd(int M, int N, int K, int dtype, nbci_operand A, nbci_operand B, void* C, int64_t ldc,
+                         int c_dtype) {
+    nbci_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.in_dtype = dtype; d.A = A; d.B = B; d.C = C; d.ldc = ldc; d.c_dtype = c_dtype;
+    d.batch = 1; d.zdiv = 1; d.splitk = 1; d.alpha = 1.f;
+    return d;
+}
+
+// weight-gradient GEMMs have K = tokens (huge) and few output tiles: split K so ~2 blocks/CU are
+// busy; partials are combined with f32 atomics straight into the (accumulating) grad buffer.
+static int wgrad_splitk(int M, int N, int K, int dtype) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int bk = dtype == NBCI_BF16 ? 64 : 16;
+    const int ktiles = (K + bk - 1) / bk;
+    int sk = (512 + tiles - 1) / tiles;
+    const int max_by_k = std::max(1, ktiles / 8);
+    sk = std::max(1, std::min(sk, max_by_k));
+    return std::min(sk, 64);
+}
+
+// dW[M][N] += A^T B over tokens, both operands row-major-in-k. grads accumulate (zero_grad is the
+// caller's memset), so splitk==1 runs with beta=1 and splitk>1 with atomics.
+static int wgrad(hipStream_t s, int dtype, int M, int N, int K, nbci_operand A, nbci_operand B, float* dW, int64_t ldw) {
+    nbci_gemm_desc d = gd(M, N, K, dtype, A, B, dW, ldw, NBCI_F32);
+    d.splitk = wgrad_splitk(M, N, K, dtype);
+    if (d.splitk == 1) d.beta = 1.f;
+    return gemm_launch(d, s);
+}
+
+#define TRY(x)                    \
+    do {                          \
+        int _r = (x);             \
+        if (_r != NBCI_OK) return _r; \
+    } while (0)
+
+struct Ctx {
+    const Plan& p;
+    const float* pf;      // f32 params
+    const void* pw;       // GEMM-weight source (f32 params or bf16 shadow)
+    size_t es;
+    int dt;
+    char* ws;
+    WS w;
+    hipStream_t s;
+    const void* W(int64_t off) const { return (const char*)pw + off * (int64_t)es; }
+};
+
+static int validate_io(const Plan& p, const nbci_ndt1_io* io) {
+    NBCI_REQUIRE(io, NBCI_EINVAL, "ndt1: null io");
+    NBCI_REQUIRE(io->B > 0 && io->T > 0, NBCI_ESHAPE, "ndt1: B and T must be positive");
+    NBCI_REQUIRE(io->spikes && io->spikes_mask && io->spikes_timestamp && io->spikes_lengths, NBCI_EINVAL,
+                 "ndt1: spikes, spikes_mask, spikes_timestamp, spikes_lengths are required");
+    NBCI_REQUIRE(io->workspace, NBCI_EWORKSPACE, "ndt1: null workspace");
+    NBCI_REQUIRE(((uintptr_t)io->workspace) % 256 == 0, NBCI_EALIGN, "ndt1: workspace must be 256-byte aligned");
+    NBCI_REQUIRE(!(p.c.use_rope && (!io->rope_cos || !io->rope_sin)), NBCI_EINVAL, "ndt1: rope tables required");
+    return NBCI_OK;
+}
+
+int ndt1_forward(const Plan& p, const float* params, const void* params_lp, const nbci_ndt1_io* io, hipStream_t s) {
+    TRY(validate_io(p, io));
+    const auto& c = p.c;
+    NBCI_REQUIRE(params, NBCI_EINVAL, "ndt1: null params");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || params_lp, NBCI_EINVAL, "ndt1: bf16 mode needs the bf16 parameter shadow");
+    Ctx x{p, params, c.dtype == NBCI_BF16 ? params_lp : (const void*)params, (size_t)(c.dtype == NBCI_BF16 ? 2 : 4), c.dtype,
+          (char*)io->workspace, {}, s};
+    const int B = io->B, T = io->T, S = io->S;
+    TRY(carve(p, B, T, S, x.w));
+    NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "ndt1: workspace too small");
+    NBCI_REQUIRE(io->preds, NBCI_EINVAL, "ndt1: preds output is required");
+    const WS& w = x.w;
+    const int Tp = w.Tp, M = w.M, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh;
+    const int dt = c.dtype;
+    const size_t es = x.es;
+    const bool train = io->train != 0;
+    const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
+    char* ws = x.ws;
+
+    // 0. token bookkeeping + smoothing/noise (ndt1.py:92-107,181-183,207-208)
+    TRY(token_prep_launch(io->spikes_mask, io->spikes_timestamp, io->spikes_lengths, B, T, Tp, c.stack_size, c.stack_stride,
+                          (int32_t*)(ws + w.tmask), (int64_t*)(ws + w.tts), (int32_t*)(ws + w.tlens), s));
+    const bool noise = train && c.noise;
+    TRY(smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
+                            noise ? c.constant_offset_sd : 0.f, io->seed, s));
+    // 1. embed Linear + activation (ndt1.py:173-176)
+    {
+        nbci_gemm_desc d = gd(B * T, D, c.n_channels, dt, op(ws + w.xs, es, 0, c.n_channels, 1),
+                              op(x.W(p.embw), es, 0, c.n_channels, 1), ws + w.y, D, dt);
+        d.bias = params + p.embb; d.act = c.embed_act;
+        TRY(gemm_launch(d, s));
+    }
+    // 2. Unfold + stack_projection as a GEMM over the overlapping-window view, + pos-emb gather,
+    //    + embed dropout (ndt1.py:138-140,180,188-189,203)
+    float* x_cur = (float*)(ws + (c.n_layers ? w.L[0].x_in : w.x_last));
+    {
+        const int KS = c.stack_size * D;
+        nbci_gemm_desc d = gd(M, H, KS, dt, op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 1, Tp, (int64_t)T * D),
+                              op(x.W(p.stkw), es, 0, KS, 1), x_cur, H, NBCI_F32);
+        d.bias = params + p.stkb;
+        if (c.pos) {
+            d.residual = params + p.pos; d.ldr = H; d.residual_rows = (const int64_t*)(ws + w.tts); d.residual_first = 1;
+        }
+        d.drop_p = p_emb; d.seed = io->seed; d.site = 3;
+        TRY(gemm_launch(d, s));
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LayerWS& lw = w.L[l];
+        const LayerOff& lo = p.L[l];
+        float* x_in = (float*)(ws + lw.x_in);
+        float* x_mid = (float*)(ws + lw.x_mid);
+        float* x_out = (float*)(ws + (l + 1 < c.n_layers ? w.L[l + 1].x_in : w.x_last));
+        // ---- attention block (ndt1.py:266-292,325)
+        TRY(layernorm_fwd_launch(x_in, params + lo.ln1w, params + lo.ln1b, ws + lw.h1, dt, (float*)(ws + lw.mean1),
+                                 (float*)(ws + lw.rstd1), M, H, s));
+        {
+            nbci_gemm_desc d = gd(M, 3 * H, H, dt, op(ws + lw.h1, es, 0, H, 1), op(x.W(lo.qw), es, 0, H, 1), ws + lw.qkv,
+                                  3 * H, dt);
+            d.bias = params + lo.qb;
+            TRY(gemm_launch(d, s));
+        }
+        if (c.use_rope)
+            TRY(rope_launch(ws + lw.qkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 0, s));
+        {   // scores = q k^T / sqrt(hd), batched over (b, head)
+            nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd),
+                                  op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd), ws + w.scores, w.ldS,
+                                  NBCI_F32);
+            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS; d.alpha = scale;
+            TRY(gemm_launch(d, s));
+        }
+        TRY(softmax_fwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + (p_lay > 0.f ? lw.Pd : lw.P), dt,
+                               (const int32_t*)(ws + w.tmask), B, nh, Tp, w.ldS, w.ldP, c.context_forward, c.context_backward,
+                               p_lay, io->seed, 16 + 4 * l, s));
+        {   // a = dropout(merge_heads(Pd v)) written straight into the merged (M, H) layout
+            const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
+            nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 1, 0, 0, (int64_t)nh * Tp * w.ldP, (int64_t)Tp * w.ldP),
+                                  op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)Tp * 3 * H, hd), ws + lw.ad, H, dt);
+            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)Tp * H; d.czs2 = hd;
+            d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
+            TRY(gemm_launch(d, s));
+        }
+        {   // x_mid = x_in + out_proj(a)
+            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), x_mid, H, NBCI_F32);
+            d.bias = params + lo.ob; d.residual = x_in; d.ldr = H;
+            TRY(gemm_launch(d, s));
+        }
+        // ---- MLP block (ndt1.py:224-227,328)
+        TRY(layernorm_fwd_launch(x_mid, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
+                                 (float*)(ws + lw.rstd2), M, H, s));
+        {
+            nbci_gemm_desc d = gd(M, I, H, dt, op(ws + lw.h2, es, 0, H, 1), op(x.W(lo.upw), es, 0, H, 1), ws + lw.g, I, dt);
+            d.bias = params + lo.upb; d.act = c.mlp_act; d.C2 = ws + lw.u;
+            TRY(gemm_launch(d, s));
+        }
+        {
+            nbci_gemm_desc d = gd(M, H, I, dt, op(ws + lw.g, es, 0, I, 1), op(x.W(lo.dnw), es, 0, I, 1), x_out, H, NBCI_F32);
+            d.bias = params + lo.dnb; d.drop_p = p_lay; d.seed = io->seed; d.site = 18 + 4 * l;
+            d.residual = x_mid; d.ldr = H;
+            TRY(gemm_launch(d, s));
+        }
+    }
+    // ---- out_norm + decoder + log-softmax (+ CTC) (ndt1.py:442,494-499,545,581)
+    TRY(layernorm_fwd_launch((const float*)(ws + w.x_last), params + p.onw, params + p.onb, ws + w.xo, dt,
+                             (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
+    {
+        nbci_gemm_desc d = gd(M, c.vocab, H, dt, op(ws + w.xo, es, 0, H, 1), op(x.W(p.decw), es, 0, H, 1), ws + w.logits,
+                              w.vpad, NBCI_F32);
+        d.bias = params + p.decb;
+        TRY(gemm_launch(d, s));
+    }
+    int32_t* amax = io->argmax ? io->argmax : (int32_t*)(ws + w.argmax);
+    TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, M, c.vocab, s));
+    if (io->hidden_out)  // optional copy-out of the encoder output (B,T',H) for BCI-style couplers
+        NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, ws + w.xo, (size_t)M * H * es, hipMemcpyDeviceToDevice, s));
+    if (io->targets) {
+        NBCI_REQUIRE(io->targets_lengths && io->loss && S > 0, NBCI_EINVAL, "ndt1: targets need targets_lengths, loss and S > 0");
+        TRY(ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tp, c.vocab, S, c.blank_id,
+                       c.zero_infinity, io->loss, (float*)(ws + w.alpha), io->want_grad ? ws + w.dlogits : nullptr, dt, w.vpad,
+                       io->grad_scale, s));
+    }
+    return NBCI_OK;
+}
+
+// Backward over segments seg_hi .. seg_lo (descending): head = L+1, layers L..1, embed = 0.
+// Gradients are ACCUMULATED into `grads` (same flat layout as the parameters).
+int ndt1_backward(const Plan& p, const float* params, const void* params_lp, const nbci_ndt1_io* io, float* grads, int seg_hi,
+                  int seg_lo, hipStream_t s) {
+    TRY(validate_io(p, io));
+    const auto& c = p.c;
+    NBCI_REQUIRE(params && grads, NBCI_EINVAL, "ndt1: null params/grads");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || params_lp, NBCI_EINVAL, "ndt1: bf16 mode needs the bf16 parameter shadow");
+    NBCI_REQUIRE(seg_hi <= c.n_layers + 1 && seg_lo >= 0 && seg_lo <= seg_hi, NBCI_EINVAL, "ndt1: bad segment range");
+    Ctx x{p, params, c.dtype == NBCI_BF16 ? params_lp : (const void*)params, (size_t)(c.dtype == NBCI_BF16 ? 2 : 4), c.dtype,
+          (char*)io->workspace, {}, s};
+    const int B = io->B, T = io->T, S = io->S;
+    TRY(carve(p, B, T, S, x.w));
+    NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "ndt1: workspace too small");
+    const WS& w = x.w;
+    const int Tp = w.Tp, M = w.M, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh, V = c.vocab;
+    const int dt = c.dtype;
+    const size_t es = x.es;
+    const bool train = io->train != 0;
+    const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
+    char* ws = x.ws;
+    float* dx = (float*)(ws + w.dx);
+    float* dtmp = (float*)(ws + w.dtmp);
+    const float scale = 1.0f / sqrtf((float)hd);
+
+    for (int seg = seg_hi; seg >= seg_lo; --seg) {
+        if (seg == c.n_layers + 1) {
+            // ---- head: decoder Linear + out_norm
+            const void* dl = ws + w.dlogits;
+            TRY(colsum_launch(dl, dt, w.vpad, M, V, grads + p.decb, s));
+            TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
+            {
+                nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
+                TRY(gemm_launch(d, s));
+            }
+            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
+                                     (const float*)(ws + w.rstd_o), dx, grads + p.onw, grads + p.onb, M, H, 0, s));
+        } else if (seg >= 1) {
+            const int l = seg - 1;
+            const LayerWS& lw = w.L[l];
+            const LayerOff& lo = p.L[l];
+            // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
+            const void* dm;  // d(down output) in the GEMM operand dtype
+            if (dt == NBCI_F32 && p_lay == 0.f) {
+                dm = dx;
+            } else {
+                TRY(dropcast_launch(dx, ws + w.dA, dt, (int64_t)M * H, p_lay, io->seed, 18 + 4 * l, s));
+                dm = ws + w.dA;
+            }
+            TRY(colsum_launch(dm, dt, H, M, H, grads + lo.dnb, s));
+            TRY(wgrad(s, dt, H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
+            {   // du = (dm W_down) * act'(u)
+                nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
+                d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
+                TRY(gemm_launch(d, s));
+            }
+            TRY(colsum_launch(ws + w.dB, dt, I, M, I, grads + lo.upb, s));
+            TRY(wgrad(s, dt, I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
+            {
+                nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
+                TRY(gemm_launch(d, s));
+            }
+            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
+                                     (const float*)(ws + lw.rstd2), dx, grads + lo.ln2w, grads + lo.ln2b, M, H, 1, s));
+            // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
+            const void* dxc;
+            if (dt == NBCI_F32) {
+                dxc = dx;
+            } else {
+                TRY(cast_launch(dx, ws + w.dA, dt, (int64_t)M * H, s));
+                dxc = ws + w.dA;
+            }
+            TRY(colsum_launch(dx, NBCI_F32, H, M, H, grads + lo.ob, s));
+            TRY(wgrad(s, dt, H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
+            {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
+                nbci_gemm_desc d = gd(M, H, H, dt, op(dxc, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dB, H, dt);
+                d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
+                TRY(gemm_launch(d, s));
+            }
+            const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
+            const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
+            const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
+            {   // dPd = da v^T   (f32, reuses the score buffer)
+                nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB, es, 0, H, 1, 0, 0, az1, hd),
+                                      op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS;
+                TRY(gemm_launch(d, s));
+            }
+            {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
+                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
+                                      op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
+                TRY(gemm_launch(d, s));
+            }
+            TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, Tp, w.ldS, w.ldP, p_lay,
+                                   io->seed, 16 + 4 * l, s));
+            {   // dq = dS k * scale
+                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
+                                      op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                TRY(gemm_launch(d, s));
+            }
+            {   // dk = dS^T q * scale
+                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
+                                      op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                TRY(gemm_launch(d, s));
+            }
+            if (c.use_rope)
+                TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
+            TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, grads + lo.qb, s));
+            TRY(wgrad(s, dt, 3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
+            {
+                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
+                                      NBCI_F32);
+                TRY(gemm_launch(d, s));
+            }
+            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
+                                     (const float*)(ws + lw.rstd1), dx, grads + lo.ln1w, grads + lo.ln1b, M, H, 1, s));
+        } else {
+            // ---- embedder backward (ndt1.py:160-203)
+            const int KS = c.stack_size * D;
+            const void* dx0;
+            if (dt == NBCI_F32 && p_emb == 0.f) {
+                dx0 = dx;
+            } else {
+                TRY(dropcast_launch(dx, ws + w.dA, dt, (int64_t)M * H, p_emb, io->seed, 3, s));
+                dx0 = ws + w.dA;
+            }
+            if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
+            TRY(colsum_launch(dx0, dt, H, M, H, grads + p.stkb, s));
+            TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
+                      op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
+            {   // dwin = dx0 W_s  (M, S*D)
+                nbci_gemm_desc d = gd(M, KS, H, dt, op(dx0, es, 0, H, 1), op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
+                TRY(gemm_launch(d, s));
+            }
+            TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
+                                      c.embed_act, s));
+            TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, grads + p.embb, s));
+            TRY(wgrad(s, dt, D, c.n_channels, B * T, op(ws + w.dpre, es, 0, D, 0), op(ws + w.xs, es, 0, c.n_channels, 0),
+                      grads + p.embw, c.n_channels));
+        }
+    }
+    return NBCI_OK;
+}
+
+}  // namespace nbci
+
+// ---------------------------------------------------------------------------------------------
+using namespace nbci;
+
+extern "C" {
+
+int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
+    if (!cfg || !out) return fail(NBCI_EINVAL, "plan_create: null argument");
+    const nbci_ndt1_config& c = *cfg;
+    NBCI_REQUIRE(c.hidden > 0 && c.n_heads > 0 && c.hidden % c.n_heads == 0, NBCI_ESHAPE,
+                 "Hidden dim is not multiple of head size");  // ndt1.py:242
+    NBCI_REQUIRE(c.hidden % 8 == 0 && c.inter % 8 == 0 && c.input_dim % 8 == 0, NBCI_ESHAPE,
+                 "hidden, inter_size and input_dim must be multiples of 8");
+    NBCI_REQUIRE((c.hidden / c.n_heads) % 8 == 0, NBCI_ESHAPE, "head size must be a multiple of 8");
+    NBCI_REQUIRE(c.n_channels > 0 && c.stack_size > 0 && c.stack_stride > 0 && c.vocab > 0 && c.n_layers >= 0, NBCI_ESHAPE,
+                 "bad NDT1 shape parameters");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.blank_id >= 0 && c.blank_id < c.vocab, NBCI_EINVAL, "blank_id out of range");
+    NBCI_REQUIRE(!(c.use_rope && ((c.hidden / c.n_heads) % 2)), NBCI_ESHAPE, "rope needs an even head size");
+    Plan* p = new Plan();
+    p->c = c;
+    build_layout(*p);
+    p->d_taps = nullptr;
+    p->ntaps = 0;
+    if (c.smooth_sd > 0.f) {
+        // scipy.signal.gaussian(1 + 6*sd, sd) normalised, built in float64 (ndt1.py:87-88)
+        const int n = 1 + (int)(6 * c.smooth_sd);
+        if (n > 64) { delete p; return fail(NBCI_ESHAPE, "smooth_sd too large (max 64 taps)"); }
+        std::vector<double> w(n);
+        double sum = 0;
+        for (int i = 0; i < n; ++i) { const double k = i - (n - 1) / 2.0; w[i] = std::exp(-0.5 * (k / c.smooth_sd) * (k / c.smooth_sd)); sum += w[i]; }
+        std::vector<float> wf(n);
+        for (int i = 0; i < n; ++i) wf[i] = (float)(w[i] / sum);
+        hipError_t e = hipMalloc(&p->d_taps, 64 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->d_taps, wf.data(), n * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete p; return fail(NBCI_EHIP, std::string("plan_create: ") + hipGetErrorString(e)); }
+        p->ntaps = n;
+    }
+    *out = (nbci_ndt1_plan)p;
+    return NBCI_OK;
+}
+
+void nbci_ndt1_plan_destroy(nbci_ndt1_plan plan) {
+    Plan* p = (Plan*)plan;
+    if (!p) return;
+    if (p->d_taps) (void)hipFree(p->d_taps);
+    delete p;
+}
+
+int64_t nbci_ndt1_param_count(nbci_ndt1_plan plan) { return plan ? ((Plan*)plan)->total : -1; }
+int32_t nbci_ndt1_num_params(nbci_ndt1_plan plan) { return plan ? (int32_t)((Plan*)plan)->params.size() : -1; }
+int32_t nbci_ndt1_num_segments(nbci_ndt1_plan plan) { return plan ? (int32_t)((Plan*)plan)->seg.size() : -1; }
+
+int nbci_ndt1_param_info(nbci_ndt1_plan plan, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
+                         int32_t* rows, int32_t* cols, int32_t* segment) {
+    Plan* p = (Plan*)plan;
+    if (!p || index < 0 || index >= (int)p->params.size()) return fail(NBCI_EINVAL, "param_info: bad plan/index");
+    const PInfo& i = p->params[index];
+    if (name && name_cap > 0) { strncpy(name, i.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = i.off;
+    if (numel) *numel = i.numel;
+    if (rows) *rows = i.rows;
+    if (cols) *cols = i.cols;
+    if (segment) *segment = i.seg;
+    return NBCI_OK;
+}
+
+int nbci_ndt1_segment_range(nbci_ndt1_plan plan, int32_t seg, int64_t* begin, int64_t* end) {
+    Plan* p = (Plan*)plan;
+    if (!p || seg < 0 || seg >= (int)p->seg.size()) return fail(NBCI_EINVAL, "segment_range: bad plan/segment");
+    *begin = p->seg[seg].first; *end = p->seg[seg].second;
+    return NBCI_OK;
+}
+
+int64_t nbci_ndt1_workspace_bytes(nbci_ndt1_plan plan, int32_t B, int32_t T, int32_t S) {
+    Plan* p = (Plan*)plan;
+    if (!p) { fail(NBCI_EINVAL, "workspace_bytes: null plan"); return -1; }
+    WS w;
+    if (carve(*p, B, T, S, w) != NBCI_OK) return -1;
+    return (int64_t)w.bytes;
+}
+
+int32_t nbci_ndt1_tokens(nbci_ndt1_plan plan, int32_t T) {
+    Plan* p = (Plan*)plan;
+    if (!p || T < p->c.stack_size) return -1;
+    return 1 + (T - p->c.stack_size) / p->c.stack_stride;
+}
+
+int nbci_ndt1_forward(nbci_ndt1_plan plan, const float* params, const void* params_lp, const nbci_ndt1_io* io,
+                      nbci_stream_t stream) {
+    if (!plan) return fail(NBCI_EINVAL, "forward: null plan");
+    return ndt1_forward(*(Plan*)plan, params, params_lp, io, (hipStream_t)stream);
+}
+
+int nbci_ndt1_backward(nbci_ndt1_plan plan, const float* params, const void* params_lp, const nbci_ndt1_io* io, float* grads,
+                       int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream) {
+    if (!plan) return fail(NBCI_EINVAL, "backward: null plan");
+    return ndt1_backward(*(Plan*)plan, params, params_lp, io, grads, seg_hi, seg_lo, (hipStream_t)stream);
+}
+
+}  // extern "C"
