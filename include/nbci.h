@@ -161,6 +161,14 @@ int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t
 
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream);
 
+/* Measurement aid (no reference counterpart): when enabled, every GEMM launched by
+ * nbci_ndt1_forward/backward is bracketed by HIP events on its own stream. collect() waits for
+ * them and fills out24[kind*3 + {0,1,2}] = {total ms, total FLOPs, launches}, kind =
+ * (bf16 ? 4 : 0) + (A.kmajor ? 2 : 0) + (B.kmajor ? 1 : 0). Host-synchronising; never call it in
+ * a timed region. */
+int nbci_profile_enable(int32_t on);
+int nbci_profile_collect(double* out24);
+
 /* ------------------------------------------------------------------------------------
  * NDT1-CTC model level. Replaces NeuralEncoder.forward + NDT1.forward(ctc) and their autograd
  * graph (models/ndt1.py:408-450, 523-589), i.e. what Trainer.train calls at trainer.py:336-339.

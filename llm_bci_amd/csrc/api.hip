@@ -61,4 +61,10 @@ int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_str
     return nbci::cast_launch(in, out, out_dtype, n, (hipStream_t)stream);
 }
 
+int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
+int nbci_profile_collect(double* out24) {
+    if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");
+    return nbci::gemm_profile_collect(out24);
+}
+
 }  // extern "C"

@@ -451,3 +451,42 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
 }
 
 }  // namespace nbci
+
+// ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch ----
+#include <vector>
+namespace nbci {
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+void gemm_profile_enable(bool on) { g_prof_on = on; }
+bool gemm_profile_on() { return g_prof_on; }
+
+int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream) {
+    if (!g_prof_on) return gemm_launch(d, stream);
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return fail(NBCI_EHIP, "event create");
+    const int batch = d.batch > 0 ? d.batch : 1;
+    r.flops = 2.0 * d.M * (double)d.N * d.K * batch;
+    r.kind = (d.in_dtype == NBCI_BF16 ? 4 : 0) + (d.A.kmajor ? 2 : 0) + (d.B.kmajor ? 1 : 0);
+    (void)hipEventRecord(r.a, stream);
+    const int rc = gemm_launch(d, stream);
+    (void)hipEventRecord(r.b, stream);
+    g_prof.push_back(r);
+    return rc;
+}
+
+// out[kind] = {total ms, total flops, launches} for kind = dtype*4 + A.kmajor*2 + B.kmajor (8 kinds)
+int gemm_profile_collect(double* out24) {
+    for (int i = 0; i < 24; ++i) out24[i] = 0.0;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+            return fail(NBCI_EHIP, "profile collect");
+        out24[r.kind * 3 + 0] += ms; out24[r.kind * 3 + 1] += r.flops; out24[r.kind * 3 + 2] += 1.0;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return NBCI_OK;
+}
+}  // namespace nbci

@@ -7,6 +7,9 @@
 namespace nbci {
 
 int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream);
+int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream);  // = gemm_launch unless profiling is on
+void gemm_profile_enable(bool on);
+int gemm_profile_collect(double* out24);
 
 // models/ndt1.py:92-107 — depthwise gaussian smoothing along T ('same', zero padded) + train noise
 int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, int T, int N, const float* taps,

@@ -206,7 +206,7 @@ static int wgrad(hipStream_t s, int dtype, int M, int N, int K, nbci_operand A, 
     nbci_gemm_desc d = gd(M, N, K, dtype, A, B, dW, ldw, NBCI_F32);
     d.splitk = wgrad_splitk(M, N, K, dtype);
     if (d.splitk == 1) d.beta = 1.f;
-    return gemm_launch(d, s);
+    return gemm_launch_timed(d, s);
 }
 
 #define TRY(x)                    \
@@ -268,7 +268,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         nbci_gemm_desc d = gd(B * T, D, c.n_channels, dt, op(ws + w.xs, es, 0, c.n_channels, 1),
                               op(x.W(p.embw), es, 0, c.n_channels, 1), ws + w.y, D, dt);
         d.bias = params + p.embb; d.act = c.embed_act;
-        TRY(gemm_launch(d, s));
+        TRY(gemm_launch_timed(d, s));
     }
     // 2. Unfold + stack_projection as a GEMM over the overlapping-window view, + pos-emb gather,
     //    + embed dropout (ndt1.py:138-140,180,188-189,203)
@@ -282,7 +282,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             d.residual = params + p.pos; d.ldr = H; d.residual_rows = (const int64_t*)(ws + w.tts); d.residual_first = 1;
         }
         d.drop_p = p_emb; d.seed = io->seed; d.site = 3;
-        TRY(gemm_launch(d, s));
+        TRY(gemm_launch_timed(d, s));
     }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -298,7 +298,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             nbci_gemm_desc d = gd(M, 3 * H, H, dt, op(ws + lw.h1, es, 0, H, 1), op(x.W(lo.qw), es, 0, H, 1), ws + lw.qkv,
                                   3 * H, dt);
             d.bias = params + lo.qb;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
         if (c.use_rope)
             TRY(rope_launch(ws + lw.qkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 0, s));
@@ -307,7 +307,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
                                   op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd), ws + w.scores, w.ldS,
                                   NBCI_F32);
             d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS; d.alpha = scale;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
         TRY(softmax_fwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + (p_lay > 0.f ? lw.Pd : lw.P), dt,
                                (const int32_t*)(ws + w.tmask), B, nh, Tp, w.ldS, w.ldP, c.context_forward, c.context_backward,
@@ -318,12 +318,12 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
                                   op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)Tp * 3 * H, hd), ws + lw.ad, H, dt);
             d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)Tp * H; d.czs2 = hd;
             d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
         {   // x_mid = x_in + out_proj(a)
             nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), x_mid, H, NBCI_F32);
             d.bias = params + lo.ob; d.residual = x_in; d.ldr = H;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
         // ---- MLP block (ndt1.py:224-227,328)
         TRY(layernorm_fwd_launch(x_mid, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
@@ -331,13 +331,13 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         {
             nbci_gemm_desc d = gd(M, I, H, dt, op(ws + lw.h2, es, 0, H, 1), op(x.W(lo.upw), es, 0, H, 1), ws + lw.g, I, dt);
             d.bias = params + lo.upb; d.act = c.mlp_act; d.C2 = ws + lw.u;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
         {
             nbci_gemm_desc d = gd(M, H, I, dt, op(ws + lw.g, es, 0, I, 1), op(x.W(lo.dnw), es, 0, I, 1), x_out, H, NBCI_F32);
             d.bias = params + lo.dnb; d.drop_p = p_lay; d.seed = io->seed; d.site = 18 + 4 * l;
             d.residual = x_mid; d.ldr = H;
-            TRY(gemm_launch(d, s));
+            TRY(gemm_launch_timed(d, s));
         }
     }
     // ---- out_norm + decoder + log-softmax (+ CTC) (ndt1.py:442,494-499,545,581)
@@ -347,7 +347,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         nbci_gemm_desc d = gd(M, c.vocab, H, dt, op(ws + w.xo, es, 0, H, 1), op(x.W(p.decw), es, 0, H, 1), ws + w.logits,
                               w.vpad, NBCI_F32);
         d.bias = params + p.decb;
-        TRY(gemm_launch(d, s));
+        TRY(gemm_launch_timed(d, s));
     }
     int32_t* amax = io->argmax ? io->argmax : (int32_t*)(ws + w.argmax);
     TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, M, c.vocab, s));
@@ -395,7 +395,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
             {
                 nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
                                      (const float*)(ws + w.rstd_o), dx, grads + p.onw, grads + p.onb, M, H, 0, s));
@@ -416,13 +416,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             {   // du = (dm W_down) * act'(u)
                 nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
                 d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(colsum_launch(ws + w.dB, dt, I, M, I, grads + lo.upb, s));
             TRY(wgrad(s, dt, I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
             {
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
                                      (const float*)(ws + lw.rstd2), dx, grads + lo.ln2w, grads + lo.ln2b, M, H, 1, s));
@@ -439,7 +439,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
                 nbci_gemm_desc d = gd(M, H, H, dt, op(dxc, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dB, H, dt);
                 d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
@@ -448,13 +448,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB, es, 0, H, 1, 0, 0, az1, hd),
                                       op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
                                       op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, Tp, w.ldS, w.ldP, p_lay,
                                    io->seed, 16 + 4 * l, s));
@@ -462,13 +462,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
                                       op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             {   // dk = dS^T q * scale
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
                                       op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             if (c.use_rope)
                 TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
@@ -477,7 +477,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             {
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
                                       NBCI_F32);
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
                                      (const float*)(ws + lw.rstd1), dx, grads + lo.ln1w, grads + lo.ln1b, M, H, 1, s));
@@ -497,7 +497,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                       op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
             {   // dwin = dx0 W_s  (M, S*D)
                 nbci_gemm_desc d = gd(M, KS, H, dt, op(dx0, es, 0, H, 1), op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
-                TRY(gemm_launch(d, s));
+                TRY(gemm_launch_timed(d, s));
             }
             TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
                                       c.embed_act, s));

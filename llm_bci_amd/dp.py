@@ -1,0 +1,75 @@
+"""Data-parallel wiring that replaces accelerate -> DDP/DeepSpeed on the 8-GPU node
+(reference: models/trainer.py:77-80 split_batches, :260-262 prepare, :339 backward all-reduce,
+:345 no_sync, :353-354,360 scalar gathers).
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm, "gloo" on
+CPU (tests). Gradients live in one flat f32 buffer whose layout is [embed | layer0 .. | head];
+each backward segment is one contiguous bucket, all-reduced (SUM) asynchronously as soon as its
+kernels are queued so the exchange overlaps the rest of the backward pass. The 1/world_size of
+DDP's mean is folded into the fused AdamW (grad_scale), not a separate pass.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(batch, rank, world):
+    """Accelerator(split_batches=True): the loader's batch is the GLOBAL batch; rank r takes the
+    r-th contiguous slice of every tensor (trainer.py:77-80)."""
+    if world == 1:
+        return batch
+    out = {}
+    for k, v in batch.items():
+        if v is None:
+            out[k] = None
+            continue
+        n = v.shape[0]
+        if n % world:
+            raise ValueError(f"global batch {n} is not divisible by world size {world}")
+        per = n // world
+        out[k] = v[rank * per:(rank + 1) * per]
+    return out
+
+
+class GradReducer:
+    """Bucketed async all-reduce over contiguous segments of a flat gradient buffer."""
+
+    def __init__(self, segments, group=None, min_bucket_elems=1 << 20):
+        self.segments = list(segments)           # [(begin, end)] ascending by offset
+        self.group = group
+        self.min_bucket = min_bucket_elems
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self._works = []
+        self._pending = None                     # [begin, end) accumulated but not yet launched
+
+    def segment_done(self, flat, seg):
+        """Call after segment `seg`'s backward kernels are queued (segments finish high -> low)."""
+        if self.world == 1:
+            return
+        b, e = self.segments[seg]
+        if self._pending is None:
+            self._pending = [b, e]
+        else:
+            assert e == self._pending[0], "segments must be reduced in descending, contiguous order"
+            self._pending[0] = b
+        if self._pending[1] - self._pending[0] >= self.min_bucket or seg == 0:
+            self._launch(flat)
+
+    def _launch(self, flat):
+        b, e = self._pending
+        self._pending = None
+        self._works.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, flat=None):
+        if self._pending is not None and flat is not None:
+            self._launch(flat)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
+def reduce_stats(stats, group=None):
+    """One small SUM all-reduce for {loss, n_examples, metric numerators...} instead of the
+    reference's per-scalar gather + .item() (trainer.py:353-354,360). `stats` is a 1-D tensor."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats

@@ -17,50 +17,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import ACT, NBCI_BF16, NBCI_F32, check, lib
+from ._lib import ACT, NBCI_BF16, NBCI_F32, NDT1IO, NDT1Config, check, lib
 from .config import DictConfig, ndt1_config, update_config
 from .model_output import NDT1Output
-
-
-class NDT1Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n_channels", "input_dim", "stack_size", "stack_stride", "hidden", "n_layers",
-                                         "n_heads", "inter", "vocab", "max_F")] + [
-        ("smooth_sd", C.c_float), ("noise", C.c_int32), ("white_noise_sd", C.c_float), ("constant_offset_sd", C.c_float),
-        ("embed_act", C.c_int32), ("mlp_act", C.c_int32), ("embed_dropout", C.c_float), ("dropout", C.c_float),
-        ("use_rope", C.c_int32), ("rope_theta", C.c_float), ("context_forward", C.c_int32), ("context_backward", C.c_int32),
-        ("pos", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32), ("dtype", C.c_int32)]
-
-
-class NDT1IO(C.Structure):
-    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("S", C.c_int32),
-                ("spikes", C.c_void_p), ("spikes_mask", C.c_void_p), ("spikes_timestamp", C.c_void_p),
-                ("spikes_lengths", C.c_void_p), ("targets", C.c_void_p), ("targets_lengths", C.c_void_p),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
-                ("preds", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
-
-
-_lib._SIGNATURES.update({
-    "nbci_ndt1_plan_create": (C.c_int, [C.POINTER(NDT1Config), C.POINTER(C.c_void_p)]),
-    "nbci_ndt1_plan_destroy": (None, [C.c_void_p]),
-    "nbci_ndt1_param_count": (C.c_int64, [C.c_void_p]),
-    "nbci_ndt1_num_params": (C.c_int32, [C.c_void_p]),
-    "nbci_ndt1_num_segments": (C.c_int32, [C.c_void_p]),
-    "nbci_ndt1_param_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
-                                       C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                       C.POINTER(C.c_int32)]),
-    "nbci_ndt1_segment_range": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "nbci_ndt1_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "nbci_ndt1_tokens": (C.c_int32, [C.c_void_p, C.c_int32]),
-    "nbci_ndt1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NDT1IO), C.c_void_p]),
-    "nbci_ndt1_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NDT1IO), C.c_void_p, C.c_int32,
-                                     C.c_int32, C.c_void_p]),
-    "nbci_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
-                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    "nbci_per": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-})
 
 
 class _Box(nn.Module):
@@ -81,7 +40,7 @@ class _NDT1Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, *params):
-        loss_vec, preds = model._run_forward(batch, want_grad=torch.is_grad_enabled())
+        loss_vec, preds = model._run_forward(batch, want_grad=True)
         ctx.model = model
         ctx.mark_non_differentiable(preds)
         return loss_vec.sum(), preds

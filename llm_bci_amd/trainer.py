@@ -1,0 +1,120 @@
+"""Native train step for the HIP NDT1: the counterpart of one iteration of the reference's
+Trainer.train loop (models/trainer.py:332-362) with the same semantics —
+  loss = SUM over examples, backward(loss / ga), AdamW over ALL parameters (lr, wd, eps from the
+  recipe, no decay exclusions), per-step OneCycle/linear scheduler, zero_grad, DDP mean over ranks —
+but without autograd, with ONE fused AdamW launch over the flat buffer, the gradient all-reduce
+overlapped with backward, and loss / PER bookkeeping kept on the device (no .item() per step).
+
+NAME2MODEL mirrors the reference registry (trainer.py:36) for the classes this package provides.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import NBCI_BF16, check, lib
+from .dp import GradReducer, reduce_stats, shard_batch
+from .ndt1 import NDT1, _ptr, _stream
+from .schedule import LinearWarmup, OneCycle, StepDecay
+
+NAME2MODEL = {"NDT1": NDT1}
+
+
+def register_into(reference_trainer_module):
+    """Registry swap: make the reference's Trainer build the HIP NDT1 for model_class 'NDT1'."""
+    reference_trainer_module.NAME2MODEL["NDT1"] = NDT1
+
+
+class NativeTrainer:
+    def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
+                 div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
+                 compute_per=True, blank_id=0):
+        self.model = model
+        self.ga = gradient_accumulation_steps
+        self.wd, self.eps, self.beta2 = wd, eps, betas[1]
+        if scheduler == "cosine":
+            self.sched = OneCycle(total_steps, lr, warmup_pct, div_factor)
+        elif scheduler == "linear":
+            self.sched = LinearWarmup(total_steps, lr, round(warmup_pct * total_steps), betas[0])
+        elif scheduler == "step":
+            self.sched = StepDecay(lr, gamma, betas[0])
+        else:
+            raise Exception(f"Scheduler '{scheduler}' not implemented")
+        dev = model._flat.device
+        n = model._total
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.reducer = GradReducer(model._segments, group=group)
+        self.world = self.reducer.world
+        self.group = group
+        self.global_step = 1          # counts micro-batches like trainer.py:321
+        self.opt_step = 0             # optimizer steps taken
+        self.compute_per = compute_per
+        self.blank_id = blank_id
+        # device-side running stats: [loss_sum, n_examples, per_ratio_sum, n_batches]
+        self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._per_bufs = None
+
+    # -------------------------------------------------------------------------------------
+    def _per(self, batch):
+        """phoneme error rate of this batch on the device (main.py:68-74 semantics)."""
+        m = self.model
+        am = m.last_argmax
+        B, Tp = am.shape
+        tg, tl = m._io_keepalive[5], m._io_keepalive[6]
+        S = tg.shape[1]
+        if self._per_bufs is None or self._per_bufs[0].shape != (B, Tp) or self._per_bufs[3].numel() < B * 2 * (S + 2):
+            dev = am.device
+            self._per_bufs = (torch.empty(B, Tp, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                              torch.empty(B, 2, dtype=torch.int32, device=dev),
+                              torch.empty(B * 2 * (S + 2), dtype=torch.int32, device=dev))
+        dec, dl, err, scr = self._per_bufs
+        check(lib().nbci_per(_ptr(am), _ptr(tg), _ptr(tl), B, Tp, S, self.blank_id, _ptr(dec), _ptr(dl), _ptr(err), _ptr(scr),
+                             _stream()), "nbci_per")
+        e = err.sum(0).double()
+        return e[0] / e[1]
+
+    def train_step(self, batch, seed=None):
+        """One micro-batch: forward, backward (+ overlapped all-reduce), and — on the steps the
+        reference synchronises on (trainer.py:335) — AdamW + scheduler + zero_grad."""
+        m = self.model
+        m.train()
+        sync = ((self.global_step - 1) % self.ga == 0)
+        loss_vec, preds = m._run_forward(batch, want_grad=True, seed=seed, grad_scale=1.0 / self.ga)
+        nseg = len(m._segments)
+        for seg in range(nseg - 1, -1, -1):
+            m._run_backward(self.grads, seg, seg)
+            if sync:
+                self.reducer.segment_done(self.grads, seg)
+        # bookkeeping while the last buckets are in flight
+        self.stats[0] += loss_vec.sum().double()
+        self.stats[1] += loss_vec.numel()
+        if self.compute_per and batch.get("targets") is not None:
+            self.stats[2] += self._per(batch)
+            self.stats[3] += 1
+        if sync:
+            self.reducer.finish(self.grads)
+            lr, beta1 = self.sched.at(self.opt_step)
+            t = self.opt_step + 1
+            lp = m._flat_lp if m.compute_dtype == NBCI_BF16 else None
+            check(lib().nbci_adamw(_ptr(m._flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(lp), m._total, lr, beta1,
+                                   self.beta2, self.eps, self.wd, 1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world,
+                                   _stream()), "nbci_adamw")
+            self.grads.zero_()
+            self.opt_step += 1
+        self.global_step += 1
+        return loss_vec, preds
+
+    def read_stats(self, reset=True):
+        """{'loss': sum_loss/sum_examples, 'PER': mean of per-batch ratios} over the steps since the
+        last read (trainer.py:306-307,370-371); ONE host sync, one small all-reduce."""
+        s = reduce_stats(self.stats.clone(), self.group).cpu()
+        out = {"loss": (s[0] / s[1]).item() if s[1] > 0 else 0.0, "n_examples": int(s[1].item()),
+               "PER": (s[2] / s[3]).item() if s[3] > 0 else None}
+        if reset:
+            self.stats.zero_()
+        return out
+
+    def end_epoch(self):
+        if isinstance(self.sched, StepDecay):
+            self.sched.end_epoch()

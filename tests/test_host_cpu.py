@@ -1,0 +1,100 @@
+"""CPU-only checks of the host side: C-ABI library loads and exports every declared symbol, the
+config loader, the plugin surface (ctor/forward signature, state-dict keys, checkpoint files),
+and loud failure without a GPU."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from llm_bci_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    l = _lib.lib()
+    names = _lib.exported_symbols()
+    assert len(names) >= 25 and "nbci_gemm" in names and "nbci_ndt1_forward" in names
+    for n in names:
+        assert hasattr(l, n), n
+    assert l.nbci_version() == 100
+    for n in names:
+        assert n in _lib._SIGNATURES or n in ("nbci_version", "nbci_last_error", "nbci_gemm"), f"no ctypes signature for {n}"
+
+
+def test_config_merge_and_include(tmp_path):
+    from llm_bci_amd.config import DictConfig, ndt1_config, update_config
+    inc = tmp_path / "model.yaml"
+    inc.write_text("a: 1\nb:\n  c: 2\n  d: [1, 2]\n")
+    top = tmp_path / "top.yaml"
+    top.write_text(f"model: include:{inc}\nx: 5\n")
+    cfg = update_config(str(top), {"model": {"b": {"c": None, "e": 7}}, "y": {"z": 1}})
+    assert cfg.model.a == 1 and cfg.model.b.c is None and cfg.model.b.d == [1, 2] and cfg.model.b.e == 7 and cfg.y.z == 1
+    assert isinstance(cfg.model, DictConfig)
+    d = ndt1_config({"encoder": {"transformer": {"n_layers": 2}}})
+    assert d.encoder.transformer.n_layers == 2 and d.encoder.transformer.hidden_size == 1024
+    assert d.encoder.embedder.stack.size == 32 and d.encoder.smooth_and_noise.smooth_sd == 2
+
+
+def test_plugin_surface_matches_reference_contract(tmp_path):
+    from llm_bci_amd.model_output import ModelOutput, NDT1Output
+    from llm_bci_amd.ndt1 import NDT1
+    from llm_bci_amd.trainer import NAME2MODEL
+    assert NAME2MODEL["NDT1"] is NDT1
+    # forward kwarg names drive the reference's collate (trainer.py:161-171)
+    assert list(inspect.signature(NDT1.forward).parameters)[1:] == [
+        "spikes", "spikes_mask", "spikes_timestamp", "spikes_lengths", "targets", "targets_lengths", "block_idx", "day_idx"]
+    assert list(NDT1Output().to_dict().keys()) == ["loss", "n_examples", "mask", "preds", "targets"]
+    assert issubclass(NDT1Output, ModelOutput)
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = NDT1(over, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "encoder.embedder.embed_spikes.weight" and keys[-1] == "decoder.0.bias"
+    assert "encoder.layers.0.attn.out_proj.weight" in keys and "encoder.out_norm.weight" in keys
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in m.state_dict().values())
+    # parameters are views into one flat buffer; checkpoint files use the reference's names
+    assert all(p.untyped_storage().data_ptr() == m._flat.untyped_storage().data_ptr() for p in m.parameters())
+    m.save_checkpoint(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["decoder.bin", "encoder.bin", "encoder_config.pth"]
+    enc_cfg = torch.load(os.path.join(tmp_path, "encoder_config.pth"), weights_only=False)
+    assert enc_cfg["transformer"]["hidden_size"] == 32
+    over2 = {"encoder": dict(over["encoder"], from_pt=str(tmp_path))}
+    m2 = NDT1(over2, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)   # warm start (ndt1.py:468-476)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(Exception, match="not implemented"):
+        NDT1(over, method_name="mlm", vocab_size=11, blank_id=0, zero_infinity=True)
+
+
+def test_no_cpu_fallback():
+    from llm_bci_amd._lib import NbciUnavailable
+    from llm_bci_amd.ndt1 import NDT1
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = NDT1(over, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    B, T = 2, 12
+    with pytest.raises(NbciUnavailable):
+        m(spikes=torch.zeros(B, T, 16), spikes_mask=torch.ones(B, T, dtype=torch.long),
+          spikes_timestamp=torch.zeros(B, T, dtype=torch.long), spikes_lengths=torch.full((B,), T))
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _dn, fn in os.walk(os.path.join(root, "llm_bci_amd")):
+        for f in fn:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_schedules_match_golden_lr_and_momentum():
+    from llm_bci_amd.schedule import OneCycle
+    from test_oracle_golden import load
+    fx = load("g_tiny")
+    oc = OneCycle(100, 1e-3, 0.0, 25)
+    for s in range(2):
+        lr, b1 = oc.at(s)
+        assert abs(lr - float(fx[f"lr_step{s}"])) < 1e-12 and abs(b1 - float(fx[f"beta1_step{s}"])) < 1e-12

@@ -1,0 +1,152 @@
+"""Single-kernel GPU parity through the C-ABI: CTC vs torch.nn.CTCLoss fixtures, AdamW vs oracle,
+LayerNorm / softmax vs float64 numpy, smoothing vs oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ndt1 as O
+from oracle import optim as OO
+from oracle import rng as R
+from test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _l():
+    from llm_bci_amd import ndt1  # noqa: F401  (registers ctypes signatures)
+    from llm_bci_amd._lib import check, lib
+    return lib(), check
+
+
+def vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def d(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("nm", ["basic", "repeat_infeasible", "too_short", "empty_target", "long"])
+def test_ctc_cases(nm):
+    l, check = _l()
+    fx = load("ctc_cases")
+    lp = fx[nm + "_lp"].astype(np.float32)
+    B, T, V = lp.shape
+    tg = fx[nm + "_targets"].astype(np.int64); S = tg.shape[1]
+    il = fx[nm + "_il"].astype(np.int32); tl = fx[nm + "_tl"].astype(np.int64)
+    loss = torch.zeros(B, device=DEV)
+    nws = l.nbci_ctc_workspace_floats(B, T, S)
+    ws = torch.zeros(max(int(nws), 1), device=DEV)
+    ldd = (V + 7) // 8 * 8
+    dl = torch.full((B, T, ldd), 7.0, device=DEV)
+    l.nbci_ctc.restype = C.c_int
+    lpd, tgd, ild, tld = d(lp), d(tg), d(il), d(tl)   # keep the borrowed buffers alive across the call
+    check(l.nbci_ctc(vp(lpd), vp(tgd), vp(ild), vp(tld), B, T, V, S, 0, 1, vp(loss), vp(ws), vp(dl), 0, ldd,
+                     C.c_float(1.0), st()), "nbci_ctc")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.cpu().numpy(), fx[nm + "_loss"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dl[:, :, :V].cpu().numpy(), fx[nm + "_grad"], atol=2e-5)
+    assert torch.all(dl[:, :, V:] == 0)
+
+
+def test_adamw_matches_oracle_and_refreshes_bf16_shadow():
+    l, check = _l()
+    g0 = np.random.default_rng(0)
+    n = 4096 + 8
+    p = g0.standard_normal(n).astype(np.float32); g = g0.standard_normal(n).astype(np.float32) * 0.1
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    pd, gd, md, vd = d(p), d(g), d(m), d(v)
+    plp = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    for t in (1, 2, 3):
+        lr, b1 = OO.onecycle(t - 1, 100, 1e-3, 0.0, 25)
+        OO.adamw_step(p, g * 0.5, m, v, t, lr, b1, 0.999, 1e-8, 5e-5)
+        check(l.nbci_adamw(vp(pd), vp(gd), vp(md), vp(vd), vp(plp), n, lr, b1, 0.999, 1e-8, 5e-5, 1 - b1 ** t, 1 - 0.999 ** t,
+                           0.5, st()), "nbci_adamw")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pd.cpu().numpy(), p, atol=2e-6)
+    np.testing.assert_allclose(md.cpu().numpy(), m, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, atol=1e-8)
+    assert torch.equal(plp, pd.bfloat16())
+
+
+@pytest.mark.parametrize("H", [32, 1024, 768])
+def test_layernorm_fwd_bwd(H):
+    l, check = _l()
+    g0 = np.random.default_rng(1)
+    M = 77
+    x = g0.standard_normal((M, H)).astype(np.float32) * 2 + 0.5
+    w = g0.standard_normal(H).astype(np.float32); b = g0.standard_normal(H).astype(np.float32)
+    dy = g0.standard_normal((M, H)).astype(np.float32)
+    y, xhat, rstd = O.layer_norm(x.astype(np.float64), w, b)
+    dx, dw, db = O.layer_norm_bwd(dy.astype(np.float64), xhat, rstd, w)
+    xd, wd, bd, dyd = d(x), d(w), d(b), d(dy)
+    yd = torch.zeros(M, H, device=DEV); mean = torch.zeros(M, device=DEV); rs = torch.zeros(M, device=DEV)
+    for fn in (l.nbci_layernorm_fwd, l.nbci_layernorm_bwd):
+        fn.restype = C.c_int
+    check(l.nbci_layernorm_fwd(vp(xd), vp(wd), vp(bd), vp(yd), 0, vp(mean), vp(rs), M, H, st()), "ln_fwd")
+    dxd = torch.ones(M, H, device=DEV); dwd = torch.zeros(H, device=DEV); dbd = torch.zeros(H, device=DEV)
+    check(l.nbci_layernorm_bwd(vp(dyd), vp(xd), vp(wd), vp(mean), vp(rs), vp(dxd), vp(dwd), vp(dbd), M, H, 1, st()), "ln_bwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(yd.cpu().numpy(), y, atol=2e-5)
+    np.testing.assert_allclose(dxd.cpu().numpy(), dx + 1, atol=5e-5)
+    np.testing.assert_allclose(dwd.cpu().numpy(), dw, atol=2e-4)
+    np.testing.assert_allclose(dbd.cpu().numpy(), db, atol=2e-4)
+
+
+@pytest.mark.parametrize("Tp,ctx", [(143, (-2, -2)), (37, (3, 2)), (300, (0, -2)), (18, (-1, -1))])
+def test_softmax_fwd_bwd_mask_and_dropout(Tp, ctx):
+    l, check = _l()
+    g0 = np.random.default_rng(2)
+    B, nh = 2, 3
+    ldS, ldP = (Tp + 3) // 4 * 4, (Tp + 7) // 8 * 8
+    S = np.zeros((B, nh, Tp, ldS), np.float32); S[..., :Tp] = g0.standard_normal((B, nh, Tp, Tp))
+    tm = (g0.random((B, Tp)) > 0.3).astype(np.int32)
+    cm = O.context_mask(ctx[0], ctx[1], max(Tp, 4))[:Tp, :Tp]
+    am = (np.eye(Tp, dtype=np.int64)[None] | (cm[None] & tm[:, None, :])).astype(bool)
+    s = np.where(am[:, None], S[..., :Tp].astype(np.float64), -np.inf)
+    e = np.exp(s - s.max(-1, keepdims=True)); P = e / e.sum(-1, keepdims=True)
+    p_drop, seed, site = 0.4, 99, 16
+    keep = R.keep_mask(seed, site, B * nh * Tp * Tp, p_drop).reshape(B, nh, Tp, Tp)
+    Pd_ = torch.zeros(B, nh, Tp, ldP, device=DEV); Pdd = torch.zeros(B, nh, Tp, ldP, device=DEV)
+    for fn in (l.nbci_softmax_fwd, l.nbci_softmax_bwd):
+        fn.restype = C.c_int
+    Sd, tmd = d(S), d(tm)
+    check(l.nbci_softmax_fwd(vp(Sd), vp(Pd_), vp(Pdd), 0, vp(tmd), B, nh, Tp, ldS, ldP, ctx[0], ctx[1], C.c_float(p_drop),
+                             seed, site, st()), "softmax_fwd")
+    dPd = np.zeros((B, nh, Tp, ldS), np.float32); dPd[..., :Tp] = g0.standard_normal((B, nh, Tp, Tp))
+    dS = torch.zeros(B, nh, Tp, ldP, device=DEV)
+    dPdd = d(dPd)
+    check(l.nbci_softmax_bwd(vp(dPdd), vp(Pd_), vp(dS), 0, B, nh, Tp, ldS, ldP, C.c_float(p_drop), seed, site, st()), "softmax_bwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Pd_[..., :Tp].cpu().numpy(), P, atol=2e-6)
+    np.testing.assert_allclose(Pdd[..., :Tp].cpu().numpy(), P * keep, atol=5e-6)
+    dP = dPd[..., :Tp].astype(np.float64) * keep
+    ref = P * (dP - (dP * P).sum(-1, keepdims=True))
+    np.testing.assert_allclose(dS[..., :Tp].cpu().numpy(), ref, atol=2e-5)
+
+
+def test_smooth_noise_matches_oracle():
+    l, check = _l()
+    g0 = np.random.default_rng(3)
+    B, T, N = 3, 70, 24
+    x = g0.standard_normal((B, T, N)).astype(np.float32)
+    taps = O.gaussian_taps(2).astype(np.float32)
+    out = torch.zeros(B, T, N, device=DEV)
+    l.nbci_smooth_noise.restype = C.c_int
+    xd, tapd = d(x), d(taps)
+    check(l.nbci_smooth_noise(vp(xd), vp(out), 0, B, T, N, vp(tapd), len(taps), C.c_float(0.0), C.c_float(0.0), 0, st()), "smooth")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), O.smooth(x, O.gaussian_taps(2)), atol=2e-6)
+    check(l.nbci_smooth_noise(vp(xd), vp(out), 0, B, T, N, vp(tapd), len(taps), C.c_float(1.0), C.c_float(0.2), 5, st()), "smooth")
+    torch.cuda.synchronize()
+    ref = O.smooth(x, O.gaussian_taps(2)) + R.normal(5, 1, B * T * N).reshape(B, T, N) + 0.2 * R.normal(5, 2, B * N).reshape(B, 1, N)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-4)
+    noise = out.cpu().numpy() - O.smooth(x, O.gaussian_taps(2))
+    assert abs(noise.std() - np.sqrt(1 + 0.04)) < 0.05 and abs(noise.mean()) < 0.05

@@ -1,0 +1,263 @@
+"""GPU parity of the HIP NDT1-CTC path (through the C-ABI) against
+  (a) the golden fixtures produced by the reference itself (tests/golden), and
+  (b) the numpy oracle on the same seeded inputs, including train mode with dropout + noise
+      (the oracle mirrors the kernels' stateless RNG bit for bit).
+Tolerances: fp32 path logits/log-probs <= 1e-3 abs (north_star), argmax / decode / PER bit-exact;
+bf16 path: stated per test.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics as OM
+from oracle import ndt1 as O
+from test_oracle_golden import batch_of, cfg_from_json, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(over, vocab, dtype="fp32", seed=1):
+    from llm_bci_amd.ndt1 import NDT1
+    torch.manual_seed(seed)
+    return NDT1(over, method_name="ctc", vocab_size=vocab, blank_id=0, zero_infinity=True, compute_dtype=dtype)
+
+
+def _to_dev(batch):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in batch.items()}
+
+
+def _grads(model, batch, train, seed=7):
+    """native (non-autograd) forward + full backward; returns loss vector, preds, {name: grad}"""
+    model.train(train)
+    loss, preds = model._run_forward(batch, want_grad=True, seed=seed)
+    g = torch.zeros_like(model._flat)
+    model._run_backward(g)
+    torch.cuda.synchronize()
+    out = {}
+    for (name, off, numel, shape, _s) in model._layout:
+        out[name] = g[off:off + numel].view(shape).cpu().numpy()
+    return loss.cpu().numpy(), preds.cpu().numpy(), out
+
+
+def _det_over(js):
+    over = json.loads(js)
+    e = over.setdefault("encoder", {})
+    e.setdefault("smooth_and_noise", {})["noise"] = False
+    e.setdefault("embedder", {})["dropout"] = 0.0
+    e.setdefault("transformer", {})["dropout"] = 0.0
+    return over
+
+
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope"])
+def test_tiny_golden_fp32(name):
+    fx = load(name)
+    m = _model(_det_over(str(fx["config_json"])), 11)
+    sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w0:")}
+    m.load_state_dict(sd)
+    m.to(DEV)
+    batch = _to_dev(batch_of(fx))
+    m.eval()
+    with torch.no_grad():
+        out = m(**batch)
+    torch.cuda.synchronize()
+    preds = out.preds.cpu().numpy()
+    np.testing.assert_allclose(preds, fx["eval_preds"], atol=1e-3)
+    np.testing.assert_allclose(out.loss.item(), float(fx["eval_loss"]), rtol=1e-4)
+    assert int(out.n_examples) == int(fx["n_examples"])
+    assert np.array_equal(m.last_argmax.cpu().numpy(), fx["argmax"])
+    loss, _, g = _grads(m, batch, train=True)
+    np.testing.assert_allclose(loss.sum(), float(fx["train_loss"]), rtol=1e-4)
+    for k, gv in g.items():
+        ref = fx["grad:" + k]
+        np.testing.assert_allclose(gv, ref, atol=5e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("name,over", [
+    ("g_c1", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}),
+    ("g_c2", {}),
+])
+def test_c1_c2_golden_fp32(name, over):
+    fx = load(name)
+    m = _model(_det_over(json.dumps(over)), 41).to(DEV)
+    batch = _to_dev(batch_of(fx))
+    m.eval()
+    with torch.no_grad():
+        out = m(**batch)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.preds.cpu().numpy(), fx["eval_preds"], atol=1e-3)
+    np.testing.assert_allclose(out.loss.item(), float(fx["eval_loss"]), rtol=1e-4)
+    assert np.array_equal(m.last_argmax.cpu().numpy(), fx["argmax"])           # bit-exact alignment indices
+    loss, _, g = _grads(m, batch, train=True)
+    np.testing.assert_allclose(loss.sum(), float(fx["train_loss"]), rtol=1e-4)
+    for k, gv in g.items():
+        ref = fx["gval:" + k]
+        got = gv.reshape(-1)[fx["gidx:" + k]]
+        np.testing.assert_allclose(got, ref, atol=1e-3 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+        s, a = fx["gsum:" + k]
+        assert abs(np.abs(gv.astype(np.float64)).sum() - a) <= 5e-3 * a + 1e-5, k
+
+
+def test_c2_golden_bf16():
+    """bf16 operands, f32 accumulate: log-probs within 0.08 abs of the reference's fp32 run and
+    >= 97 % of the greedy path identical (frames whose fp32 top-2 margin is below bf16 noise may flip)."""
+    fx = load("g_c2")
+    m = _model(_det_over("{}"), 41, dtype="bf16").to(DEV)
+    batch = _to_dev(batch_of(fx))
+    m.eval()
+    with torch.no_grad():
+        out = m(**batch)
+    torch.cuda.synchronize()
+    preds = out.preds.cpu().numpy()
+    assert np.abs(preds - fx["eval_preds"]).max() < 0.08
+    assert abs(out.loss.item() - float(fx["eval_loss"])) / float(fx["eval_loss"]) < 5e-3
+    am = m.last_argmax.cpu().numpy()
+    safe = fx["margin"] > 0.1
+    assert np.array_equal(am[safe], fx["argmax"][safe])
+    assert (am == fx["argmax"]).mean() > 0.97
+    _, _, g = _grads(m, batch, train=True)
+    for k, gv in g.items():
+        s, a = fx["gsum:" + k]
+        if a > 1e-3:
+            assert abs(np.abs(gv.astype(np.float64)).sum() - a) <= 0.05 * a, (k, np.abs(gv).sum(), a)
+
+
+def _oracle_cfg(m, **kw):
+    c = m._ccfg
+    return O.make_config(n_channels=c.n_channels, input_dim=c.input_dim, stack_size=c.stack_size, stack_stride=c.stack_stride,
+                         hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads, inter=c.inter, vocab=c.vocab, max_F=c.max_F,
+                         smooth_sd=int(c.smooth_sd), noise=bool(c.noise), white_noise_sd=c.white_noise_sd,
+                         constant_offset_sd=c.constant_offset_sd, embed_dropout=c.embed_dropout, dropout=c.dropout,
+                         use_rope=bool(c.use_rope), context_forward=c.context_forward, context_backward=c.context_backward, **kw)
+
+
+def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
+    g = np.random.default_rng(seed)
+    spikes = g.standard_normal((B, T, N)).astype(np.float32)
+    mask = np.zeros((B, T), np.int64)
+    ts = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):
+        spikes[b, L:] = 0
+        mask[b, :L] = 1
+        ts[b, :L] = np.arange(L)
+    return dict(spikes=spikes, spikes_mask=mask, spikes_timestamp=ts, spikes_lengths=np.array(lens, np.int64),
+                targets=g.integers(1, vocab, (B, S)).astype(np.int64), targets_lengths=np.array(tlens, np.int64))
+
+
+@pytest.mark.parametrize("which", ["tiny", "c1"])
+def test_train_mode_matches_oracle_with_dropout_and_noise(which):
+    """recipe dropout (0.2 / 0.4) and noise ON: HIP and oracle draw identical masks (same counter RNG)."""
+    if which == "tiny":
+        over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                            "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+        vocab, batch = 11, _rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2])
+    else:
+        over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
+        vocab, batch = 41, _rand_batch(4, 100, 64, 10, 41, [100, 100, 80, 64], [10, 8, 6, 3])
+    m = _model(over, vocab).to(DEV)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    loss, preds, g = _grads(m, _to_dev(batch), train=True, seed=1234)
+    cfg = _oracle_cfg(m)
+    o, cache = O.forward(cfg, p, batch, train=True, seed=1234)
+    go = O.backward(cache)
+    np.testing.assert_allclose(preds, o["preds"], atol=1e-3)
+    np.testing.assert_allclose(loss, o["loss_per_sample"], rtol=2e-4, atol=1e-3)
+    for k in g:
+        tol = 1e-3 * max(1.0, float(np.abs(go[k]).max()))
+        np.testing.assert_allclose(g[k], go[k], atol=tol, err_msg=k)
+    # dropout actually happened: eval-mode output differs
+    m.eval()
+    l2, _ = m._run_forward(_to_dev(batch), want_grad=False)
+    assert abs(float(l2.sum()) - float(loss.sum())) > 1e-3
+
+
+def test_autograd_path_equals_native_and_ga_scaling():
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = _model(over, 11).to(DEV)
+    batch = _to_dev(_rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2]))
+    _, _, g = _grads(m, batch, train=False)
+    m.eval()
+    out = m(**batch)
+    (out.loss / 4).backward()                      # trainer.py:339 divides by gradient_accumulation_steps
+    torch.cuda.synchronize()
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        np.testing.assert_allclose(p.grad.cpu().numpy() * 4, g[name], atol=1e-5 * max(1.0, np.abs(g[name]).max()), err_msg=name)
+
+
+def test_infeasible_ctc_sample_contributes_nothing():
+    """zero_infinity=True: a target longer than the token count gives loss 0 and zero gradients."""
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = _model(over, 11).to(DEV)
+    b = _rand_batch(2, 12, 16, 9, 11, [12, 12], [9, 2])   # T'=5 tokens < 9 labels for sample 0
+    loss, preds, g = _grads(m, _to_dev(b), train=False)
+    assert loss[0] == 0.0 and loss[1] > 0
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    o, cache = O.forward(_oracle_cfg(m), p, b, train=False)
+    go = O.backward(cache)
+    for k in g:
+        np.testing.assert_allclose(g[k], go[k], atol=1e-4 * max(1.0, float(np.abs(go[k]).max())), err_msg=k)
+
+
+def test_per_metric_device_matches_reference_fixture_and_oracle():
+    import ctypes as C
+    from llm_bci_amd._lib import check, lib
+    fx = load("metric_cases")
+    po = np.concatenate([[0], np.cumsum(fx["paths_len"])]); to = np.concatenate([[0], np.cumsum(fx["tgts_len"])])
+    n = len(fx["paths_len"]); Tp = int(fx["paths_len"].max()); S = int(fx["tgts_len"].max())
+    paths = np.zeros((n, Tp), np.int32); tg = np.zeros((n, S), np.int64)
+    for i in range(n):
+        pth = fx["paths_flat"][po[i]:po[i + 1]]
+        paths[i, :len(pth)] = pth                     # trailing frames = blank, as padded frames decode
+        tg[i, :fx["tgts_len"][i]] = fx["tgts_flat"][to[i]:to[i + 1]]
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    pa, tgd, tl = d(paths), d(tg), d(fx["tgts_len"].astype(np.int64))
+    dec = torch.zeros(n, Tp, dtype=torch.int32, device=DEV); dl = torch.zeros(n, dtype=torch.int32, device=DEV)
+    err = torch.zeros(n, 2, dtype=torch.int32, device=DEV); scr = torch.zeros(n * 2 * (S + 2), dtype=torch.int32, device=DEV)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    check(lib().nbci_per(vp(pa), vp(tgd), vp(tl), n, Tp, S, 0, vp(dec), vp(dl), vp(err), vp(scr),
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nbci_per")
+    torch.cuda.synchronize()
+    assert np.array_equal(err.cpu().numpy(), fx["per"])
+    do = np.concatenate([[0], np.cumsum(fx["dec_len"])])
+    for i in range(n):
+        assert list(dec[i, :dl[i]].cpu().numpy()) == list(fx["dec_flat"][do[i]:do[i + 1]])
+    # random paths vs oracle
+    g = np.random.default_rng(5)
+    paths = g.integers(0, 6, (16, 40)).astype(np.int32); tg = g.integers(1, 6, (16, 12)).astype(np.int64)
+    tl = g.integers(0, 13, (16,)).astype(np.int64)
+    pa, tgd, tld = d(paths), d(tg), d(tl)
+    dec = torch.zeros(16, 40, dtype=torch.int32, device=DEV); dl = torch.zeros(16, dtype=torch.int32, device=DEV)
+    err = torch.zeros(16, 2, dtype=torch.int32, device=DEV); scr = torch.zeros(16 * 2 * 14, dtype=torch.int32, device=DEV)
+    check(lib().nbci_per(vp(pa), vp(tgd), vp(tld), 16, 40, 12, 0, vp(dec), vp(dl), vp(err), vp(scr),
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nbci_per")
+    torch.cuda.synchronize()
+    for i in range(16):
+        dd = OM.format_ctc(paths[i], 0)
+        tt = list(tg[i, :tl[i]])
+        assert (OM.edit_distance(dd if dd else [""], tt if tt else [""]), max(1, len(tt))) == tuple(err[i].cpu().numpy())
+
+
+def test_checkpoint_roundtrip_and_reference_key_layout(tmp_path):
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = _model(over, 11).to(DEV)
+    batch = _to_dev(_rand_batch(2, 20, 16, 3, 11, [20, 20], [3, 2]))
+    m.eval()
+    with torch.no_grad():
+        a = m(**batch).preds.cpu()
+    m.save_checkpoint(str(tmp_path))
+    enc = torch.load(os.path.join(tmp_path, "encoder.bin"))
+    assert "embedder.stack_projection.weight" in enc and "layers.0.attn.query.weight" in enc and "out_norm.bias" in enc
+    assert set(torch.load(os.path.join(tmp_path, "decoder.bin")).keys()) == {"0.weight", "0.bias"}
+    m2 = _model(over, 11, seed=99).to(DEV)
+    m2.load_checkpoint(str(tmp_path))
+    m2.eval()
+    with torch.no_grad():
+        b = m2(**batch).preds.cpu()
+    assert torch.equal(a, b)

@@ -1,0 +1,76 @@
+"""GPU: the native train step (fwd + bwd + fused AdamW + OneCycle + zero_grad) against the
+reference-generated golden weights after two steps, against the oracle trainer with dropout
+on, and gradient-accumulation semantics (trainer.py:335-349)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ndt1 as O
+from oracle.step import CpuTrainer
+from test_ndt1_gpu import _det_over, _model, _oracle_cfg, _rand_batch, _to_dev
+from test_oracle_golden import batch_of, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_two_adamw_onecycle_steps_match_reference_golden_c1():
+    from llm_bci_amd.trainer import NativeTrainer
+    fx = load("g_c1")
+    over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
+    m = _model(_det_over(json.dumps(over)), 41).to(DEV)
+    tr = NativeTrainer(m, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=100, warmup_pct=0.0, div_factor=25)
+    batch = _to_dev(batch_of(fx))
+    for s in range(2):
+        loss, _ = tr.train_step(batch)
+        np.testing.assert_allclose(float(loss.sum()), float(fx[f"loss_step{s}"]), rtol=2e-4)
+    torch.cuda.synchronize()
+    for k, v in m.state_dict().items():
+        if k.endswith("attn.key.bias"):
+            continue
+        d = np.abs(v.cpu().numpy().reshape(-1)[fx["w0idx:" + k]] - fx["w2val:" + k])
+        assert (d > 3e-5).mean() <= 0.05 and d.max() <= 2.1e-3, (k, d.max())
+    st = tr.read_stats()
+    assert st["n_examples"] == 4 and st["PER"] is not None
+
+
+@pytest.mark.parametrize("ga", [1, 2])
+def test_train_steps_match_oracle_trainer_with_dropout(ga):
+    from llm_bci_amd.trainer import NativeTrainer
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    m = _model(over, 11).to(DEV)
+    p0 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    tr = NativeTrainer(m, total_steps=20, gradient_accumulation_steps=ga)
+    ct = CpuTrainer(_oracle_cfg(m), p0, total_steps=20, ga=ga)
+    b = _rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2])
+    bd = _to_dev(b)
+    for s in range(4):
+        loss, _ = tr.train_step(bd, seed=50 + s)
+        out = ct.step(b, train=True, seed=50 + s)
+        np.testing.assert_allclose(loss.cpu().numpy(), out["loss_per_sample"], rtol=2e-3, atol=2e-3)
+    torch.cuda.synchronize()
+    assert tr.opt_step == ct.opt_step
+    for k, v in m.state_dict().items():
+        if k.endswith("attn.key.bias"):
+            continue
+        d = np.abs(v.cpu().numpy() - ct.p[k])
+        assert (d > 5e-5).mean() < 0.02 and d.max() < 8.1e-3, (k, d.max(), (d > 5e-5).mean())
+
+
+def test_bf16_training_reduces_loss_and_keeps_shadow_in_sync():
+    from llm_bci_amd.trainer import NativeTrainer
+    over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
+    m = _model(over, 41, dtype="bf16").to(DEV)
+    tr = NativeTrainer(m, total_steps=40)
+    bd = _to_dev(_rand_batch(8, 100, 64, 10, 41, [100] * 8, [10] * 8))
+    losses = []
+    for s in range(12):
+        loss, _ = tr.train_step(bd, seed=s)
+        losses.append(float(loss.sum()))
+    torch.cuda.synchronize()
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert torch.equal(m._flat_lp, m._flat.bfloat16())
+    assert all(np.isfinite(losses))
