@@ -63,7 +63,8 @@ const char* nbci_last_error(void);
  * Batch z (0 <= z < batch) adds (z / zdiv) * zs1 + (z % zdiv) * zs2.
  * Epilogue order: acc*alpha (+bias[n]) -> [store C2 = pre-activation] -> (+residual if
  * residual_first) -> act -> (*act'(gate)) -> dropout -> (+residual) -> (+beta*C) -> store C.
- * The dropout draw for an element is rng(seed, site, element offset inside C).
+ * The dropout draw for an element is keyed by (seed, site, element offset inside C): one 32-bit
+ * hash per pair of elements, 16 bits each, drop iff draw < floor(p * 65536).
  * splitk > 1: C(f32) += partial via atomics; then only alpha is honoured.
  */
 typedef struct nbci_operand {
@@ -101,6 +102,8 @@ typedef struct nbci_gemm_desc {
     const void* gate;             /* optional [M][ldg] in in_dtype: result *= act'(gate) (GELU/softsign backward) */
     int64_t ldg;
     int32_t gate_act;
+    float* colsum;                /* optional f32 [N]: colsum[n] += sum_m C[m][n] of the STORED values (bias
+                                     gradient fused into the GEMM that produces the activation gradient) */
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);

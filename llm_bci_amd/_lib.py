@@ -7,6 +7,10 @@ raises `NbciUnavailable` loudly.
 import ctypes as C
 import os
 
+# PyTorch bundles its own libamdhip64.so.7; it must be the copy that gets loaded (libnbci.so then
+# binds to it by SONAME), otherwise two HIP runtimes end up in one process and neither sees the GPU.
+import torch  # noqa: F401  (keep this import BEFORE loading libnbci.so)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnbci.so")
 
@@ -37,7 +41,8 @@ class GemmDesc(C.Structure):
                 ("act", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
                 ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
-                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32)]
+                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32),
+                ("colsum", C.c_void_p)]
 
 
 class NDT1Config(C.Structure):
@@ -108,6 +113,9 @@ def lib():
         raise NbciUnavailable(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C llm_bci_amd/csrc` (needs hipcc). There is no CPU fallback for the product path.")
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     l = C.CDLL(LIB_PATH)
     l.nbci_version.restype = C.c_int
     l.nbci_last_error.restype = C.c_char_p

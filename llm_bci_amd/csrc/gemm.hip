@@ -60,7 +60,8 @@ struct GemmK {
     float alpha, beta;
     const float* bias;
     int act;
-    float drop_scale; unsigned drop_thr; unsigned seed, site;
+    float drop_scale; unsigned drop_thr; unsigned drop_key;
+    float* colsum;  // optional: colsum[(coff % ldc) + n] += sum over rows of the stored value
     const float* residual; long long ldr;
     const long long* residual_rows;  // optional gather: residual row for output row m
     int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
@@ -282,6 +283,36 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
 
     // ---- epilogue: lane owns m = .. + (lane&15), n = .. + 4*(lane>>4) + 0..3 ---------------
     const int i16 = lane & 15, g = lane >> 4;
+    if (d.splitk > 1) {
+        // Split-K partials go to C with f32 atomics. A wave-instruction of float atomics runs at full
+        // rate only when it covers 256 contiguous bytes, so each wave first transposes its 64x64
+        // accumulator through LDS (XOR-swizzled float4 columns: conflict-free both ways) and then
+        // issues one atomic per ROW: 64 lanes = 64 consecutive n.
+        float* sw = (float*)smem + w * 4096;  // 16 KB per wave; main-loop LDS is dead after the last barrier
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ml = mi * 16 + i16, c4 = ni * 4 + g;
+                *(float4*)(sw + ml * 64 + ((c4 ^ (ml & 15)) << 2)) =
+                    make_float4(acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha, acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha);
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+        const int nn = n0 + wn * 64 + lane;
+        float* cbase = (float*)d.C + nn;
+        for (int ml = 0; ml < 64; ++ml) {
+            const int m = m0 + wm * 64 + ml;
+            if (m >= d.M) break;
+            const float val = sw[ml * 64 + ((((lane >> 2) ^ (ml & 15)) << 2) | (lane & 3))];
+            if (nn < d.N) atomicAdd(cbase + (long long)m * d.ldc, val);
+        }
+        return;
+    }
+    float csum[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) csum[a][b] = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + i16;
@@ -293,13 +324,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
             float v[4] = {acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha,
                           acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha};
             const long long cidx = coff + (long long)m * d.ldc + n;
-            if (d.splitk > 1) {
-                float* c = (float*)d.C + cidx;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < d.N) atomicAdd(c + e, v[e]);
-                continue;
-            }
             const bool full = (n + 3 < d.N) && d.cvec;
             if (d.bias) {
                 if (full) {
@@ -345,15 +369,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
                 // dropout stream index = element offset inside C (so a head-batched GEMM that writes
                 // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
                 const unsigned idx = (unsigned)cidx;
+                if ((idx & 1u) == 0u) {
+                    drop4(d.drop_key, d.drop_thr, idx, d.drop_scale, v);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = (rng_u32(d.seed, d.site, idx + e) >= d.drop_thr) ? v[e] * d.drop_scale : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = drop_keep(d.drop_key, d.drop_thr, idx + e) ? v[e] * d.drop_scale : 0.f;
+                }
             }
             if (d.residual && !d.residual_first) {
                 const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
                 const float* r = d.residual + rr * d.ldr + n;
                 if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
                 else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+            }
+            if (d.colsum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[ni][e] += v[e];
             }
             if (d.c_bf16) {
                 bf16_t* c = (bf16_t*)d.C + cidx;
@@ -370,6 +401,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
             }
         }
     }
+    if (d.colsum) {
+        // bias gradient fused into the producing GEMM: reduce this wave's 64 rows (16 lanes x 4 mi)
+        // with shuffles, then one atomic per column per wave
+        const int cbase = (int)(coff % d.ldc);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = csum[ni][e];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                const int n = n0 + wn * 64 + ni * 16 + 4 * g + e;
+                if (i16 == 0 && n < d.N) atomicAdd(d.colsum + cbase + n, t);
+            }
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -384,7 +429,8 @@ static bool operand_vec_ok(const nbci_operand& o, int E, size_t esz) {
 
 template <typename T, bool AK, bool BKM>
 static int launch_inst(const GemmK& k, dim3 grid, hipStream_t stream) {
-    constexpr int lds = 4 * GemmTile<T>::REGION;
+    // split-K transposes the 4 x 16 KB accumulator tiles through LDS in its epilogue
+    const int lds = (k.splitk > 1 && 4 * GemmTile<T>::REGION < 65536) ? 65536 : 4 * GemmTile<T>::REGION;
     hipLaunchKernelGGL((gemm_kernel<T, AK, BKM>), grid, dim3(GEMM_THREADS), lds, stream, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm launch: ") + hipGetErrorString(e));
@@ -408,7 +454,7 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     const int splitk = d.splitk > 1 ? d.splitk : 1;
     NBCI_REQUIRE(!(splitk > 1 && batch > 1), NBCI_EINVAL, "gemm: splitk and batch are exclusive");
     NBCI_REQUIRE(!(splitk > 1 && d.c_dtype != NBCI_F32), NBCI_EINVAL, "gemm: splitk needs f32 C");
-    NBCI_REQUIRE(!(splitk > 1 && (d.bias || d.act || d.residual || d.C2 || d.gate || d.drop_p > 0.f)), NBCI_EINVAL,
+    NBCI_REQUIRE(!(splitk > 1 && (d.bias || d.act || d.residual || d.C2 || d.gate || d.colsum || d.drop_p > 0.f)), NBCI_EINVAL,
                  "gemm: splitk supports alpha only");
     NBCI_REQUIRE(!(d.beta != 0.f && d.c_dtype != NBCI_F32), NBCI_EINVAL, "gemm: beta needs f32 C");
     NBCI_REQUIRE(d.drop_p >= 0.f && d.drop_p < 1.f, NBCI_EINVAL, "gemm: drop_p out of [0,1)");
@@ -434,7 +480,8 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     k.bias = d.bias; k.act = d.act;
     k.drop_thr = drop_threshold(d.drop_p);
     k.drop_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
-    k.seed = d.seed; k.site = d.site;
+    k.drop_key = drop_key(d.seed, d.site);
+    k.colsum = d.colsum;
     k.residual = d.residual; k.ldr = d.ldr;
     k.residual_rows = (const long long*)d.residual_rows; k.residual_first = d.residual_first;
     k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16;

@@ -38,6 +38,9 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
 // out(act dtype) = in(f32) * keepmask(site)   (p = 0: plain cast)
 int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float drop_p, uint32_t seed,
                     uint32_t site, hipStream_t s);
+// 2-D form with the bias-gradient column sum fused in: colsum[n] += sum_m out[m][n] (may be NULL)
+int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed,
+                      uint32_t site, float* colsum, hipStream_t s);
 // out[n] += sum_m in[m][n]  (bias gradients)
 int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s);
 

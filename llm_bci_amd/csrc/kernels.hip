@@ -164,7 +164,7 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
     return check_launch("layernorm_fwd");
 }
 
-constexpr int LNB_ROWS = 32;  // rows per block in the backward
+constexpr int LNB_ROWS = 16;  // rows per block in the backward (4 per wave): ~2 blocks/CU at M = 9152
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -274,7 +274,7 @@ template <int NV, typename TP>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, TP* __restrict__ P,
                                                           TP* __restrict__ Pd, const int32_t* __restrict__ tmask,
                                                           int rows, int nh, int Tp, int ldS, int ldP, int cf, int cb,
-                                                          unsigned thr, float dscale, uint32_t seed, uint32_t site) {
+                                                          unsigned thr, float dscale, uint32_t key) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
             stf<TP>(pr, j, p);
             if (thr && j < Tp) {
                 const unsigned idx = (unsigned)((long long)row * Tp + j);
-                p = (rng_u32(seed, site, idx) >= thr) ? p * dscale : 0.f;
+                p = drop_keep(key, thr, idx) ? p * dscale : 0.f;
             }
             stf<TP>(pdr, j, p);
         }
@@ -329,10 +329,10 @@ int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int
     DISPATCH_DTYPE(p_dtype, TP, {
         if (ldP <= 256)
             hipLaunchKernelGGL((softmax_fwd_kernel<4, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
-                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, seed, site);
+                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, drop_key(seed, site));
         else
             hipLaunchKernelGGL((softmax_fwd_kernel<16, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
-                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, seed, site);
+                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, drop_key(seed, site));
     });
     return check_launch("softmax_fwd");
 }
@@ -340,7 +340,7 @@ int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int
 template <int NV, typename TP>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dPd, const TP* __restrict__ P,
                                                           TP* __restrict__ dS, int rows, int Tp, int ldS, int ldP,
-                                                          unsigned thr, float dscale, uint32_t seed, uint32_t site) {
+                                                          unsigned thr, float dscale, uint32_t key) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
             float g = dPd[(long long)row * ldS + j];
             if (thr) {
                 const unsigned idx = (unsigned)((long long)row * Tp + j);
-                g = (rng_u32(seed, site, idx) >= thr) ? g * dscale : 0.f;
+                g = drop_keep(key, thr, idx) ? g * dscale : 0.f;
             }
             dp[k] = g;
             dot += g * p[k];
@@ -379,10 +379,10 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
     DISPATCH_DTYPE(p_dtype, TP, {
         if (ldP <= 256)
             hipLaunchKernelGGL((softmax_bwd_kernel<4, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
-                               ldP, thr, dscale, seed, site);
+                               ldP, thr, dscale, drop_key(seed, site));
         else
             hipLaunchKernelGGL((softmax_bwd_kernel<16, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
-                               ldP, thr, dscale, seed, site);
+                               ldP, thr, dscale, drop_key(seed, site));
     });
     return check_launch("softmax_bwd");
 }
@@ -390,40 +390,49 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
 // ------------------------------------------------------------------------------------------
 // dropout-cast, cast, colsum
 // ------------------------------------------------------------------------------------------
+constexpr int DC_ROWS = 32;  // rows per block
+
+// out = in * keepmask (act dtype), optionally colsum[n] += sum_m out[m][n]. One thread owns 4
+// consecutive columns of DC_ROWS rows, so the bias-gradient column sums cost one atomic per column per block.
 template <typename TO>
-__global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n,
-                                                       unsigned thr, float dscale, uint32_t seed, uint32_t site) {
-    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const long long stride = (long long)gridDim.x * 256 * 4;
-    for (; i < n; i += stride) {
-        if (i + 3 < n) {
-            float4 v = *(const float4*)(in + i);
-            if (thr) {
-                v.x = (rng_u32(seed, site, (unsigned)i + 0) >= thr) ? v.x * dscale : 0.f;
-                v.y = (rng_u32(seed, site, (unsigned)i + 1) >= thr) ? v.y * dscale : 0.f;
-                v.z = (rng_u32(seed, site, (unsigned)i + 2) >= thr) ? v.z * dscale : 0.f;
-                v.w = (rng_u32(seed, site, (unsigned)i + 3) >= thr) ? v.w * dscale : 0.f;
-            }
-            stf<TO>(out, i, v.x); stf<TO>(out, i + 1, v.y); stf<TO>(out, i + 2, v.z); stf<TO>(out, i + 3, v.w);
-        } else {
-            for (long long e = i; e < n; ++e) {
-                float v = in[e];
-                if (thr) v = (rng_u32(seed, site, (unsigned)e) >= thr) ? v * dscale : 0.f;
-                stf<TO>(out, e, v);
-            }
-        }
+__global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, int M, int N,
+                                                       unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * DC_ROWS;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < min(M, r0 + DC_ROWS); ++r) {
+        const long long i = (long long)r * N + c;
+        const float4 q = *(const float4*)(in + i);
+        float v[4] = {q.x, q.y, q.z, q.w};
+        if (thr) drop4(key, thr, (unsigned)i, dscale, v);
+        stf<TO>(out, i, v[0]); stf<TO>(out, i + 1, v[1]); stf<TO>(out, i + 2, v[2]); stf<TO>(out, i + 3, v[3]);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
+    if (colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(colsum + c + e, s[e]);
+    }
+}
+
+int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed, uint32_t site,
+                      float* colsum, hipStream_t s) {
+    NBCI_REQUIRE(N % 4 == 0, NBCI_ESHAPE, "dropcast: N must be a multiple of 4");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    dim3 g((N / 4 + 255) / 256, (M + DC_ROWS - 1) / DC_ROWS);
+    DISPATCH_DTYPE(out_dtype, TO,
+                   hipLaunchKernelGGL((dropcast_kernel<TO>), g, dim3(256), 0, s, in, (TO*)out, M, N, thr, dscale,
+                                      drop_key(seed, site), colsum));
+    return check_launch("dropcast");
 }
 
 int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float drop_p, uint32_t seed, uint32_t site,
                     hipStream_t s) {
-    const unsigned thr = drop_threshold(drop_p);
-    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const long long blocks = std::min<long long>(2048, (n / 4 + 255) / 256 + 1);
-    DISPATCH_DTYPE(out_dtype, TO,
-                   hipLaunchKernelGGL((dropcast_kernel<TO>), dim3((unsigned)blocks), dim3(256), 0, s, in, (TO*)out,
-                                      (long long)n, thr, dscale, seed, site));
-    return check_launch("dropcast");
+    // flat form: treat as rows of 1024 (or one row when short / not divisible)
+    const int N = (n % 1024 == 0) ? 1024 : (int)n;
+    NBCI_REQUIRE(n % 4 == 0 && n / N < 2147483647LL, NBCI_ESHAPE, "dropcast: length must be a multiple of 4");
+    return dropcast2d_launch(in, out, out_dtype, (int)(n / N), N, drop_p, seed, site, nullptr, s);
 }
 
 int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s) {
@@ -500,12 +509,12 @@ int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype
 
 __global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tts,
                                                       float* __restrict__ dpos, int M, int H, unsigned thr, float dscale,
-                                                      uint32_t seed, uint32_t site) {
+                                                      uint32_t key) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), c = (int)(i % H);
     float v = dx[i];
-    if (thr) v = (rng_u32(seed, site, (unsigned)i) >= thr) ? v * dscale : 0.f;
+    if (thr) v = drop_keep(key, thr, (unsigned)i) ? v * dscale : 0.f;
     if (v != 0.f) atomicAdd(dpos + tts[row] * H + c, v);
 }
 
@@ -515,7 +524,7 @@ int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int 
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const long long total = (long long)M * H;
     hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, tts, dpos, M, H, thr,
-                       dscale, seed, site);
+                       dscale, drop_key(seed, site));
     return check_launch("posgrad");
 }
 
@@ -709,49 +718,76 @@ int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_len
     return check_launch("ctc");
 }
 
-// greedy decode with the reference's collapse rule + token Levenshtein; one lane per sample
-__global__ void per_kernel(const int32_t* __restrict__ argmax, const int64_t* __restrict__ targets,
-                           const int64_t* __restrict__ tgt_lens, int B, int Tp, int S, int blank,
-                           int32_t* __restrict__ decoded, int32_t* __restrict__ dec_lens, int32_t* __restrict__ errors,
-                           int32_t* __restrict__ scratch) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int32_t* dec = decoded + (long long)b * Tp;
-    int n = 0, last = -1;
-    for (int t = 0; t < Tp; ++t) {
-        const int idx = argmax[(long long)b * Tp + t];
-        if (idx != last && idx != blank) { dec[n++] = idx; last = idx; }  // `last` only moves on emission
-    }
-    dec_lens[b] = n;
-    for (int t = n; t < Tp; ++t) dec[t] = -1;
-    // " ".join([]).split(" ") == [""]: an empty side counts as ONE empty token (id -1)
+// greedy decode with the reference's collapse rule + token Levenshtein. One wave per sample: the
+// path is staged in LDS, lane 0 does the (inherently sequential) collapse, then the edit-distance
+// table is swept by anti-diagonals with 64 cells in flight.
+__global__ __launch_bounds__(64) void per_kernel(const int32_t* __restrict__ argmax, const int64_t* __restrict__ targets,
+                                                 const int64_t* __restrict__ tgt_lens, int Tp, int S, int blank,
+                                                 int32_t* __restrict__ decoded, int32_t* __restrict__ dec_lens,
+                                                 int32_t* __restrict__ errors) {
+    extern __shared__ int smi[];
+    int* path = smi;                // [Tp]
+    int* dec = path + Tp;           // [Tp]
+    int* tg = dec + Tp;             // [S + 1]
+    int* d0 = tg + S + 1;           // three diagonals, indexed by i (prediction position), [Tp + 2] each
+    int* d1 = d0 + Tp + 2;
+    int* d2 = d1 + Tp + 2;
+    __shared__ int s_n;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int t = lane; t < Tp; t += 64) path[t] = argmax[(long long)b * Tp + t];
     int nt = (int)tgt_lens[b];
     if (nt > S) nt = S;
-    const int na = n > 0 ? n : 1, nb = nt > 0 ? nt : 1;
-    int32_t* prev = scratch + (long long)b * 2 * (S + 2);
-    int32_t* cur = prev + (S + 2);
-    for (int j = 0; j <= nb; ++j) prev[j] = j;
-    for (int i = 1; i <= na; ++i) {
-        const int x = n > 0 ? dec[i - 1] : -1;
-        cur[0] = i;
-        for (int j = 1; j <= nb; ++j) {
-            const int y = nt > 0 ? (int)targets[(long long)b * S + j - 1] : -1;
-            int v = prev[j] + 1;
-            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
-            const int sub = prev[j - 1] + (x != y ? 1 : 0);
-            if (sub < v) v = sub;
-            cur[j] = v;
+    for (int j = lane; j < nt; j += 64) tg[j] = (int)targets[(long long)b * S + j];
+    __syncthreads();
+    if (lane == 0) {
+        int n = 0, last = -1;
+        for (int t = 0; t < Tp; ++t) {
+            const int idx = path[t];
+            if (idx != last && idx != blank) { dec[n++] = idx; last = idx; }  // `last` only moves on emission
         }
-        int32_t* tmp = prev; prev = cur; cur = tmp;
+        s_n = n;
     }
-    errors[2 * b] = prev[nb];
-    errors[2 * b + 1] = nb;
+    __syncthreads();
+    const int n = s_n;
+    for (int t = lane; t < Tp; t += 64) decoded[(long long)b * Tp + t] = t < n ? dec[t] : -1;
+    // " ".join([]).split(" ") == [""]: an empty side counts as ONE empty token (id -1)
+    const int na = n > 0 ? n : 1, nb = nt > 0 ? nt : 1;
+    int *p2 = d0, *p1 = d1, *cur = d2;
+    if (lane == 0) p1[0] = 0;  // diagonal 0
+    __syncthreads();
+    for (int d = 1; d <= na + nb; ++d) {
+        const int ilo = d - nb > 0 ? d - nb : 0, ihi = d < na ? d : na;
+        for (int i = ilo + lane; i <= ihi; i += 64) {
+            const int j = d - i;
+            int v;
+            if (i == 0) v = j;
+            else if (j == 0) v = i;
+            else {
+                const int x = n > 0 ? dec[i - 1] : -1, y = nt > 0 ? tg[j - 1] : -1;
+                v = p1[i - 1] + 1;                          // D[i-1][j]
+                const int ins = p1[i] + 1;                  // D[i][j-1]
+                const int sub = p2[i - 1] + (x != y ? 1 : 0);
+                v = ins < v ? ins : v;
+                v = sub < v ? sub : v;
+            }
+            cur[i] = v;
+        }
+        __syncthreads();
+        int* tmp = p2; p2 = p1; p1 = cur; cur = tmp;
+    }
+    if (lane == 0) {
+        dec_lens[b] = n;
+        errors[2 * b] = p1[na];
+        errors[2 * b + 1] = nb;
+    }
 }
 
 int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int B, int Tp, int S, int blank,
                int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, hipStream_t s) {
-    hipLaunchKernelGGL(per_kernel, dim3((B + 63) / 64), dim3(64), 0, s, argmax, targets, tgt_lens, B, Tp, S, blank, decoded,
-                       dec_lens, errors, scratch);
+    (void)scratch;  // kept in the C-ABI for callers that sized it; the table now lives in LDS
+    const size_t lds = (size_t)(2 * Tp + (S + 1) + 3 * (Tp + 2)) * sizeof(int);
+    NBCI_REQUIRE(lds <= 60000, NBCI_ESHAPE, "per: sequence too long for the LDS-resident edit distance");
+    hipLaunchKernelGGL(per_kernel, dim3(B), dim3(64), lds, s, argmax, targets, tgt_lens, Tp, S, blank, decoded, dec_lens, errors);
     return check_launch("per");
 }
 

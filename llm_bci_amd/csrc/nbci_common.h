@@ -55,12 +55,32 @@ __host__ __device__ __forceinline__ uint32_t rng_u32(uint32_t seed, uint32_t sit
     h = mix32(h ^ (site * 0xC2B2AE35U + 0x27D4EB2FU));
     return h;
 }
-// keep-mask for dropout probability p: threshold = floor(p * 2^32); keep iff draw >= threshold
+// ---- dropout draws: ONE 32-bit hash per PAIR of elements, 16 bits each (GEMM epilogues own
+// 4 consecutive elements per lane, so dropout costs two hashes per lane-quad; a full 32-bit
+// draw per element made the epilogue VALU work rival the K=1024 MFMA work).
+//   key  = drop_key(seed, site)                     (host, once per launch)
+//   keep = drop_keep(key, thr16, idx)  with thr16 = floor(p * 65536): P(drop) = thr16 / 65536
+__host__ __device__ __forceinline__ uint32_t drop_key(uint32_t seed, uint32_t site) {
+    return mix32(seed * 0x9E3779B9U + site * 0x85EBCA6BU + 0x27D4EB2FU);
+}
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0;
     if (t <= 0.0) return 0u;
-    if (t >= 4294967295.0) return 4294967295u;
+    if (t >= 65535.0) return 65535u;
     return (uint32_t)t;
+}
+__host__ __device__ __forceinline__ uint32_t drop_pair(uint32_t key, uint32_t idx) { return mix32((idx >> 1) ^ key); }
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t thr16, uint32_t idx) {
+    const uint32_t h = drop_pair(key, idx);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
+// 4 consecutive elements starting at an EVEN idx: two hashes
+__device__ __forceinline__ void drop4(uint32_t key, uint32_t thr16, uint32_t idx, float scale, float (&v)[4]) {
+    const uint32_t h0 = drop_pair(key, idx), h1 = drop_pair(key, idx + 2);
+    v[0] = ((h0 & 0xFFFFu) >= thr16) ? v[0] * scale : 0.f;
+    v[1] = ((h0 >> 16) >= thr16) ? v[1] * scale : 0.f;
+    v[2] = ((h1 & 0xFFFFu) >= thr16) ? v[2] * scale : 0.f;
+    v[3] = ((h1 >> 16) >= thr16) ? v[3] * scale : 0.f;
 }
 __device__ __forceinline__ float rng_uniform01(uint32_t u) {  // (0,1]
     return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
@@ -88,10 +108,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // activation ids shared by GEMM epilogues and elementwise kernels
 enum Act { ACT_NONE = 0, ACT_SOFTSIGN = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_TANH = 4 };
 
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): ~12 VALU ops + one exp + one rcp instead
+// of libm erff's ~40; the GELU sits in GEMM epilogues where every op per element is paid 2048 MACs apart.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
     switch (act) {
         case ACT_SOFTSIGN: return x / (1.0f + fabsf(x));
-        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_GELU: return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f));
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_TANH: return tanhf(x);
         default: return x;
@@ -102,7 +132,7 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
     switch (act) {
         case ACT_SOFTSIGN: { float d = 1.0f + fabsf(x); return 1.0f / (d * d); }
         case ACT_GELU: {
-            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
             float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
             return cdf + x * pdf;
         }

@@ -404,21 +404,21 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const LayerWS& lw = w.L[l];
             const LayerOff& lo = p.L[l];
             // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
-            const void* dm;  // d(down output) in the GEMM operand dtype
+            const void* dm;  // d(down output) in the GEMM operand dtype; bias grad fused into the cast pass
             if (dt == NBCI_F32 && p_lay == 0.f) {
                 dm = dx;
+                TRY(colsum_launch(dm, dt, H, M, H, grads + lo.dnb, s));
             } else {
-                TRY(dropcast_launch(dx, ws + w.dA, dt, (int64_t)M * H, p_lay, io->seed, 18 + 4 * l, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_lay, io->seed, 18 + 4 * l, grads + lo.dnb, s));
                 dm = ws + w.dA;
             }
-            TRY(colsum_launch(dm, dt, H, M, H, grads + lo.dnb, s));
             TRY(wgrad(s, dt, H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
             {   // du = (dm W_down) * act'(u)
                 nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
                 d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
+                d.colsum = grads + lo.upb;  // up_proj bias grad = column sums of du
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(colsum_launch(ws + w.dB, dt, I, M, I, grads + lo.upb, s));
             TRY(wgrad(s, dt, I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
             {
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
@@ -430,11 +430,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const void* dxc;
             if (dt == NBCI_F32) {
                 dxc = dx;
+                TRY(colsum_launch(dx, NBCI_F32, H, M, H, grads + lo.ob, s));
             } else {
-                TRY(cast_launch(dx, ws + w.dA, dt, (int64_t)M * H, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, 0.f, 0, 0, grads + lo.ob, s));
                 dxc = ws + w.dA;
             }
-            TRY(colsum_launch(dx, NBCI_F32, H, M, H, grads + lo.ob, s));
             TRY(wgrad(s, dt, H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
             {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
                 nbci_gemm_desc d = gd(M, H, H, dt, op(dxc, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dB, H, dt);
@@ -454,6 +454,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
                                       op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
+                if (!c.use_rope) d.colsum = grads + lo.vb;
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, Tp, w.ldS, w.ldP, p_lay,
@@ -462,17 +463,20 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
                                       op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                if (!c.use_rope) d.colsum = grads + lo.qb;
                 TRY(gemm_launch_timed(d, s));
             }
             {   // dk = dS^T q * scale
                 nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
                                       op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                if (!c.use_rope) d.colsum = grads + lo.kb;
                 TRY(gemm_launch_timed(d, s));
             }
-            if (c.use_rope)
+            if (c.use_rope) {  // bias grads are taken after the inverse rotation
                 TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
-            TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, grads + lo.qb, s));
+                TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, grads + lo.qb, s));
+            }
             TRY(wgrad(s, dt, 3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
             {
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
@@ -487,12 +491,12 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const void* dx0;
             if (dt == NBCI_F32 && p_emb == 0.f) {
                 dx0 = dx;
+                TRY(colsum_launch(dx0, dt, H, M, H, grads + p.stkb, s));
             } else {
-                TRY(dropcast_launch(dx, ws + w.dA, dt, (int64_t)M * H, p_emb, io->seed, 3, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_emb, io->seed, 3, grads + p.stkb, s));
                 dx0 = ws + w.dA;
             }
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
-            TRY(colsum_launch(dx0, dt, H, M, H, grads + p.stkb, s));
             TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
                       op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
             {   // dwin = dx0 W_s  (M, S*D)

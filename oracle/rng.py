@@ -28,21 +28,29 @@ def rng_u32(seed, site, idx):
     return mix32(mix32(idx ^ s1) ^ s2)
 
 
+def drop_key(seed, site):
+    return int(mix32(U32((int(seed) * 0x9E3779B9 + int(site) * 0x85EBCA6B + 0x27D4EB2F) & 0xFFFFFFFF)))
+
+
 def drop_threshold(p):
-    t = float(np.float32(p)) * 4294967296.0
+    """16-bit threshold: P(drop) = floor(p * 65536) / 65536."""
+    t = float(np.float32(p)) * 65536.0
     if t <= 0:
         return 0
-    if t >= 4294967295.0:
-        return 4294967295
+    if t >= 65535.0:
+        return 65535
     return int(t)
 
 
 def keep_mask(seed, site, n, p):
-    """float32 array of n multipliers: 1/(1-p) where kept, 0 where dropped (p == 0 -> ones)."""
+    """float32 array of n multipliers: 1/(1-p) where kept, 0 where dropped (p == 0 -> ones).
+    One 32-bit hash per PAIR of elements, low 16 bits for the even index, high 16 for the odd."""
     thr = drop_threshold(p)
     if thr == 0:
         return np.ones(n, np.float32)
-    draws = rng_u32(seed, site, np.arange(n, dtype=np.uint32))
+    idx = np.arange(n, dtype=np.uint32)
+    h = mix32((idx >> U32(1)) ^ U32(drop_key(seed, site)))
+    draws = np.where((idx & U32(1)) == 1, h >> U32(16), h & U32(0xFFFF))
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
     return np.where(draws >= U32(thr), scale, np.float32(0)).astype(np.float32)
 
