@@ -1,0 +1,358 @@
+// gemm_common.h — pieces shared by the two GEMM kernels (see gemm.hip for the design notes).
+//
+// C[z] = alpha * A[z](M x K) . B[z]^T(N x K), f32 accumulate, fused epilogue.
+// Layouts: each operand is either k-major (storage rows = m/n, k contiguous) or
+// row-major-in-k (storage rows = k, m/n contiguous). The second kind is read out of LDS with
+// ds_read_b64_tr_b16 (bf16) so forward (x.W^T), data-grad (dy.W) and weight-grad (dy^T.x)
+// products all run on one kernel without transposed copies in HBM.
+// Storage rows may be an overlapping-window view (rpb/gstride): nn.Unfold + Linear of the
+// reference (models/ndt1.py:138,180) is a plain GEMM over that view.
+//
+// Tile: 128 x 128 x BK (BK = 64 bf16 / 16 f32), 256 threads = 4 waves, each wave a 64 x 64
+// sub-tile as 4 x 4 MFMA 16x16 blocks (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32).
+// The MFMA is issued with operands swapped (B fragment first) so every lane ends up with
+// 4 CONSECUTIVE n for one m: epilogue loads/stores are 16-byte (f32) / 8-byte (bf16) wide.
+// Register-staged global->LDS with two LDS stages: one barrier per K tile.
+#pragma once
+#include "nbci_common.h"
+#include "../../include/nbci.h"
+
+namespace nbci {
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_THREADS = 256;
+
+template <typename T> struct GemmTile;
+template <> struct GemmTile<bf16_t> {
+    static constexpr int BK = 64;        // k per tile
+    static constexpr int E = 8;          // elements per 16-byte chunk
+    static constexpr int NCH = 4;        // chunks per thread per operand per tile
+    static constexpr int REGION = 16384; // LDS bytes per operand per stage
+};
+template <> struct GemmTile<float> {
+    static constexpr int BK = 16;
+    static constexpr int E = 4;
+    static constexpr int NCH = 2;
+    static constexpr int REGION = 9216;  // max(128*17*4, 16*144*4)
+};
+constexpr int F32_KM_STRIDE = 17;   // dwords per row, k-major f32 tile [128][16+1]
+constexpr int F32_RM_STRIDE = 144;  // dwords per row, row-major f32 tile [16][128+16]
+
+struct OperandK {  // device copy of nbci_operand, batch offset already applied
+    const void* ptr;
+    long long ld;
+    int rpb;
+    long long gstride;
+    int vec;  // 16-byte loads legal
+};
+
+struct GemmK {
+    int M, N, K;
+    OperandK A, B;
+    long long azs1, azs2, bzs1, bzs2;
+    void* C; void* C2;
+    long long ldc, czs1, czs2;
+    int c_bf16;
+    int zdiv;
+    int splitk;
+    int tiles_per_split;
+    int tiles_m, tiles_n;
+    float alpha, beta;
+    const float* bias;
+    int act;
+    float drop_scale; unsigned drop_thr; unsigned drop_key;
+    float* colsum;  // optional: colsum[(coff % ldc) + n] += sum over rows of the stored value
+    const float* residual; long long ldr;
+    const long long* residual_rows;  // optional gather: residual row for output row m
+    int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
+    const void* gate; long long ldg; int gate_act;  // v *= act'(gate[m][n]) (gate in the input dtype)
+    int gate_bf16;
+    int cvec;  // vector C/residual accesses legal
+};
+
+__device__ __forceinline__ long long row_offset(const OperandK& o, int r) {
+    if (o.rpb > 0) return (long long)(r / o.rpb) * o.gstride + (long long)(r % o.rpb) * o.ld;
+    return (long long)r * o.ld;
+}
+
+// f(k) used to XOR-swizzle the 32-byte granules of the row-major bf16 tile [64][128]:
+// the 8 rows touched by one 32-lane half of a ds_read_b64_tr_b16 get 8 distinct granules.
+__device__ __forceinline__ int rm_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> registers --------------------------------------------------------------
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void load_chunks(const OperandK& o, int row0, int R, int k0, int K,
+                                            uint4 (&regs)[GemmTile<T>::NCH], int t) {
+    constexpr int E = GemmTile<T>::E;
+    constexpr int BK = GemmTile<T>::BK;
+    constexpr int CPR = KMAJOR ? (BK / E) : (128 / E);  // chunks per storage row of the tile
+    constexpr int RPP = GEMM_THREADS / CPR;             // storage rows per pass
+    const int lc = (t % CPR) * E;
+    const int lr = t / CPR;
+    const int rows_lim = KMAJOR ? R : K;
+    const int cols_lim = KMAJOR ? K : R;
+    const T* base = (const T*)o.ptr;
+#pragma unroll
+    for (int i = 0; i < GemmTile<T>::NCH; ++i) {
+        const int srow = (KMAJOR ? row0 : k0) + lr + i * RPP;
+        const int scol = (KMAJOR ? k0 : row0) + lc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (srow < rows_lim && scol < cols_lim) {
+            const T* p = base + row_offset(o, srow) + scol;
+            if (o.vec && scol + E <= cols_lim) {
+                v = *(const uint4*)p;
+            } else {
+                alignas(16) T tmp[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) tmp[e] = (scol + e < cols_lim) ? p[e] : (T)0.0f;
+                v = *(const uint4*)tmp;
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+// ---- registers -> LDS -----------------------------------------------------------------
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void store_chunks(char* s, const uint4 (&regs)[GemmTile<T>::NCH], int t) {
+    constexpr int E = GemmTile<T>::E;
+    constexpr int BK = GemmTile<T>::BK;
+    constexpr int CPR = KMAJOR ? (BK / E) : (128 / E);
+    constexpr int RPP = GEMM_THREADS / CPR;
+    const int c = t % CPR;
+    const int lr = t / CPR;
+#pragma unroll
+    for (int i = 0; i < GemmTile<T>::NCH; ++i) {
+        const int row = lr + i * RPP;
+        if constexpr (sizeof(T) == 2) {
+            if constexpr (KMAJOR) {  // [128][64] bf16, 128-B rows, chunk ^= (row>>1)&7
+                *(uint4*)(s + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = regs[i];
+            } else {                 // [64][128] bf16, 256-B rows, 32-B granule ^= rm_swz(k)
+                const int phys = ((((c >> 1) ^ rm_swz(row)) << 1) | (c & 1));
+                *(uint4*)(s + row * 256 + (phys << 4)) = regs[i];
+            }
+        } else {
+            if constexpr (KMAJOR) {  // [128][17] f32 (padded: scalar stores)
+                float* d = (float*)s + row * F32_KM_STRIDE + c * 4;
+                d[0] = __uint_as_float(regs[i].x); d[1] = __uint_as_float(regs[i].y);
+                d[2] = __uint_as_float(regs[i].z); d[3] = __uint_as_float(regs[i].w);
+            } else {                 // [16][144] f32
+                *(uint4*)((float*)s + row * F32_RM_STRIDE + c * 4) = regs[i];
+            }
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragments (bf16) -------------------------------------------------------
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag_bf16(const char* s, int r0, int ks, int i16, int g) {
+    if constexpr (KMAJOR) {
+        const int row = r0 + i16;
+        const int chunk = 4 * ks + g;
+        return *(const bf16x8*)(s + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    } else {
+        // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block;
+        // lane i receives column i (= m/n index r0+i), rows in elements 0..3.
+        const int q = i16 >> 2, p = i16 & 3;
+        const int col = r0 + 4 * p;
+        s16x4 lo, hi;
+        {
+            const int krow = 32 * ks + 8 * g + q;
+            const char* a = s + krow * 256 + ((((col >> 4) ^ rm_swz(krow)) << 5) | ((col & 15) << 1));
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+        }
+        {
+            const int krow = 32 * ks + 8 * g + 4 + q;
+            const char* a = s + krow * 256 + ((((col >> 4) ^ rm_swz(krow)) << 5) | ((col & 15) << 1));
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+        }
+        union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+        u.p2.a = lo; u.p2.b = hi;
+        return u.v;
+    }
+}
+
+template <typename T, bool AK, bool BKM>
+__device__ __forceinline__ void compute_tile(const char* sA, const char* sB, f32x4 (&acc)[4][4],
+                                             int wm, int wn, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) af[sb] = read_frag_bf16<AK>(sA, wm * 64 + sb * 16, ks, i16, g);
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) bf[sb] = read_frag_bf16<BKM>(sB, wn * 64 + sb * 16, ks, i16, g);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+    } else {
+        const float* fA = (const float*)sA;
+        const float* fB = (const float*)sB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                const int ra = wm * 64 + sb * 16 + i16;
+                a[sb] = AK ? fA[ra * F32_KM_STRIDE + 4 * kk + g] : fA[(4 * kk + g) * F32_RM_STRIDE + ra];
+                const int rb = wn * 64 + sb * 16 + i16;
+                b[sb] = BKM ? fB[rb * F32_KM_STRIDE + 4 * kk + g] : fB[(4 * kk + g) * F32_RM_STRIDE + rb];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+}
+
+// ---- epilogue shared by both kernels. The wave owns rows [mw, mw + 16*MI) x cols [nw, nw + 16*NI);
+// lane owns m = mw + 16*mi + (lane&15), n = nw + 16*ni + 4*(lane>>4) + 0..3.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][NI], int mw, int nw, long long coff,
+                                              int lane, int w, char* smem) {
+    const int i16 = lane & 15, g = lane >> 4;
+    if constexpr (MI == 4 && NI == 4) {
+    if (d.splitk > 1) {
+        // Split-K partials go to C with f32 atomics. A wave-instruction of float atomics runs at full
+        // rate only when it covers 256 contiguous bytes, so each wave first transposes its 64x64
+        // accumulator through LDS (XOR-swizzled float4 columns: conflict-free both ways) and then
+        // issues one atomic per ROW: 64 lanes = 64 consecutive n.
+        float* sw = (float*)smem + w * 4096;  // 16 KB per wave; main-loop LDS is dead after the last barrier
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int ml = mi * 16 + i16, c4 = ni * 4 + g;
+                *(float4*)(sw + ml * 64 + ((c4 ^ (ml & 15)) << 2)) =
+                    make_float4(acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha, acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha);
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+        const int nn = nw + lane;
+        float* cbase = (float*)d.C + nn;
+        for (int ml = 0; ml < 64; ++ml) {
+            const int m = mw + ml;
+            if (m >= d.M) break;
+            const float val = sw[ml * 64 + ((((lane >> 2) ^ (ml & 15)) << 2) | (lane & 3))];
+            if (nn < d.N) atomicAdd(cbase + (long long)m * d.ldc, val);
+        }
+        return;
+    }
+    }
+    float csum[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) csum[a][b] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mw + mi * 16 + i16;
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = nw + ni * 16 + 4 * g;
+            if (n >= d.N) continue;
+            float v[4] = {acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha,
+                          acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha};
+            const long long cidx = coff + (long long)m * d.ldc + n;
+            const bool full = (n + 3 < d.N) && d.cvec;
+            if (d.bias) {
+                if (full) {
+                    const float4 b4 = *(const float4*)(d.bias + n);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.bias[n + e];
+                }
+            }
+            if (d.C2) {
+                if (d.c_bf16) {
+                    bf16_t* c2 = (bf16_t*)d.C2 + cidx;
+                    if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c2 = o; }
+                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(v[e]); }
+                } else {
+                    float* c2 = (float*)d.C2 + cidx;
+                    if (full) *(float4*)c2 = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = v[e]; }
+                }
+            }
+            if (d.residual && d.residual_first) {
+                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+                const float* r = d.residual + rr * d.ldr + n;
+                if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+            }
+            if (d.act != ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
+            }
+            if (d.gate) {
+                const long long gi = (long long)m * d.ldg + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < d.N) {
+                        const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
+                        v[e] *= act_bwd(d.gate_act, gv);
+                    }
+                }
+            }
+            if (d.drop_thr) {
+                // dropout stream index = element offset inside C (so a head-batched GEMM that writes
+                // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
+                const unsigned idx = (unsigned)cidx;
+                if ((idx & 1u) == 0u) {
+                    drop4(d.drop_key, d.drop_thr, idx, d.drop_scale, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = drop_keep(d.drop_key, d.drop_thr, idx + e) ? v[e] * d.drop_scale : 0.f;
+                }
+            }
+            if (d.residual && !d.residual_first) {
+                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+                const float* r = d.residual + rr * d.ldr + n;
+                if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+            }
+            if (d.colsum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[ni][e] += v[e];
+            }
+            if (d.c_bf16) {
+                bf16_t* c = (bf16_t*)d.C + cidx;
+                if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
+                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
+            } else {
+                float* c = (float*)d.C + cidx;
+                if (d.beta != 0.f) {
+                    if (full) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
+                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
+                }
+                if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
+            }
+        }
+    }
+    if (d.colsum) {
+        // bias gradient fused into the producing GEMM: reduce this wave's 64 rows (16 lanes x 4 mi)
+        // with shuffles, then one atomic per column per wave
+        const int cbase = (int)(coff % d.ldc);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = csum[ni][e];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                const int n = nw + ni * 16 + 4 * g + e;
+                if (i16 == 0 && n < d.N) atomicAdd(d.colsum + cbase + n, t);
+            }
+    }
+}
+
+}  // namespace nbci

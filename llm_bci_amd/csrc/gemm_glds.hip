@@ -1,0 +1,246 @@
+// gemm_glds.hip — bf16 fast-path GEMM: operands go HBM -> LDS directly (global_load_lds, 16 B per
+// lane, no VGPR staging), two LDS stages, one barrier per K tile.
+//
+// LDS image = the one gemm_kernel builds (so the fragment readers are shared): a wave-instruction
+// of global_load_lds writes 1 KiB of LDS linearly (base + lane*16), therefore the XOR swizzles of
+// the image are applied to each lane's SOURCE address instead:
+//   k-major tile  [rows][64 k]   128-B rows : piece = 8 rows ; lane -> row l>>3, physical 16-B
+//                                             chunk l&7 holds logical chunk (l&7) ^ ((row>>1)&7)
+//   row-major-in-k [64 k][128]   256-B rows : piece = 4 k-rows ; lane -> k-row l>>4, physical chunk
+//                                             l&15 holds logical (((l&15)>>1) ^ f(k))<<1 | (l&1)
+// Rows past the operand's extent are CLAMPED to a valid row instead of zero-filled: they only feed
+// accumulator rows/cols that the epilogue never stores. Only a partial last K tile needs real
+// zeros; it goes through the masked register-staged loader of gemm_common.h.
+//
+// Tile height is a template parameter (BM = 16*MI*WM): for the token-major GEMMs of the train step
+// (M = B*T' = 9152) BM = 144 gives 64 x 8 = 512 tiles = exactly two per CU, where 128 x 128 tiles
+// need a second, 12 %-full round.
+#include "gemm_common.h"
+
+namespace nbci {
+
+typedef __attribute__((address_space(1))) void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+template <bool KMAJOR, int NPIECES>
+struct GldsOperand {
+    static constexpr int PER_WAVE = (NPIECES + 3) / 4;
+    const bf16_t* base;        // operand base (batch offset applied)
+    long long off[PER_WAVE];   // per-piece element offset of this lane's chunk at k-tile 0
+    long long step;            // element step per K tile (kmajor: 64; else 64 * ld), 0 if recomputed
+    int col[PER_WAVE];         // (!KMAJOR, rpb view) column of the chunk
+    int krow[PER_WAVE];        // (!KMAJOR) local k row of this lane in the piece
+};
+
+// per-lane source offsets for the pieces this wave stages
+template <bool KMAJOR, int NPIECES>
+__device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES>& g, const OperandK& o, int row0, int R, int w, int lane) {
+    g.base = (const bf16_t*)o.ptr;
+#pragma unroll
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES>::PER_WAVE; ++i) {
+        const int p = w + 4 * i;
+        if constexpr (KMAJOR) {
+            const int rl = 8 * p + (lane >> 3);
+            int row = row0 + rl;
+            if (row > R - 1) row = R - 1;                       // clamp: garbage rows are never stored
+            const int c = (lane & 7) ^ ((rl >> 1) & 7);
+            g.off[i] = row_offset(o, row) + c * 8;
+            g.col[i] = 0; g.krow[i] = 0;
+        } else {
+            const int kl = 4 * p + (lane >> 4);
+            const int c = ((((lane & 15) >> 1) ^ rm_swz(kl)) << 1) | (lane & 1);
+            int col = row0 + c * 8;
+            if (col + 8 > ((R + 7) & ~7)) col = 0;              // chunk entirely past the padded extent
+            g.col[i] = col; g.krow[i] = kl;
+            g.off[i] = (long long)kl * o.ld + col;              // plain (non-view) addressing
+        }
+    }
+    g.step = KMAJOR ? 64 : 64 * o.ld;
+}
+
+template <bool KMAJOR, int NPIECES>
+__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES>& g, const OperandK& o, char* lds, int kt, int w) {
+#pragma unroll
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES>::PER_WAVE; ++i) {
+        const int p = w + 4 * i;
+        if (p < NPIECES) {
+            const bf16_t* src;
+            if (!KMAJOR && o.rpb > 0) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
+            else src = g.base + g.off[i] + (long long)kt * g.step;
+            __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <bool AK, bool BKM, int MI, int NI>
+__device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MI], bf[NI];
+#pragma unroll
+        for (int sb = 0; sb < MI; ++sb) af[sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
+#pragma unroll
+        for (int sb = 0; sb < NI; ++sb) bf[sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    static_assert(BN == 128, "B tile is always 128 wide");
+    static_assert(AK || BM == 128, "row-major-in-k A needs 256-byte tile rows");
+    constexpr int A_BYTES = BM * 128;       // k-major: BM rows x 128 B ; row-major-in-k: 64 x 256 B
+    constexpr int B_BYTES = 16384;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NPA = A_BYTES / 1024, NPB = 16;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w / WN, wn = w % WN;
+
+    const int nwg = d.tiles_m * d.tiles_n;
+    int wg;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tm = wg / d.tiles_n, tn = wg % d.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int ktiles = (d.K + 63) / 64;
+    int kt_begin = 0, kt_end = ktiles;
+    OperandK A = d.A, B = d.B;
+    long long coff = 0;
+    if (d.splitk > 1) {
+        kt_begin = z * d.tiles_per_split;
+        kt_end = min(kt_end, kt_begin + d.tiles_per_split);
+        if (kt_begin >= kt_end) return;
+    } else {
+        const int z1 = z / d.zdiv, z2 = z % d.zdiv;
+        A.ptr = (const bf16_t*)A.ptr + z1 * d.azs1 + z2 * d.azs2;
+        B.ptr = (const bf16_t*)B.ptr + z1 * d.bzs1 + z2 * d.bzs2;
+        coff = z1 * d.czs1 + z2 * d.czs2;
+    }
+    const int kt_full_end = min(kt_end, d.K / 64);  // tiles that are entirely inside K
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    GldsOperand<AK, NPA> ga;
+    GldsOperand<BKM, NPB> gb;
+    glds_setup<AK, NPA>(ga, A, m0, d.M, w, lane);
+    glds_setup<BKM, NPB>(gb, B, n0, d.N, w, lane);
+
+    int cur = 0;
+    if (kt_begin < kt_full_end) {
+        glds_stage<AK, NPA>(ga, A, smem, kt_begin, w);
+        glds_stage<BKM, NPB>(gb, B, smem + A_BYTES, kt_begin, w);
+    }
+    __syncthreads();  // drains the LDS-DMA (hipcc emits vmcnt(0) ahead of the barrier)
+    for (int kt = kt_begin; kt < kt_full_end; ++kt) {
+        if (kt + 1 < kt_full_end) {
+            char* nx = smem + (cur ^ 1) * STAGE;
+            glds_stage<AK, NPA>(ga, A, nx, kt + 1, w);
+            glds_stage<BKM, NPB>(gb, B, nx + A_BYTES, kt + 1, w);
+        }
+        const char* sA = smem + cur * STAGE;
+        compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if constexpr (BM == 128) {
+        if (kt_full_end < kt_end) {  // partial last K tile: masked register-staged loads (zero fill)
+            uint4 ra[4], rb[4];
+            load_chunks<bf16_t, AK>(A, m0, d.M, kt_full_end * 64, d.K, ra, t);
+            load_chunks<bf16_t, BKM>(B, n0, d.N, kt_full_end * 64, d.K, rb, t);
+            char* sA = smem + cur * STAGE;
+            store_chunks<bf16_t, AK>(sA, ra, t);
+            store_chunks<bf16_t, BKM>(sA + A_BYTES, rb, t);
+            __syncthreads();
+            compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
+}
+
+// ---- host --------------------------------------------------------------------------------------
+static bool glds_operand_ok(const nbci_operand& o, int R) {
+    if (((uintptr_t)o.ptr) % 16) return false;
+    if (o.ld % 8 || (o.rpb > 0 && o.gstride % 8) || (o.zs1 % 8) || (o.zs2 % 8)) return false;
+    if (!o.kmajor && o.ld < ((R + 7) & ~7)) return false;  // padded extent must stay inside the row
+    return true;
+}
+
+bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k) {
+    (void)k;
+    if (d.in_dtype != NBCI_BF16 || d.K < 64) return false;
+    return glds_operand_ok(d.A, d.M) && glds_operand_ok(d.B, d.N);
+}
+
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
+    constexpr int lds = 2 * (WM * MI * 16 * 128 + 16384);
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds: LDS attribute: ") + hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<AK, BKM, WM, WN, MI, NI>), grid, dim3(GEMM_THREADS), lds, s, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds launch: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+template <int WM, int WN, int MI, int NI>
+static int launch_glds_layout(const GemmK& k, bool ak, bool bk, dim3 grid, hipStream_t s) {
+    if constexpr (WM * MI * 16 == 128) {
+        if (ak && bk) return launch_glds<true, true, WM, WN, MI, NI>(k, grid, s);
+        if (ak && !bk) return launch_glds<true, false, WM, WN, MI, NI>(k, grid, s);
+        if (!ak && bk) return launch_glds<false, true, WM, WN, MI, NI>(k, grid, s);
+        return launch_glds<false, false, WM, WN, MI, NI>(k, grid, s);
+    } else {  // tall tiles exist for k-major A only
+        if (bk) return launch_glds<true, true, WM, WN, MI, NI>(k, grid, s);
+        return launch_glds<true, false, WM, WN, MI, NI>(k, grid, s);
+    }
+}
+
+int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const int splitk = k.splitk;
+    // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
+    // whole K tiles and no split-K.
+    int bm = 128;
+    if (d.A.kmajor && d.K % 64 == 0 && splitk == 1) {
+        long best = -1;
+        const int cands[2] = {128, 144};  // (160 / 192 rows spill accumulators to scratch with hipcc 7.2: not offered)
+        for (int c : cands) {
+            const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
+            const long cost = ((tiles + 511) / 512) * c;
+            if (best < 0 || cost < best) { best = cost; bm = c; }
+        }
+    }
+    k.tiles_m = (d.M + bm - 1) / bm;
+    dim3 grid(k.tiles_m * k.tiles_n, splitk > 1 ? splitk : batch);
+    const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
+    switch (bm) {
+        case 144: return launch_glds_layout<1, 4, 9, 2>(k, ak, bk, grid, stream);
+        default: return launch_glds_layout<2, 2, 4, 4>(k, ak, bk, grid, stream);
+    }
+}
+
+}  // namespace nbci
