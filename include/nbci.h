@@ -104,6 +104,8 @@ typedef struct nbci_gemm_desc {
     int32_t gate_act;
     float* colsum;                /* optional f32 [N]: colsum[n] += sum_m C[m][n] of the STORED values (bias
                                      gradient fused into the GEMM that produces the activation gradient) */
+    int64_t colsum_rep_stride;    /* colsum replicas (to spread same-address atomics): replica r at colsum + r*stride */
+    int32_t colsum_nrep;          /* 0/1 = no replication */
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);
@@ -135,6 +137,18 @@ int nbci_softmax_fwd(const float* S, void* P, void* Pd, int32_t p_dtype, const i
 int nbci_softmax_bwd(const float* dPd, const void* P, void* dS, int32_t p_dtype, int32_t B, int32_t n_heads,
                      int32_t Tp, int32_t ldS, int32_t ldP, float drop_p, uint32_t seed, uint32_t site,
                      nbci_stream_t stream);
+
+/* Fused attention (bf16, head size 128, T' <= 160): F.scaled_dot_product_attention(q,k,v,attn_mask,dropout_p)
+ * of ndt1.py:289 on a packed (B*T', 3H) qkv buffer, mask of ndt1.py:435-437 built on the fly, output already in the
+ * merged (B*T', H) layout with the attention-output dropout of ndt1.py:292 applied. Backward: d_out = d loss / d(Pd v)
+ * (B*T', H) -> dqkv (B*T', 3H); dS_ws / Pd_ws: bf16 scratch (B, heads, T', ldP), ldP = round_up(T', 8);
+ * bias_grad: optional f32 (3H) += column sums of dqkv. */
+int nbci_attention_fwd(const void* qkv, const int32_t* token_mask, void* out, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
+                       int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob,
+                       uint32_t site_out, nbci_stream_t stream);
+int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d_out, void* dS_ws, void* Pd_ws, int32_t ldP,
+                       void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H, int32_t ctx_forward,
+                       int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream);
 
 /* nn.LogSoftmax(-1) of the decoder (ndt1.py:499) + argmax path (main.py:69) */
 int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V,

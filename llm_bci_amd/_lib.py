@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32),
-                ("colsum", C.c_void_p)]
+                ("colsum", C.c_void_p), ("colsum_rep_stride", C.c_int64), ("colsum_nrep", C.c_int32)]
 
 
 class NDT1Config(C.Structure):
@@ -94,6 +94,10 @@ _SIGNATURES = {
     "nbci_ctc": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                            C.c_float, C.c_void_p]),
     "nbci_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
+    "nbci_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_float, C.c_uint32, C.c_uint32,
+                                                                                               C.c_uint32, C.c_void_p]),
+    "nbci_attention_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +
+                           [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nbci_profile_enable": (C.c_int, [C.c_int32]),
     "nbci_profile_collect": (C.c_int, [C.POINTER(C.c_double)]),
     "nbci_per": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

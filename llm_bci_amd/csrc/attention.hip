@@ -1,0 +1,424 @@
+// attention.hip — fused masked attention for the NDT1 token counts (T' <= 160, head 128, bf16):
+// replaces F.scaled_dot_product_attention(q, k, v, attn_mask, dropout_p) of the reference
+// (models/ndt1.py:289) and its autograd, including the mask of ndt1.py:435-437 (eye | ctx & key
+// validity, computed on the fly) and the attention-prob dropout.
+//
+// One workgroup (8 waves) per (batch, head). K and V of that head live in LDS as 256-byte-row
+// images that serve both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads
+// (XOR swizzle (b) of the CDNA4 guide). Each wave owns 16-query blocks; the whole score row
+// (<= 160 keys) stays in registers, so softmax needs only two cross-lane steps and P never
+// leaves registers: the QK^T accumulator IS the B operand of the PV product once the k-order
+// permutation pi(g, j) = {4g+j | 16+4g+(j-4)} is applied to the V operand's row addresses.
+//   fwd     : S = q k^T, masked softmax, dropout, O = Pd v   -> a (pre-dropout) / ad (merged layout)
+//   bwd_dq  : recomputes P; dP = (da v^T) * keep; dS = P (dP - rowsum(dP P)) / sqrt(d);
+//             dq = dS k -> dqkv; stores dS and Pd (bf16) for the second kernel
+//   bwd_dkv : dk = dS^T q, dv = Pd^T da  (contraction over queries: both operands tr-read)
+// Larger T', other head sizes and the f32 parity path use the batched-GEMM + softmax kernels.
+#include <cstring>
+
+#include "kernels.h"
+
+namespace nbci {
+
+constexpr int AT_TPAD = 160;   // padded keys / queries (10 blocks of 16, 5 MFMA k-steps of 32)
+constexpr int AT_NB = 10;
+constexpr int AT_HD = 128;
+constexpr int AT_THREADS = 512;
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` in a 256-byte-row image
+__device__ __forceinline__ int img_off(int row, int ch) {
+    return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+// global (rows x 128 bf16, row stride ld elements) -> LDS image, rows >= nrows zero-filled
+__device__ __forceinline__ void load_image(char* img, const bf16_t* src, long long ld, int nrows, int tid) {
+    for (int i = tid; i < AT_TPAD * 16; i += AT_THREADS) {
+        const int row = i >> 4, ch = i & 15;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < nrows) v = *(const uint4*)(src + (long long)row * ld + ch * 8);
+        *(uint4*)(img + img_off(row, ch)) = v;
+    }
+}
+
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int ks, int g) {
+    return *(const bf16x8*)(img + img_off(row, 4 * ks + g));
+}
+
+// transposed fragment: 8 image ROWS (two groups of 4, given by r_lo / r_hi for this lane's group)
+// x 16 columns starting at element column c0; lane i of each 16-lane group receives column c0 + i.
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int r_lo, int r_hi, int c0, int i16) {
+    const int q = i16 >> 2, p = i16 & 3;
+    const int col = c0 + 4 * p;                 // element column of this lane's address
+    const int ch = col >> 3, within = (col & 7) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(img + img_off(r_lo + q, ch) + within));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(img + img_off(r_hi + q, ch) + within));
+    union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+    u.p2.a = lo; u.p2.b = hi;
+    return u.v;
+}
+
+__device__ __forceinline__ bool ctx_ok(int i, int j, int f, int bk) {
+    if (f >= -1 && j - i > f) return false;
+    if (bk >= -1 && i - j > bk) return false;
+    return true;
+}
+
+struct AttnArgs {
+    const bf16_t* qkv;     // (B*Tp, 3H)
+    const int32_t* tmask;  // (B, Tp)
+    int B, nh, Tp, H;
+    int cf, cb;
+    float scale;
+    unsigned p_thr; float p_scale; uint32_t p_key;   // attention-prob dropout
+    unsigned o_thr; float o_scale; uint32_t o_key;   // attention-output dropout (forward only)
+    bf16_t* ad;            // fwd out (B*Tp, H): dropout(merge_heads(Pd v))
+    const bf16_t* da;      // bwd in  (B*Tp, H): d loss / d (Pd v)
+    bf16_t* dS;            // bwd scratch (B, nh, Tp, ldP)
+    bf16_t* Pd;            // bwd scratch (B, nh, Tp, ldP)
+    int ldP;
+    bf16_t* dqkv;          // bwd out (B*Tp, 3H)
+    float* bias_grad;      // optional (3H): column sums of dqkv
+    RepCfg rc;             // replication of bias_grad
+};
+
+// scores of one 16-query block against all keys: acc[kb][r] = S[query i16][key 16kb + 4g + r]
+__device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4], f32x4 (&acc)[AT_NB], int i16, int g) {
+#pragma unroll
+    for (int kb = 0; kb < AT_NB; ++kb) {
+        acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, 16 * kb + i16, ks, g), qf[ks], acc[kb], 0, 0, 0);
+        if (kb & 1) __builtin_amdgcn_sched_barrier(0);  // keep the LDS fragment loads from being hoisted en bloc (VGPR pressure)
+    }
+}
+
+// masked softmax of the register-resident row; returns normalised probabilities in place
+__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, int b, int query, int g) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kb + 4 * g + r;
+            const bool ok = key < a.Tp && ((key == query) || (ctx_ok(query, key, a.cf, a.cb) && a.tmask[b * a.Tp + key] != 0));
+            const float s = ok ? acc[kb][r] * a.scale : -INFINITY;
+            acc[kb][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = (acc[kb][r] == -INFINITY) ? 0.f : __expf(acc[kb][r] - mx);
+            acc[kb][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[kb][r] *= inv;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    bf16x8 o = {f2bf(lo[0]), f2bf(lo[1]), f2bf(lo[2]), f2bf(lo[3]), f2bf(hi[0]), f2bf(hi[1]), f2bf(hi[2]), f2bf(hi[3])};
+    return o;
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + AT_TPAD * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
+    load_image(sK, base + a.H, ld, a.Tp, tid);
+    load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
+    __syncthreads();
+    const int nqb = (a.Tp + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += AT_THREADS / 64) {
+        const int query = 16 * qb + i16;
+        const int qrow = query < a.Tp ? query : a.Tp - 1;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+        f32x4 acc[AT_NB];
+        score_block(sK, qf, acc, i16, g);
+        softmax_rows(acc, a, b, qrow, g);
+        if (a.p_thr) {
+            const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
+#pragma unroll
+            for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kb + 4 * g + r;
+                    if (key < a.Tp) acc[kb][r] = drop_keep(a.p_key, a.p_thr, rbase + key) ? acc[kb][r] * a.p_scale : 0.f;
+                }
+        }
+        f32x4 o[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < AT_NB / 2; ++s) {
+            const bf16x8 pf = pack8(acc[2 * s], acc[2 * s + 1]);
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, i16), pf,
+                                                                o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (query < a.Tp) {
+            const long long obase = ((long long)b * a.Tp + query) * a.H + h * AT_HD;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                float v[4] = {o[db][0], o[db][1], o[db][2], o[db][3]};
+                const long long oi = obase + 16 * db + 4 * g;
+                if (a.o_thr) drop4(a.o_key, a.o_thr, (unsigned)oi, a.o_scale, v);
+                bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)(a.ad + oi) = ov;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + AT_TPAD * 256;
+    float* sbias = (float*)(smem + 2 * AT_TPAD * 256);  // [128] per-workgroup column sums (bias gradient)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < AT_HD) sbias[tid] = 0.f;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
+    load_image(sK, base + a.H, ld, a.Tp, tid);
+    load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
+    __syncthreads();
+    const int nqb = (a.Tp + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += AT_THREADS / 64) {
+        const int query = 16 * qb + i16;
+        const int qrow = query < a.Tp ? query : a.Tp - 1;
+        f32x4 p[AT_NB], dp[AT_NB];
+        {
+            bf16x8 qf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+            score_block(sK, qf, p, i16, g);
+        }
+        softmax_rows(p, a, b, qrow, g);
+        {
+            bf16x8 df[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                df[ks] = *(const bf16x8*)(a.da + ((long long)b * a.Tp + qrow) * a.H + h * AT_HD + 32 * ks + 8 * g);
+            score_block(sV, df, dp, i16, g);      // dPd[query][key] = da . v^T
+        }
+        const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
+        const long long srow = ((long long)blockIdx.x * a.Tp + query) * a.ldP;
+        float delta = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < AT_NB; ++kb) {
+            float pdv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kb + 4 * g + r;
+                float keep = (key < a.Tp) ? 1.f : 0.f;
+                if (a.p_thr && key < a.Tp) keep = drop_keep(a.p_key, a.p_thr, rbase + key) ? a.p_scale : 0.f;
+                dp[kb][r] *= keep;                         // dP = dPd * keep
+                pdv[r] = p[kb][r] * keep;                  // Pd
+                delta += dp[kb][r] * p[kb][r];
+            }
+            const int key0 = 16 * kb + 4 * g;
+            if (query < a.Tp && key0 < a.ldP) {
+                bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
+                *(bf16x4*)(a.Pd + srow + key0) = pv;
+            }
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+        for (int kb = 0; kb < AT_NB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[kb][r] = p[kb][r] * (dp[kb][r] - delta) * a.scale;   // dS (scaled), in place
+            const int key0 = 16 * kb + 4 * g;
+            if (query < a.Tp && key0 < a.ldP) {
+                bf16x4 sv = {f2bf(dp[kb][0]), f2bf(dp[kb][1]), f2bf(dp[kb][2]), f2bf(dp[kb][3])};
+                *(bf16x4*)(a.dS + srow + key0) = sv;
+            }
+        }
+        // dq[query][d] = sum_key dS[query][key] k[key][d]   (k image read transposed)
+        f32x4 o[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < AT_NB / 2; ++s) {
+            const bf16x8 sf = pack8(dp[2 * s], dp[2 * s + 1]);
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, i16), sf,
+                                                                o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long obase = ((long long)b * a.Tp + qrow) * ld + h * AT_HD;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            bf16x4 ov = {f2bf(o[db][0]), f2bf(o[db][1]), f2bf(o[db][2]), f2bf(o[db][3])};
+            if (query < a.Tp) *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+            if (a.bias_grad) {  // query-bias gradient: column sums of the stored dq
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = query < a.Tp ? bf2f(ov[r]) : 0.f;
+                    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                    if (i16 == 0) atomicAdd(&sbias[16 * db + 4 * g + r], t);   // LDS atomic
+                }
+            }
+        }
+    }
+    if (a.bias_grad) {  // one contiguous global atomic pass per workgroup
+        __syncthreads();
+        if (tid < AT_HD) atomicAdd(rep_ptr(a.bias_grad, a.rc, blockIdx.x) + h * AT_HD + tid, sbias[tid]);
+    }
+}
+
+// X image: [160 query rows][160 keys] bf16, 320-byte rows, 16-byte chunk ^= f(row) within each 64-B group
+__device__ __forceinline__ int ximg_off(int row, int col) {  // byte offset of element (row, col)
+    const int ch = col >> 3;
+    return row * 320 + (((ch & ~3) | ((ch & 3) ^ (row & 3))) << 4) + (col & 7) * 2;
+}
+
+// grid (B*nh, 2): z = 0 -> dk = dS^T q ; z = 1 -> dv = Pd^T da.  out[key][d] = sum_q X[q][key] Y[q][d]
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sY = smem;                          // [160][128] image
+    char* sX = smem + AT_TPAD * 256;          // [160][160]
+    float* sbias = (float*)(smem + AT_TPAD * 256 + AT_TPAD * 320);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < AT_HD) sbias[tid] = 0.f;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const int which = blockIdx.y;
+    const long long ld3 = 3LL * a.H;
+    const bf16_t* X = (which == 0 ? a.dS : a.Pd) + (long long)blockIdx.x * a.Tp * a.ldP;
+    if (which == 0) load_image(sY, a.qkv + (long long)b * a.Tp * ld3 + h * AT_HD, ld3, a.Tp, tid);
+    else load_image(sY, a.da + (long long)b * a.Tp * a.H + h * AT_HD, a.H, a.Tp, tid);
+    for (int i = tid; i < AT_TPAD * 20; i += AT_THREADS) {
+        const int row = i / 20, ch = i % 20;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < a.Tp && ch * 8 < a.ldP) v = *(const uint4*)(X + (long long)row * a.ldP + ch * 8);
+        *(uint4*)(sX + ximg_off(row, ch * 8)) = v;
+    }
+    __syncthreads();
+    const int q = i16 >> 2, p = i16 & 3;
+    for (int kb = wave; kb < (a.Tp + 15) / 16; kb += AT_THREADS / 64) {
+        f32x4 o[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < AT_NB / 2; ++s) {
+            const int r0 = 32 * s + 8 * g;   // natural k order: query rows r0..r0+3 and r0+4..r0+7
+            bf16x8 xf;
+            {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sX + ximg_off(r0 + q, 16 * kb + 4 * p)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sX + ximg_off(r0 + 4 + q, 16 * kb + 4 * p)));
+                union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+                u.p2.a = lo; u.p2.b = hi;
+                xf = u.v;
+            }
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sY, r0, r0 + 4, 16 * db, i16), xf, o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int key = 16 * kb + i16;
+        const long long obase = ((long long)b * a.Tp + key) * ld3 + (which == 0 ? a.H : 2 * a.H) + h * AT_HD;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            bf16x4 ov = {f2bf(o[db][0]), f2bf(o[db][1]), f2bf(o[db][2]), f2bf(o[db][3])};
+            if (key < a.Tp) *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+            if (a.bias_grad) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = key < a.Tp ? bf2f(ov[r]) : 0.f;
+                    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                    if (i16 == 0) atomicAdd(&sbias[16 * db + 4 * g + r], t);
+                }
+            }
+        }
+    }
+    if (a.bias_grad) {
+        __syncthreads();
+        if (tid < AT_HD) atomicAdd(rep_ptr(a.bias_grad, a.rc, blockIdx.x) + (which == 0 ? a.H : 2 * a.H) + h * AT_HD + tid, sbias[tid]);
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------
+bool attn_fused_eligible(int dtype, int Tp, int H, int nh) {
+    return dtype == NBCI_BF16 && nh > 0 && H / nh == AT_HD && Tp >= 1 && Tp <= AT_TPAD;
+}
+
+static int set_lds(const void* fn, int bytes) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attention: LDS attribute: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+static AttnArgs base_args(const void* qkv, const int32_t* tmask, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
+                          uint32_t seed, uint32_t site_p) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = (const bf16_t*)qkv; a.tmask = tmask; a.B = B; a.nh = nh; a.Tp = Tp; a.H = H; a.cf = cf; a.cb = cb;
+    a.scale = 1.0f / sqrtf((float)AT_HD);
+    a.p_thr = drop_threshold(drop_p); a.p_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.p_key = drop_key(seed, site_p);
+    return a;
+}
+
+int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
+                    uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s) {
+    NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
+    static bool once = false;
+    const int lds = 2 * AT_TPAD * 256;
+    if (!once) { int r = set_lds((const void*)attn_fwd_kernel, lds); if (r) return r; once = true; }
+    AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
+    a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
+    a.ad = (bf16_t*)ad;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(AT_THREADS), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_fwd: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void* dS, void* Pd, int ldP, void* dqkv,
+                    float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
+                    hipStream_t s, RepCfg rc) {
+    NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
+    NBCI_REQUIRE(ldP % 8 == 0 && ldP >= Tp && ldP <= AT_TPAD, NBCI_ESHAPE, "fused attention: bad ldP");
+    static bool once = false;
+    const int lds1 = 2 * AT_TPAD * 256 + AT_HD * 4, lds2 = AT_TPAD * 256 + AT_TPAD * 320 + AT_HD * 4;
+    if (!once) {
+        int r = set_lds((const void*)attn_bwd_dq_kernel, lds1); if (r) return r;
+        r = set_lds((const void*)attn_bwd_dkv_kernel, lds2); if (r) return r;
+        once = true;
+    }
+    AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
+    a.da = (const bf16_t*)da; a.dS = (bf16_t*)dS; a.Pd = (bf16_t*)Pd; a.ldP = ldP; a.dqkv = (bf16_t*)dqkv; a.bias_grad = bias_grad; a.rc = rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(AT_THREADS), lds1, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(AT_THREADS), lds2, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_bwd: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+}  // namespace nbci

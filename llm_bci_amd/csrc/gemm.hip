@@ -158,6 +158,8 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     k.drop_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
     k.drop_key = drop_key(d.seed, d.site);
     k.colsum = d.colsum;
+    k.colsum_rc = RepCfg{d.colsum_rep_stride, d.colsum_nrep > 1 ? d.colsum_nrep : 1};
+    k.tile_row = 0;
     k.residual = d.residual; k.ldr = d.ldr;
     k.residual_rows = (const long long*)d.residual_rows; k.residual_first = d.residual_first;
     k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16;

@@ -63,6 +63,7 @@ struct GemmK {
     int act;
     float drop_scale; unsigned drop_thr; unsigned drop_key;
     float* colsum;  // optional: colsum[(coff % ldc) + n] += sum over rows of the stored value
+    RepCfg colsum_rc; int tile_row;  // replica config; tile_row = replica selector (set by the kernel)
     const float* residual; long long ldr;
     const long long* residual_rows;  // optional gather: residual row for output row m
     int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
@@ -350,7 +351,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
                 float t = csum[ni][e];
                 t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
                 const int n = nw + ni * 16 + 4 * g + e;
-                if (i16 == 0 && n < d.N) atomicAdd(d.colsum + cbase + n, t);
+                if (i16 == 0 && n < d.N) atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(mw >> 4) + (unsigned)(coff / d.ldc)) + cbase + n, t);
             }
     }
 }

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
 static bool glds_operand_ok(const nbci_operand& o, int R) {
     if (((uintptr_t)o.ptr) % 16) return false;
     if (o.ld % 8 || (o.rpb > 0 && o.gstride % 8) || (o.zs1 % 8) || (o.zs2 % 8)) return false;
-    if (!o.kmajor && o.ld < ((R + 7) & ~7)) return false;  // padded extent must stay inside the row
+    // padded extent must stay inside the storage row (a window view's rows are longer than ld by design)
+    if (!o.kmajor && o.rpb == 0 && o.ld < ((R + 7) & ~7)) return false;
     return true;
 }
 

@@ -24,7 +24,8 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
                          float* rstd, int M, int H, hipStream_t s);
 // backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
 int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s);
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s,
+                         RepCfg rc = RepCfg{0, 1});
 
 // masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437),
 // writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP
@@ -40,9 +41,13 @@ int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float 
                     uint32_t site, hipStream_t s);
 // 2-D form with the bias-gradient column sum fused in: colsum[n] += sum_m out[m][n] (may be NULL)
 int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed,
-                      uint32_t site, float* colsum, hipStream_t s);
+                      uint32_t site, float* colsum, hipStream_t s, RepCfg rc = RepCfg{0, 1});
 // out[n] += sum_m in[m][n]  (bias gradients)
-int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s);
+int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s,
+                  RepCfg rc = RepCfg{0, 1});
+// grads[flat_of[ci]] += sum_r rep[r*stride + ci] for ci in [cbegin, cend); replicas are zeroed
+int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat_of, int cbegin, int cend, float* grads,
+                         hipStream_t s);
 
 // stack backward: dy[b,t,c] = sum_j dwin[b,j,(t - stride*j)*D + c]; dpre = dy * act'(y) -> act dtype
 int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype, int B, int T, int Tp, int D,
@@ -73,5 +78,13 @@ int adamw_launch(float* p, const float* g, float* m, float* v, void* p_lp, int64
                  float beta2, float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s);
 
 int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s);
+
+// fused attention (attention.hip): bf16, head 128, T' <= 160
+bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
+int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
+                    uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s);
+int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void* dS, void* Pd, int ldP, void* dqkv,
+                    float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
+                    hipStream_t s, RepCfg rc = RepCfg{0, 1});
 
 }  // namespace nbci

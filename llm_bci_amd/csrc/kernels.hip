@@ -164,42 +164,54 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
     return check_launch("layernorm_fwd");
 }
 
-constexpr int LNB_ROWS = 16;  // rows per block in the backward (4 per wave): ~2 blocks/CU at M = 9152
+constexpr int LNB_ROWS = 8;  // rows per block: 2 per wave, both rows' loads in flight together
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
-                                                     int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][NV*256]
+                                                     int accumulate, RepCfg rc) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][NV*256]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4 gw[NV], gb[NV], ww[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = (k * 64 + lane) * 4;
-        gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gb[k] = gw[k];
-        ww[k] = (c < H) ? *(const float4*)(w + c) : gw[k];
-    }
     const float invH = 1.0f / (float)H;
-    const int r0 = blockIdx.x * LNB_ROWS;
-    for (int r = r0 + wv; r < min(M, r0 + LNB_ROWS); r += 4) {
-        const float mu = mean[r], rs = rstd[r];
+    const int W = NV * 256;
+    float4 gw[NV], gb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; }
+    const int ra = blockIdx.x * LNB_ROWS + wv * 2;
+    float4 xv[2][NV], dv[2][NV], od[2][NV];
+    float mu[2], rs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = ra + j;
+        mu[j] = r < M ? mean[r] : 0.f; rs[j] = r < M ? rstd[r] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            const bool ok = r < M && c < H;
+            xv[j][k] = ok ? *(const float4*)(x + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[j][k] = ok ? *(const float4*)(dy + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            od[j][k] = (ok && accumulate) ? *(const float4*)(dx + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = ra + j;
         float4 xh[NV], dh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * 64 + lane) * 4;
-            if (c < H) {
-                const float4 xv = *(const float4*)(x + (long long)r * H + c);
-                const float4 dv = *(const float4*)(dy + (long long)r * H + c);
-                xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                dh[k] = make_float4(dv.x * ww[k].x, dv.y * ww[k].y, dv.z * ww[k].z, dv.w * ww[k].w);
+            const float4 ww = (c < H) ? *(const float4*)(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[k] = make_float4((xv[j][k].x - mu[j]) * rs[j], (xv[j][k].y - mu[j]) * rs[j], (xv[j][k].z - mu[j]) * rs[j],
+                                (xv[j][k].w - mu[j]) * rs[j]);
+            dh[k] = make_float4(dv[j][k].x * ww.x, dv[j][k].y * ww.y, dv[j][k].z * ww.z, dv[j][k].w * ww.w);
+            if (c < H && r < M) {
                 s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
                 s2 += dh[k].x * xh[k].x + dh[k].y * xh[k].y + dh[k].z * xh[k].z + dh[k].w * xh[k].w;
-                gw[k].x += dv.x * xh[k].x; gw[k].y += dv.y * xh[k].y; gw[k].z += dv.z * xh[k].z; gw[k].w += dv.w * xh[k].w;
-                gb[k].x += dv.x; gb[k].y += dv.y; gb[k].z += dv.z; gb[k].w += dv.w;
+                gw[k].x += dv[j][k].x * xh[k].x; gw[k].y += dv[j][k].y * xh[k].y; gw[k].z += dv[j][k].z * xh[k].z; gw[k].w += dv[j][k].w * xh[k].w;
+                gb[k].x += dv[j][k].x; gb[k].y += dv[j][k].y; gb[k].z += dv[j][k].z; gb[k].w += dv[j][k].w;
             }
         }
         s1 = wave_sum(s1) * invH;
@@ -207,52 +219,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * 64 + lane) * 4;
-            if (c < H) {
-                float4 o = make_float4(rs * (dh[k].x - s1 - xh[k].x * s2), rs * (dh[k].y - s1 - xh[k].y * s2),
-                                       rs * (dh[k].z - s1 - xh[k].z * s2), rs * (dh[k].w - s1 - xh[k].w * s2));
-                float4* p = (float4*)(dx + (long long)r * H + c);
-                if (accumulate) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                *p = o;
+            if (c < H && r < M) {
+                const float4 o = make_float4(od[j][k].x + rs[j] * (dh[k].x - s1 - xh[k].x * s2), od[j][k].y + rs[j] * (dh[k].y - s1 - xh[k].y * s2),
+                                             od[j][k].z + rs[j] * (dh[k].z - s1 - xh[k].z * s2), od[j][k].w + rs[j] * (dh[k].w - s1 - xh[k].w * s2));
+                *(float4*)(dx + (long long)r * H + c) = o;
             }
         }
     }
-    // cross-wave reduce of the per-column partials, then one atomic per column per block
-    const int W = NV * 256;
-    if (wv > 0) {
+    // cross-wave reduce through LDS, then thread t owns columns t, t+256, ...: one CONTIGUOUS 256-B
+    // atomic wave-instruction per 64 columns (float atomics run at full rate only in that shape)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            *(float4*)(red + ((wv - 1) * 2 + 0) * W + (k * 64 + lane) * 4) = gw[k];
-            *(float4*)(red + ((wv - 1) * 2 + 1) * W + (k * 64 + lane) * 4) = gb[k];
-        }
+    for (int k = 0; k < NV; ++k) {
+        *(float4*)(red + (wv * 2 + 0) * W + (k * 64 + lane) * 4) = gw[k];
+        *(float4*)(red + (wv * 2 + 1) * W + (k * 64 + lane) * 4) = gb[k];
     }
     __syncthreads();
-    if (wv == 0) {
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float a = 0.f, b2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int c = (k * 64 + lane) * 4;
-            if (c < H) {
-                float4 a = gw[k], bsum = gb[k];
-                for (int o = 0; o < 3; ++o) {
-                    const float4 a2 = *(const float4*)(red + (o * 2 + 0) * W + c);
-                    const float4 b2 = *(const float4*)(red + (o * 2 + 1) * W + c);
-                    a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-                    bsum.x += b2.x; bsum.y += b2.y; bsum.z += b2.z; bsum.w += b2.w;
-                }
-                atomicAdd(dw + c + 0, a.x); atomicAdd(dw + c + 1, a.y); atomicAdd(dw + c + 2, a.z); atomicAdd(dw + c + 3, a.w);
-                atomicAdd(db + c + 0, bsum.x); atomicAdd(db + c + 1, bsum.y); atomicAdd(db + c + 2, bsum.z); atomicAdd(db + c + 3, bsum.w);
-            }
-        }
+        for (int o = 0; o < 4; ++o) { a += red[(o * 2 + 0) * W + c]; b2 += red[(o * 2 + 1) * W + c]; }
+        atomicAdd(rep_ptr(dw, rc, blockIdx.x) + c, a);
+        atomicAdd(rep_ptr(db, rc, blockIdx.x) + c, b2);
     }
 }
 
 int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s) {
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
     const int nv = (H + 255) / 256;
     dim3 g((M + LNB_ROWS - 1) / LNB_ROWS);
 #define LNB(NVV)                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 3 * 2 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
-                       rstd, dx, dw, db, M, H, accumulate_dx)
+    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 4 * 2 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
+                       rstd, dx, dw, db, M, H, accumulate_dx, rc)
     if (nv <= 1) LNB(1);
     else if (nv <= 4) LNB(4);
     else LNB(8);
@@ -390,40 +388,50 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
 // ------------------------------------------------------------------------------------------
 // dropout-cast, cast, colsum
 // ------------------------------------------------------------------------------------------
-constexpr int DC_ROWS = 32;  // rows per block
+constexpr int DC_ROWS = 8;  // rows per block: all 8 row loads of a thread are in flight together
 
 // out = in * keepmask (act dtype), optionally colsum[n] += sum_m out[m][n]. One thread owns 4
 // consecutive columns of DC_ROWS rows, so the bias-gradient column sums cost one atomic per column per block.
 template <typename TO>
 __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, int M, int N,
-                                                       unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum) {
+                                                       unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum, RepCfg rc) {
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= N) return;
     const int r0 = blockIdx.y * DC_ROWS;
+    float4 q[DC_ROWS];
+#pragma unroll
+    for (int j = 0; j < DC_ROWS; ++j)
+        q[j] = (r0 + j < M) ? *(const float4*)(in + (long long)(r0 + j) * N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < min(M, r0 + DC_ROWS); ++r) {
-        const long long i = (long long)r * N + c;
-        const float4 q = *(const float4*)(in + i);
-        float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < DC_ROWS; ++j) {
+        if (r0 + j >= M) break;
+        const long long i = (long long)(r0 + j) * N + c;
+        float v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
         if (thr) drop4(key, thr, (unsigned)i, dscale, v);
-        stf<TO>(out, i, v[0]); stf<TO>(out, i + 1, v[1]); stf<TO>(out, i + 2, v[2]); stf<TO>(out, i + 3, v[3]);
+        if constexpr (sizeof(TO) == 2) {
+            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)((bf16_t*)out + i) = o;
+        } else {
+            *(float4*)((float*)out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
     if (colsum) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(colsum + c + e, s[e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(rep_ptr(colsum, rc, blockIdx.y) + c + e, s[e]);
     }
 }
 
 int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed, uint32_t site,
-                      float* colsum, hipStream_t s) {
+                      float* colsum, hipStream_t s, RepCfg rc) {
     NBCI_REQUIRE(N % 4 == 0, NBCI_ESHAPE, "dropcast: N must be a multiple of 4");
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     dim3 g((N / 4 + 255) / 256, (M + DC_ROWS - 1) / DC_ROWS);
     DISPATCH_DTYPE(out_dtype, TO,
                    hipLaunchKernelGGL((dropcast_kernel<TO>), g, dim3(256), 0, s, in, (TO*)out, M, N, thr, dscale,
-                                      drop_key(seed, site), colsum));
+                                      drop_key(seed, site), colsum, rc));
     return check_launch("dropcast");
 }
 
@@ -432,34 +440,59 @@ int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float 
     // flat form: treat as rows of 1024 (or one row when short / not divisible)
     const int N = (n % 1024 == 0) ? 1024 : (int)n;
     NBCI_REQUIRE(n % 4 == 0 && n / N < 2147483647LL, NBCI_ESHAPE, "dropcast: length must be a multiple of 4");
-    return dropcast2d_launch(in, out, out_dtype, (int)(n / N), N, drop_p, seed, site, nullptr, s);
+    return dropcast2d_launch(in, out, out_dtype, (int)(n / N), N, drop_p, seed, site, nullptr, s, RepCfg{0, 1});
 }
 
 int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s) {
     return dropcast_launch(in, out, out_dtype, n, 0.f, 0, 0, s);
 }
 
-constexpr int CS_ROWS = 256;  // rows per block
+constexpr int CS_ROWS = 128;  // rows per block (4 row-threads x 32 rows each, 16-byte loads)
 
-template <typename TI>
+// out[n] += sum_m in[m][n]. Block = 64 column-threads x 4 row-threads; a thread owns E = 16 B / sizeof(T)
+// consecutive columns. Falls back to scalar columns when the row pitch is not 16-byte aligned.
+template <typename TI, bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, long long ld, int M, int N,
-                                                     float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rq = threadIdx.x >> 6;
+                                                     float* __restrict__ out, RepCfg rc) {
+    constexpr int E = VEC ? (int)(16 / sizeof(TI)) : 1;
+    __shared__ float red[4][64 * E];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cx) * E;
     const int r0 = blockIdx.y * CS_ROWS;
-    float acc = 0.f;
-    if (c < N)
-        for (int r = r0 + rq; r < min(M, r0 + CS_ROWS); r += 4) acc += ldf<TI>(in, (long long)r * ld + c);
-    red[rq][threadIdx.x & 63] = acc;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (c < N) {
+        const int rend = min(M, r0 + CS_ROWS);
+        if constexpr (VEC) {
+#pragma unroll 4
+            for (int r = r0 + ry; r < rend; r += 4) {
+                const uint4 q = *(const uint4*)(in + (long long)r * ld + c);
+                const TI* qe = (const TI*)&q;
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += (c + e < N) ? (float)qe[e] : 0.f;
+            }
+        } else {
+            for (int r = r0 + ry; r < rend; r += 4) acc[0] += ldf<TI>(in, (long long)r * ld + c);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[ry][cx * E + e] = acc[e];
     __syncthreads();
-    if (rq == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    for (int i = threadIdx.x; i < 64 * E; i += 256) {
+        const int col = blockIdx.x * 64 * E + i;
+        if (col < N) atomicAdd(rep_ptr(out, rc, blockIdx.y) + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    }
 }
 
-int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s) {
-    dim3 g((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS);
-    DISPATCH_DTYPE(in_dtype, TI,
-                   hipLaunchKernelGGL((colsum_kernel<TI>), g, dim3(256), 0, s, (const TI*)in, (long long)ld, M, N, out));
+int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s, RepCfg rc) {
+    const int E = in_dtype == NBCI_BF16 ? 8 : 4;
+    const bool vec = (ld % E == 0) && (((uintptr_t)in) % 16 == 0);
+    dim3 g(vec ? (N + 64 * E - 1) / (64 * E) : (N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS);
+    DISPATCH_DTYPE(in_dtype, TI, {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<TI, true>), g, dim3(256), 0, s, (const TI*)in, (long long)ld, M, N, out, rc);
+        else hipLaunchKernelGGL((colsum_kernel<TI, false>), g, dim3(256), 0, s, (const TI*)in, (long long)ld, M, N, out, rc);
+    });
     return check_launch("colsum");
 }
 
@@ -789,6 +822,28 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
     NBCI_REQUIRE(lds <= 60000, NBCI_ESHAPE, "per: sequence too long for the LDS-resident edit distance");
     hipLaunchKernelGGL(per_kernel, dim3(B), dim3(64), lds, s, argmax, targets, tgt_lens, Tp, S, blank, decoded, dec_lens, errors);
     return check_launch("per");
+}
+
+// ------------------------------------------------------------------------------------------
+// fold the replicated small-vector accumulators into the flat gradient buffer and clear them
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_replicas_kernel(float* __restrict__ rep, long long stride, int nrep,
+                                                            const int* __restrict__ flat_of, int cbegin, int cend,
+                                                            float* __restrict__ grads) {
+    const int ci = cbegin + blockIdx.x * 256 + threadIdx.x;
+    if (ci >= cend) return;
+    float s = 0.f;
+    for (int r = 0; r < nrep; ++r) { s += rep[(long long)r * stride + ci]; rep[(long long)r * stride + ci] = 0.f; }
+    const int fo = flat_of[ci];
+    if (fo >= 0) grads[fo] += s;
+}
+
+int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat_of, int cbegin, int cend, float* grads,
+                         hipStream_t s) {
+    if (cend <= cbegin) return NBCI_OK;
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((cend - cbegin + 255) / 256), dim3(256), 0, s, rep, stride, nrep, flat_of, cbegin,
+                       cend, grads);
+    return check_launch("fold_replicas");
 }
 
 // ------------------------------------------------------------------------------------------

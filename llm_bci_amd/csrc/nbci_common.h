@@ -93,6 +93,15 @@ __device__ __forceinline__ float rng_normal(uint32_t seed, uint32_t site, uint32
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
+// ---- replicated accumulators ---------------------------------------------------------------
+// Float atomics to ONE address serialise at ~100 ns per adder on MI355X, so small vectors that many
+// workgroups sum into (bias / LayerNorm gradients) are spread over `n` replicas `stride` floats
+// apart; workgroup `blk` adds into replica blk % n and a fold kernel sums the replicas afterwards.
+struct RepCfg { long long stride; int n; };
+__device__ __forceinline__ float* rep_ptr(float* p, RepCfg rc, unsigned blk) {
+    return rc.n > 1 ? p + (long long)(blk % (unsigned)rc.n) * rc.stride : p;
+}
+
 // ---- wave64 reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

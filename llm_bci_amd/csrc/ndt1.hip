@@ -10,6 +10,7 @@
 // contiguous range = one RCCL bucket. Activations saved for backward live in the caller's
 // workspace (size from nbci_ndt1_workspace_bytes).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,7 +37,19 @@ struct Plan {
     std::vector<std::pair<int64_t, int64_t>> seg;  // [begin,end) per segment
     float* d_taps;
     int ntaps;
+    bool fused_attn;  // use attention.hip when the shape allows (NBCI_FUSED_ATTN=0 disables)
+    // replicated accumulators for the 1-D parameters' gradients (biases, LayerNorm): compact index space
+    std::vector<int> flat_of;               // compact index -> flat gradient offset (-1 = padding)
+    std::vector<std::pair<int, int>> cseg;  // compact [begin,end) per segment
+    int* d_flat_of;
+    int compact_total;
+    int compact_of(int64_t flat_off) const {
+        for (size_t i = 0; i < cmap.size(); ++i) if (cmap[i].first == flat_off) return cmap[i].second;
+        return -1;
+    }
+    std::vector<std::pair<int64_t, int>> cmap;  // (flat offset of a 1-D param, compact offset)
 };
+constexpr int NREP = 32;
 
 constexpr int64_t PALIGN = 8;  // elements: 32 B in f32, 16 B in bf16
 
@@ -94,6 +107,24 @@ static void build_layout(Plan& p) {
     cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
     p.seg.push_back({begin, cur});
     p.total = cur;
+    // compact index space of all 1-D parameters, in parameter order (so a segment's entries are contiguous)
+    int cc = 0;
+    p.cseg.assign(p.seg.size(), {0, 0});
+    int cur_seg = -1;
+    for (const PInfo& pi : p.params) {
+        if (pi.seg != cur_seg) {
+            if (cur_seg >= 0) p.cseg[cur_seg].second = cc;
+            cur_seg = pi.seg;
+            p.cseg[cur_seg].first = cc;
+        }
+        if (pi.cols != 0) continue;
+        p.cmap.push_back({pi.off, cc});
+        for (int i = 0; i < pi.rows; ++i) p.flat_of.push_back((int)(pi.off + i));
+        cc += pi.rows;
+        while (cc % 4) { p.flat_of.push_back(-1); ++cc; }
+    }
+    if (cur_seg >= 0) p.cseg[cur_seg].second = cc;
+    p.compact_total = cc;
 }
 
 // ---- workspace carve -----------------------------------------------------------------------
@@ -105,7 +136,7 @@ struct WS {
     std::vector<LayerWS> L;
     size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
-    size_t dx, dtmp, dA, dB, dqkv, dS, dwin, dpre;
+    size_t dx, dtmp, dA, dB, dqkv, dS, dwin, dpre, rep;
     size_t bytes;
     int Tp, M, ldS, ldP, vpad;
 };
@@ -166,6 +197,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.dS = bump(cur, nP * es);
     w.dwin = bump(cur, M * (size_t)c.stack_size * D * es);
     w.dpre = bump(cur, (size_t)B * T * D * es);
+    w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
     w.bytes = (cur + 255) / 256 * 256;
     return NBCI_OK;
 }
@@ -257,6 +289,8 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
     char* ws = x.ws;
 
+    if (io->want_grad)  // replicated small-gradient accumulators start each step at zero
+        NBCI_CHECK_HIP(hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * p.compact_total * 4, s));
     // 0. token bookkeeping + smoothing/noise (ndt1.py:92-107,181-183,207-208)
     TRY(token_prep_launch(io->spikes_mask, io->spikes_timestamp, io->spikes_lengths, B, T, Tp, c.stack_size, c.stack_stride,
                           (int32_t*)(ws + w.tmask), (int64_t*)(ws + w.tts), (int32_t*)(ws + w.tlens), s));
@@ -302,23 +336,28 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         }
         if (c.use_rope)
             TRY(rope_launch(ws + lw.qkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 0, s));
-        {   // scores = q k^T / sqrt(hd), batched over (b, head)
-            nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd),
-                                  op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd), ws + w.scores, w.ldS,
-                                  NBCI_F32);
-            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS; d.alpha = scale;
-            TRY(gemm_launch_timed(d, s));
-        }
-        TRY(softmax_fwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + (p_lay > 0.f ? lw.Pd : lw.P), dt,
-                               (const int32_t*)(ws + w.tmask), B, nh, Tp, w.ldS, w.ldP, c.context_forward, c.context_backward,
-                               p_lay, io->seed, 16 + 4 * l, s));
-        {   // a = dropout(merge_heads(Pd v)) written straight into the merged (M, H) layout
-            const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
-            nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 1, 0, 0, (int64_t)nh * Tp * w.ldP, (int64_t)Tp * w.ldP),
-                                  op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)Tp * 3 * H, hd), ws + lw.ad, H, dt);
-            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)Tp * H; d.czs2 = hd;
-            d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
-            TRY(gemm_launch_timed(d, s));
+        if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
+            TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, B, nh, Tp, H, c.context_forward,
+                                c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
+        } else {
+            {   // scores = q k^T / sqrt(hd), batched over (b, head)
+                nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd),
+                                      op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd), ws + w.scores, w.ldS,
+                                      NBCI_F32);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS; d.alpha = scale;
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(softmax_fwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + (p_lay > 0.f ? lw.Pd : lw.P), dt,
+                                   (const int32_t*)(ws + w.tmask), B, nh, Tp, w.ldS, w.ldP, c.context_forward, c.context_backward,
+                                   p_lay, io->seed, 16 + 4 * l, s));
+            {   // a = dropout(merge_heads(Pd v)) written straight into the merged (M, H) layout
+                const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
+                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 1, 0, 0, (int64_t)nh * Tp * w.ldP, (int64_t)Tp * w.ldP),
+                                      op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)Tp * 3 * H, hd), ws + lw.ad, H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)Tp * H; d.czs2 = hd;
+                d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
+                TRY(gemm_launch_timed(d, s));
+            }
         }
         {   // x_mid = x_in + out_proj(a)
             nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), x_mid, H, NBCI_F32);
@@ -386,19 +425,22 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     float* dx = (float*)(ws + w.dx);
     float* dtmp = (float*)(ws + w.dtmp);
     const float scale = 1.0f / sqrtf((float)hd);
+    float* rep = (float*)(ws + w.rep);
+    const RepCfg rc{p.compact_total, NREP};
+    auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };  // replica-0 slot of a 1-D param's grad
 
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
         if (seg == c.n_layers + 1) {
             // ---- head: decoder Linear + out_norm
             const void* dl = ws + w.dlogits;
-            TRY(colsum_launch(dl, dt, w.vpad, M, V, grads + p.decb, s));
+            TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
             TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
             {
                 nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
-                                     (const float*)(ws + w.rstd_o), dx, grads + p.onw, grads + p.onb, M, H, 0, s));
+                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
@@ -407,16 +449,16 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const void* dm;  // d(down output) in the GEMM operand dtype; bias grad fused into the cast pass
             if (dt == NBCI_F32 && p_lay == 0.f) {
                 dm = dx;
-                TRY(colsum_launch(dm, dt, H, M, H, grads + lo.dnb, s));
+                TRY(colsum_launch(dm, dt, H, M, H, RG(lo.dnb), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_lay, io->seed, 18 + 4 * l, grads + lo.dnb, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_lay, io->seed, 18 + 4 * l, RG(lo.dnb), s, rc));
                 dm = ws + w.dA;
             }
             TRY(wgrad(s, dt, H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
             {   // du = (dm W_down) * act'(u)
                 nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
                 d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
-                d.colsum = grads + lo.upb;  // up_proj bias grad = column sums of du
+                d.colsum = RG(lo.upb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;  // up_proj bias grad = column sums of du
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(wgrad(s, dt, I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
@@ -425,14 +467,14 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
-                                     (const float*)(ws + lw.rstd2), dx, grads + lo.ln2w, grads + lo.ln2b, M, H, 1, s));
+                                     (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
             if (dt == NBCI_F32) {
                 dxc = dx;
-                TRY(colsum_launch(dx, NBCI_F32, H, M, H, grads + lo.ob, s));
+                TRY(colsum_launch(dx, NBCI_F32, H, M, H, RG(lo.ob), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, 0.f, 0, 0, grads + lo.ob, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, 0.f, 0, 0, RG(lo.ob), s, rc));
                 dxc = ws + w.dA;
             }
             TRY(wgrad(s, dt, H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
@@ -444,39 +486,45 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
             const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
-            {   // dPd = da v^T   (f32, reuses the score buffer)
-                nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB, es, 0, H, 1, 0, 0, az1, hd),
-                                      op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
-                d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS;
-                TRY(gemm_launch_timed(d, s));
+            if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
+                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + w.dB, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
+                                    nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
+                                    io->seed, 16 + 4 * l, s, rc));
+            } else {
+                {   // dPd = da v^T   (f32, reuses the score buffer)
+                    nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB, es, 0, H, 1, 0, 0, az1, hd),
+                                          op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
+                    d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS;
+                    TRY(gemm_launch_timed(d, s));
+                }
+                {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
+                    nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
+                                          op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
+                    d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
+                    if (!c.use_rope) d.colsum = RG(lo.vb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                    TRY(gemm_launch_timed(d, s));
+                }
+                TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, Tp, w.ldS, w.ldP, p_lay,
+                                       io->seed, 16 + 4 * l, s));
+                {   // dq = dS k * scale
+                    nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
+                                          op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
+                    d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                    if (!c.use_rope) d.colsum = RG(lo.qb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                    TRY(gemm_launch_timed(d, s));
+                }
+                {   // dk = dS^T q * scale
+                    nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
+                                          op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
+                    d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                    if (!c.use_rope) d.colsum = RG(lo.kb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                    TRY(gemm_launch_timed(d, s));
+                }
             }
-            {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
-                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
-                                      op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
-                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
-                if (!c.use_rope) d.colsum = grads + lo.vb;
-                TRY(gemm_launch_timed(d, s));
-            }
-            TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, Tp, w.ldS, w.ldP, p_lay,
-                                   io->seed, 16 + 4 * l, s));
-            {   // dq = dS k * scale
-                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
-                                      op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
-                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
-                if (!c.use_rope) d.colsum = grads + lo.qb;
-                TRY(gemm_launch_timed(d, s));
-            }
-            {   // dk = dS^T q * scale
-                nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
-                                      op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
-                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
-                if (!c.use_rope) d.colsum = grads + lo.kb;
-                TRY(gemm_launch_timed(d, s));
-            }
-            if (c.use_rope) {  // bias grads are taken after the inverse rotation
-                TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
-                TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, grads + lo.qb, s));
-            }
+            const bool fused_bwd = p.fused_attn && attn_fused_eligible(dt, Tp, H, nh);
+            if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
+            if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
+                TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
             TRY(wgrad(s, dt, 3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
             {
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
@@ -484,16 +532,16 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
-                                     (const float*)(ws + lw.rstd1), dx, grads + lo.ln1w, grads + lo.ln1b, M, H, 1, s));
+                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc));
         } else {
             // ---- embedder backward (ndt1.py:160-203)
             const int KS = c.stack_size * D;
             const void* dx0;
             if (dt == NBCI_F32 && p_emb == 0.f) {
                 dx0 = dx;
-                TRY(colsum_launch(dx0, dt, H, M, H, grads + p.stkb, s));
+                TRY(colsum_launch(dx0, dt, H, M, H, RG(p.stkb), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_emb, io->seed, 3, grads + p.stkb, s));
+                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_emb, io->seed, 3, RG(p.stkb), s, rc));
                 dx0 = ws + w.dA;
             }
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
@@ -505,10 +553,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
                                       c.embed_act, s));
-            TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, grads + p.embb, s));
+            TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, RG(p.embb), s, rc));
             TRY(wgrad(s, dt, D, c.n_channels, B * T, op(ws + w.dpre, es, 0, D, 0), op(ws + w.xs, es, 0, c.n_channels, 0),
                       grads + p.embw, c.n_channels));
         }
+        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
     return NBCI_OK;
 }
@@ -538,6 +587,10 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
     build_layout(*p);
     p->d_taps = nullptr;
     p->ntaps = 0;
+    {
+        const char* e = getenv("NBCI_FUSED_ATTN");
+        p->fused_attn = !(e && e[0] == '0');
+    }
     if (c.smooth_sd > 0.f) {
         // scipy.signal.gaussian(1 + 6*sd, sd) normalised, built in float64 (ndt1.py:87-88)
         const int n = 1 + (int)(6 * c.smooth_sd);
@@ -552,6 +605,13 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
         if (e != hipSuccess) { delete p; return fail(NBCI_EHIP, std::string("plan_create: ") + hipGetErrorString(e)); }
         p->ntaps = n;
     }
+    p->d_flat_of = nullptr;
+    {
+        hipError_t e = hipMalloc(&p->d_flat_of, std::max<size_t>(4, p->flat_of.size() * sizeof(int)));
+        if (e == hipSuccess && !p->flat_of.empty())
+            e = hipMemcpy(p->d_flat_of, p->flat_of.data(), p->flat_of.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (p->d_taps) (void)hipFree(p->d_taps); delete p; return fail(NBCI_EHIP, std::string("plan_create: ") + hipGetErrorString(e)); }
+    }
     *out = (nbci_ndt1_plan)p;
     return NBCI_OK;
 }
@@ -560,6 +620,7 @@ void nbci_ndt1_plan_destroy(nbci_ndt1_plan plan) {
     Plan* p = (Plan*)plan;
     if (!p) return;
     if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_flat_of) (void)hipFree(p->d_flat_of);
     delete p;
 }
 

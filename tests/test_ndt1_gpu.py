@@ -261,3 +261,27 @@ def test_checkpoint_roundtrip_and_reference_key_layout(tmp_path):
     with torch.no_grad():
         b = m2(**batch).preds.cpu()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("T,lens,ctx", [(600, [600, 450], (-2, -2)), (100, [100, 70], (3, 2)), (664, [664, 664], (-2, -2))])
+def test_fused_attention_matches_batched_gemm_path(T, lens, ctx, monkeypatch):
+    """bf16: attention.hip (fused, T' <= 160) vs the batched-GEMM + softmax kernels on the same
+    weights, inputs and dropout streams (train mode, recipe dropout). Both are bf16 pipelines that
+    round at different points, so the bound is bf16-level: 0.03 on log-probs, 3 % of each
+    gradient's max-abs."""
+    over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2},
+                        "context": {"forward": ctx[0], "backward": ctx[1]}}}
+    batch = _to_dev(_rand_batch(2, T, 64, 12, 41, lens, [12, 7]))
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NBCI_FUSED_ATTN", fused)
+        m = _model(over, 41, dtype="bf16").to(DEV)
+        outs.append(_grads(m, batch, train=True, seed=77))
+    (l1, p1, g1), (l0, p0, g0) = outs
+    assert np.abs(p1 - p0).max() < 0.03, np.abs(p1 - p0).max()
+    np.testing.assert_allclose(l1, l0, rtol=5e-3)
+    for k in g1:
+        if k.endswith("attn.key.bias"):
+            continue  # exactly zero in theory (softmax shift invariance): both paths return rounding noise
+        scale = max(1e-6, float(np.abs(g0[k]).max()))
+        assert np.abs(g1[k] - g0[k]).max() <= 0.03 * scale + 1e-6, (k, np.abs(g1[k] - g0[k]).max(), scale)
