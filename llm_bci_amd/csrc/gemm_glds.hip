@@ -112,7 +112,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int tm = wg / d.tiles_n, tn = wg % d.tiles_n;
+    // grouped raster: 8 tile-rows x successive tile-columns, so the ~64 tiles an XCD runs at once
+    // form an 8 x 8 patch (8 A panels + 8 B panels in its 4 MB L2) instead of 1 x 64
+    int tm, tn;
+    {
+        const int per_group = 8 * d.tiles_n;
+        const int grp = wg / per_group, in_grp = wg % per_group;
+        const int first_m = grp * 8;
+        const int gsize = min(8, d.tiles_m - first_m);
+        tm = first_m + in_grp % gsize;
+        tn = in_grp / gsize;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.y;
