@@ -33,12 +33,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
 
     // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (round-robin dispatch), so give
     // every XCD a contiguous run of tiles; consecutive tiles share the A row panel in that L2.
+    // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (round-robin dispatch), so give every
+    // XCD a contiguous run of work items. Split-K launches are 1-D over (split, tile) with the split
+    // index slowest: one XCD then owns (most of) one K slice, whose A/B slices fit its 4 MB L2 and are
+    // fetched from HBM once instead of once per tile row/column.
     const int nwg = d.tiles_m * d.tiles_n;
-    int wg;
+    const int nitems = nwg * (d.splitk > 1 ? d.splitk : 1);
+    int item;
     {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int orig = blockIdx.x, xcd = orig & 7, q = nitems >> 3, r = nitems & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
+    const int wg = item % nwg;
+    const int zsplit = item / nwg;
     // grouped raster: 8 tile-rows x successive tile-columns, so the ~64 tiles an XCD runs at once
     // form an 8 x 8 patch (8 A panels + 8 B panels in its 4 MB L2) instead of 1 x 64
     int tm, tn;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
     }
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
-    const int z = blockIdx.y;
+    const int z = d.splitk > 1 ? zsplit : (int)blockIdx.y;
     int kt_begin = 0, kt_end = (d.K + BK - 1) / BK;
     OperandK A = d.A, B = d.B;
     long long coff = 0;
@@ -181,7 +188,7 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     k.cvec = cvec ? 1 : 0;
 
     if (d.in_dtype == NBCI_BF16 && glds_eligible(d, k)) return gemm_glds_launch(d, k, stream);
-    dim3 grid(k.tiles_m * k.tiles_n, splitk > 1 ? splitk : batch);
+    dim3 grid(k.tiles_m * k.tiles_n * (splitk > 1 ? splitk : 1), splitk > 1 ? 1 : batch);
     if (d.in_dtype == NBCI_BF16) return launch_layout<bf16_t>(k, d.A.kmajor != 0, d.B.kmajor != 0, grid, stream);
     return launch_layout<float>(k, d.A.kmajor != 0, d.B.kmajor != 0, grid, stream);
 }

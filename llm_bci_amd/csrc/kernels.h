@@ -25,7 +25,7 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
 // backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
 int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s,
-                         RepCfg rc = RepCfg{0, 1});
+                         RepCfg rc = RepCfg{0, 1}, LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr});
 
 // masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437),
 // writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP

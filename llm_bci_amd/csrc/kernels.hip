@@ -28,10 +28,22 @@ static int check_launch(const char* what) {
 // ------------------------------------------------------------------------------------------
 // smoothing + noise
 // ------------------------------------------------------------------------------------------
-constexpr int SM_TCHUNK = 32;
+constexpr int SM_TCHUNK = 30;   // outputs per thread (even: white noise is drawn in (cos, sin) pairs)
 constexpr int SM_MAXTAPS = 64;
 
-template <typename TO>
+// two standard normals from one Box-Muller transform (pair index = element index >> 1 along time)
+__device__ __forceinline__ void normal_pair(uint32_t seed, uint32_t site, uint32_t pidx, float& z0, float& z1) {
+    const uint32_t a = rng_u32(seed, site, pidx);
+    const uint32_t b = rng_u32(seed ^ 0x5bd1e995U, site + 0x1000193U, pidx);
+    const float rad = sqrtf(-2.0f * __logf(rng_uniform01(a)));
+    const float ang = 6.283185307179586f * rng_uniform01(b);
+    z0 = rad * __cosf(ang);
+    z1 = rad * __sinf(ang);
+}
+
+// One thread = one (batch, channel) column x SM_TCHUNK consecutive bins; lanes run along channels
+// (coalesced). The taps slide over a register window, so every input element is loaded once per thread.
+template <typename TO, int NT>
 __global__ __launch_bounds__(256) void smooth_noise_kernel(const float* __restrict__ in, TO* __restrict__ out, int B,
                                                            int T, int N, const float* __restrict__ taps, int ntaps,
                                                            float white_sd, float offset_sd, uint32_t seed) {
@@ -46,20 +58,51 @@ __global__ __launch_bounds__(256) void smooth_noise_kernel(const float* __restri
     const float* src = in + (long long)b * T * N + n;
     float off = 0.f;
     if (offset_sd != 0.f) off = offset_sd * rng_normal(seed, 2u, (uint32_t)(b * N + n));
-    for (int t = t0; t < min(T, t0 + SM_TCHUNK); ++t) {
-        float acc = 0.f;
-        if (ntaps > 0) {
-            for (int i = 0; i < ntaps; ++i) {
-                const int tt = t + i - half;
-                if (tt >= 0 && tt < T) acc += stap[i] * src[(long long)tt * N];
-            }
-        } else {
-            acc = src[(long long)t * N];
+    if constexpr (NT > 0) {
+        float win[NT + SM_TCHUNK - 1];
+#pragma unroll
+        for (int i = 0; i < NT + SM_TCHUNK - 1; ++i) {
+            const int tt = t0 + i - (NT - 1) / 2;
+            win[i] = (tt >= 0 && tt < T) ? src[(long long)tt * N] : 0.f;
         }
-        const long long o = ((long long)b * T + t) * N + n;
-        if (white_sd != 0.f) acc += white_sd * rng_normal(seed, 1u, (uint32_t)o);
-        acc += off;
-        stf<TO>(out, o, acc);
+#pragma unroll
+        for (int j = 0; j < SM_TCHUNK; j += 2) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { a0 += stap[i] * win[j + i]; a1 += stap[i] * win[j + 1 + i]; }
+            const int t = t0 + j;
+            const long long o = ((long long)b * T + t) * N + n;
+            if (white_sd != 0.f) {
+                // pair (t, t+1) of one channel shares a Box-Muller draw; index = position of the even bin
+                float z0, z1;
+                normal_pair(seed, 1u, (uint32_t)(((long long)b * N + n) * ((T + 1) / 2) + (t >> 1)), z0, z1);
+                a0 += white_sd * z0; a1 += white_sd * z1;
+            }
+            if (t < T) stf<TO>(out, o, a0 + off);
+            if (t + 1 < T) stf<TO>(out, o + N, a1 + off);
+        }
+    } else {
+        for (int t = t0; t < min(T, t0 + SM_TCHUNK); t += 2) {
+            float a0 = 0.f, a1 = 0.f;
+            if (ntaps > 0) {
+                for (int i = 0; i < ntaps; ++i) {
+                    const int tt = t + i - half;
+                    if (tt >= 0 && tt < T) a0 += stap[i] * src[(long long)tt * N];
+                    if (tt + 1 >= 0 && tt + 1 < T) a1 += stap[i] * src[(long long)(tt + 1) * N];
+                }
+            } else {
+                a0 = src[(long long)t * N];
+                a1 = (t + 1 < T) ? src[(long long)(t + 1) * N] : 0.f;
+            }
+            const long long o = ((long long)b * T + t) * N + n;
+            if (white_sd != 0.f) {
+                float z0, z1;
+                normal_pair(seed, 1u, (uint32_t)(((long long)b * N + n) * ((T + 1) / 2) + (t >> 1)), z0, z1);
+                a0 += white_sd * z0; a1 += white_sd * z1;
+            }
+            stf<TO>(out, o, a0 + off);
+            if (t + 1 < T) stf<TO>(out, o + N, a1 + off);
+        }
     }
 }
 
@@ -67,9 +110,14 @@ int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, in
                         int ntaps, float white_sd, float offset_sd, uint32_t seed, hipStream_t s) {
     NBCI_REQUIRE(ntaps <= SM_MAXTAPS, NBCI_ESHAPE, "smooth: too many taps (max 64)");
     dim3 grid((unsigned)(((long long)B * N + 255) / 256), (T + SM_TCHUNK - 1) / SM_TCHUNK);
-    DISPATCH_DTYPE(out_dtype, TO,
-                   hipLaunchKernelGGL((smooth_noise_kernel<TO>), grid, dim3(256), 0, s, spikes, (TO*)out, B, T, N, taps,
-                                      ntaps, white_sd, offset_sd, seed));
+    DISPATCH_DTYPE(out_dtype, TO, {
+        if (ntaps == 13)  // the recipe's smooth_sd = 2: taps unrolled over a register window
+            hipLaunchKernelGGL((smooth_noise_kernel<TO, 13>), grid, dim3(256), 0, s, spikes, (TO*)out, B, T, N, taps, ntaps,
+                               white_sd, offset_sd, seed);
+        else
+            hipLaunchKernelGGL((smooth_noise_kernel<TO, 0>), grid, dim3(256), 0, s, spikes, (TO*)out, B, T, N, taps, ntaps,
+                               white_sd, offset_sd, seed);
+    });
     return check_launch("smooth_noise");
 }
 
@@ -171,14 +219,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
-                                                     int accumulate, RepCfg rc) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][NV*256]
+                                                     int accumulate, RepCfg rc, LnCast cz) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][NV*256]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float invH = 1.0f / (float)H;
     const int W = NV * 256;
-    float4 gw[NV], gb[NV];
+    float4 gw[NV], gb[NV], gc[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; }
+    for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; gc[k] = gw[k]; }
     const int ra = blockIdx.x * LNB_ROWS + wv * 2;
     float4 xv[2][NV], dv[2][NV], od[2][NV];
     float mu[2], rs[2];
@@ -223,6 +271,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 const float4 o = make_float4(od[j][k].x + rs[j] * (dh[k].x - s1 - xh[k].x * s2), od[j][k].y + rs[j] * (dh[k].y - s1 - xh[k].y * s2),
                                              od[j][k].z + rs[j] * (dh[k].z - s1 - xh[k].z * s2), od[j][k].w + rs[j] * (dh[k].w - s1 - xh[k].w * s2));
                 *(float4*)(dx + (long long)r * H + c) = o;
+                if (cz.out) {  // fused "dropcast" of the updated gradient stream for the next GEMMs (+ bias-grad sums)
+                    const long long i = (long long)r * H + c;
+                    float v[4] = {o.x, o.y, o.z, o.w};
+                    if (cz.thr) drop4(cz.key, cz.thr, (unsigned)i, cz.scale, v);
+                    if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + i) = ov; }
+                    else *(float4*)((float*)cz.out + i) = make_float4(v[0], v[1], v[2], v[3]);
+                    gc[k].x += v[0]; gc[k].y += v[1]; gc[k].z += v[2]; gc[k].w += v[3];
+                }
             }
         }
     }
@@ -230,27 +286,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // atomic wave-instruction per 64 columns (float atomics run at full rate only in that shape)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        *(float4*)(red + (wv * 2 + 0) * W + (k * 64 + lane) * 4) = gw[k];
-        *(float4*)(red + (wv * 2 + 1) * W + (k * 64 + lane) * 4) = gb[k];
+        *(float4*)(red + (wv * 3 + 0) * W + (k * 64 + lane) * 4) = gw[k];
+        *(float4*)(red + (wv * 3 + 1) * W + (k * 64 + lane) * 4) = gb[k];
+        *(float4*)(red + (wv * 3 + 2) * W + (k * 64 + lane) * 4) = gc[k];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < H; c += 256) {
-        float a = 0.f, b2 = 0.f;
+        float a = 0.f, b2 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) { a += red[(o * 2 + 0) * W + c]; b2 += red[(o * 2 + 1) * W + c]; }
+        for (int o = 0; o < 4; ++o) { a += red[(o * 3 + 0) * W + c]; b2 += red[(o * 3 + 1) * W + c]; c2 += red[(o * 3 + 2) * W + c]; }
         atomicAdd(rep_ptr(dw, rc, blockIdx.x) + c, a);
         atomicAdd(rep_ptr(db, rc, blockIdx.x) + c, b2);
+        if (cz.colsum) atomicAdd(rep_ptr(cz.colsum, rc, blockIdx.x) + c, c2);
     }
 }
 
 int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc) {
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
     const int nv = (H + 255) / 256;
     dim3 g((M + LNB_ROWS - 1) / LNB_ROWS);
 #define LNB(NVV)                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 4 * 2 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
-                       rstd, dx, dw, db, M, H, accumulate_dx, rc)
+    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
+                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz)
     if (nv <= 1) LNB(1);
     else if (nv <= 4) LNB(4);
     else LNB(8);
@@ -637,21 +695,24 @@ __device__ __forceinline__ float log_add3(float a, float b, float c) {
     return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
-size_t ctc_alpha_floats(int B, int Tp, int S) { return (size_t)B * Tp * (2 * (size_t)S + 1); }
+size_t ctc_alpha_floats(int B, int Tp, int S) { return 2 * (size_t)B * Tp * (2 * (size_t)S + 1); }  // alpha + beta
 
-// One workgroup per sample. alpha is kept in global memory (B, Tp, 2S+1); beta lives in LDS.
+// One workgroup per sample. The alpha recursion (threads 0..127) and the beta recursion (threads
+// 128..255) advance together, one frame per barrier, each keeping its running row in LDS and
+// writing the full lattice to the HBM workspace; the occupancy sums and the gradient are then a
+// fully parallel pass over (frame, state).
 template <typename TD>
 __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ preds, const int64_t* __restrict__ targets,
                                                   const int32_t* __restrict__ in_lens, const int64_t* __restrict__ tgt_lens,
                                                   int Tp, int V, int S, int blank, int zero_inf, float* __restrict__ loss,
-                                                  float* __restrict__ alpha_ws, TD* __restrict__ dlogits, int ldd,
-                                                  float grad_scale) {
+                                                  float* __restrict__ ws, TD* __restrict__ dlogits, int ldd,
+                                                  float grad_scale, int Bn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Lmax = 2 * S + 1;
-    float* buf0 = sm;                 // [Lmax]
-    float* buf1 = sm + Lmax;          // [Lmax]
-    float* occ = sm + 2 * Lmax;       // [V]
-    int* ext = (int*)(sm + 2 * Lmax + V);  // [Lmax]
+    float* rowA = sm;                       // [2][Lmax] alpha double buffer
+    float* rowB = sm + 2 * Lmax;            // [2][Lmax] beta double buffer
+    int* ext = (int*)(sm + 4 * Lmax);       // [Lmax]
+    float* occ = sm + 5 * Lmax;             // [Tp][V] (gradient pass)
     __shared__ float s_nll;
     const int b = blockIdx.x, tid = threadIdx.x;
     int Tb = in_lens[b];
@@ -661,33 +722,53 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     if (Sb > S) Sb = S;
     const int L = 2 * Sb + 1;
     const float* lp = preds + (long long)b * Tp * V;
-    float* aw = alpha_ws + (long long)b * Tp * Lmax;
+    float* aw = ws + (long long)b * Tp * Lmax;
+    float* bw = ws + ((long long)Bn + b) * Tp * Lmax;
     for (int s = tid; s < L; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * S + (s >> 1)] : blank;
     __syncthreads();
-    // ---- alpha
-    float* prev = buf0; float* cur = buf1;
-    if (Tb > 0) {
-        for (int s = tid; s < L; s += 256) {
-            const float v = (s < 2) ? lp[ext[s]] : -INFINITY;
-            prev[s] = v; aw[s] = v;
-        }
-        __syncthreads();
-        for (int t = 1; t < Tb; ++t) {
-            for (int s = tid; s < L; s += 256) {
-                const float a0 = prev[s];
-                const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-                const float a2 = (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) ? prev[s - 2] : -INFINITY;
-                const float v = log_add3(a0, a1, a2) + lp[(long long)t * V + ext[s]];
+    const bool is_alpha = tid < 128;
+    const int ht = tid & 127;
+    for (int step = 0; step < Tb; ++step) {
+        if (is_alpha) {
+            const int t = step;
+            const float* prev = rowA + ((t + 1) & 1) * Lmax;
+            float* cur = rowA + (t & 1) * Lmax;
+            for (int s = ht; s < L; s += 128) {
+                float v;
+                if (t == 0) {
+                    v = (s < 2) ? lp[ext[s]] : -INFINITY;
+                } else {
+                    const float a0 = prev[s];
+                    const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+                    const float a2 = (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+                    v = log_add3(a0, a1, a2) + lp[(long long)t * V + ext[s]];
+                }
                 cur[s] = v; aw[(long long)t * Lmax + s] = v;
             }
-            __syncthreads();
-            float* tmp = prev; prev = cur; cur = tmp;
+        } else {
+            const int t = Tb - 1 - step;
+            const float* prev = rowB + ((step + 1) & 1) * Lmax;
+            float* cur = rowB + (step & 1) * Lmax;
+            for (int s = ht; s < L; s += 128) {
+                float v;
+                if (step == 0) {
+                    v = (s >= L - 2) ? lp[(long long)t * V + ext[s]] : -INFINITY;
+                } else {
+                    const float b0 = prev[s];
+                    const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+                    const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != ext[s]) ? prev[s + 2] : -INFINITY;
+                    v = log_add3(b0, b1, b2) + lp[(long long)t * V + ext[s]];
+                }
+                cur[s] = v; bw[(long long)t * Lmax + s] = v;
+            }
         }
+        __syncthreads();
     }
     if (tid == 0) {
         float ll;
         if (Tb > 0) {
-            const float a = prev[L - 1], c = L > 1 ? prev[L - 2] : -INFINITY;
+            const float* last = rowA + ((Tb - 1) & 1) * Lmax;
+            const float a = last[L - 1], c = L > 1 ? last[L - 2] : -INFINITY;
             const float m = fmaxf(a, c);
             ll = (m == -INFINITY) ? -INFINITY : m + logf(expf(a - m) + expf(c - m));
         } else {
@@ -704,50 +785,31 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     const int tz = finite ? Tb : 0;
     for (long long i = tid + (long long)tz * ldd; i < (long long)Tp * ldd; i += 256) stf<TD>(dlogits, (long long)b * Tp * ldd + i, 0.f);
     if (!finite || Tb == 0) return;
-    // ---- beta + occupancy
-    prev = buf0; cur = buf1;
+    // ---- occupancy: occ[t][c] = sum_{s: ext[s] = c} exp(alpha + beta - lp + nll), all (t, s) in parallel
+    for (int i = tid; i < Tb * V; i += 256) occ[i] = 0.f;
+    __syncthreads();   // also makes this block's alpha/beta global writes visible to its own threads
+    for (int i = tid; i < Tb * L; i += 256) {
+        const int t = i / L, s = i % L;
+        const float ab = aw[(long long)t * Lmax + s] + bw[(long long)t * Lmax + s];
+        if (ab > -INFINITY) atomicAdd(&occ[t * V + ext[s]], expf(ab - lp[(long long)t * V + ext[s]] + nll));
+    }
     __syncthreads();
-    for (int t = Tb - 1; t >= 0; --t) {
-        for (int c = tid; c < V; c += 256) occ[c] = 0.f;
-        for (int s = tid; s < L; s += 256) {
-            float v;
-            if (t == Tb - 1) {
-                v = (s >= L - 2) ? lp[(long long)t * V + ext[s]] : -INFINITY;
-            } else {
-                const float b0 = prev[s];
-                const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
-                const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != ext[s]) ? prev[s + 2] : -INFINITY;
-                v = log_add3(b0, b1, b2) + lp[(long long)t * V + ext[s]];
-            }
-            cur[s] = v;
-        }
-        __syncthreads();
-        for (int s = tid; s < L; s += 256) {
-            const float ab = aw[(long long)t * Lmax + s] + cur[s];
-            if (ab > -INFINITY) {
-                const float g = expf(ab - lp[(long long)t * V + ext[s]] + nll);  // posterior of state s at t
-                atomicAdd(&occ[ext[s]], g);
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < ldd; c += 256) {
-            const float v = (c < V) ? (expf(lp[(long long)t * V + c]) - occ[c]) * grad_scale : 0.f;
-            stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
-        }
-        __syncthreads();
-        float* tmp = prev; prev = cur; cur = tmp;
+    for (int i = tid; i < Tb * ldd; i += 256) {
+        const int t = i / ldd, c = i % ldd;
+        const float v = (c < V) ? (expf(lp[(long long)t * V + c]) - occ[t * V + c]) * grad_scale : 0.f;
+        stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
     }
 }
 
 int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int B, int Tp,
                int V, int S, int blank, int zero_infinity, float* loss, float* alpha_ws, void* dlogits, int d_dtype,
                int ldd, float grad_scale, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (2 * S + 1) + V + (2 * S + 1)) * sizeof(float);
-    NBCI_REQUIRE(lds <= 60000, NBCI_ESHAPE, "ctc: target too long for the LDS-resident recursion");
+    const size_t lds = (size_t)(5 * (2 * S + 1) + (size_t)Tp * V) * sizeof(float);
+    NBCI_REQUIRE(lds <= 64000, NBCI_ESHAPE, "ctc: frames x vocab + targets too large for the LDS-resident gradient pass");
     NBCI_REQUIRE(blank >= 0 && blank < V, NBCI_EINVAL, "ctc: blank id out of range");
     DISPATCH_DTYPE(d_dtype, TD,
                    hipLaunchKernelGGL((ctc_kernel<TD>), dim3(B), dim3(256), lds, s, preds, targets, in_lens, tgt_lens, Tp, V,
-                                      S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale));
+                                      S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale, B));
     return check_launch("ctc");
 }
 
@@ -827,13 +889,21 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
 // ------------------------------------------------------------------------------------------
 // fold the replicated small-vector accumulators into the flat gradient buffer and clear them
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fold_replicas_kernel(float* __restrict__ rep, long long stride, int nrep,
+__global__ __launch_bounds__(64) void fold_replicas_kernel(float* __restrict__ rep, long long stride, int nrep,
                                                             const int* __restrict__ flat_of, int cbegin, int cend,
                                                             float* __restrict__ grads) {
-    const int ci = cbegin + blockIdx.x * 256 + threadIdx.x;
+    const int ci = cbegin + blockIdx.x * 64 + threadIdx.x;
     if (ci >= cend) return;
     float s = 0.f;
-    for (int r = 0; r < nrep; ++r) { s += rep[(long long)r * stride + ci]; rep[(long long)r * stride + ci] = 0.f; }
+    if (nrep == 32) {  // all 32 loads in flight at once (the dependent-load loop was latency-bound)
+        float v[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v[r] = rep[(long long)r * stride + ci];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { s += v[r]; rep[(long long)r * stride + ci] = 0.f; }
+    } else {
+        for (int r = 0; r < nrep; ++r) { s += rep[(long long)r * stride + ci]; rep[(long long)r * stride + ci] = 0.f; }
+    }
     const int fo = flat_of[ci];
     if (fo >= 0) grads[fo] += s;
 }
@@ -841,7 +911,7 @@ __global__ __launch_bounds__(256) void fold_replicas_kernel(float* __restrict__ 
 int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat_of, int cbegin, int cend, float* grads,
                          hipStream_t s) {
     if (cend <= cbegin) return NBCI_OK;
-    hipLaunchKernelGGL(fold_replicas_kernel, dim3((cend - cbegin + 255) / 256), dim3(256), 0, s, rep, stride, nrep, flat_of, cbegin,
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((cend - cbegin + 63) / 64), dim3(64), 0, s, rep, stride, nrep, flat_of, cbegin,
                        cend, grads);
     return check_launch("fold_replicas");
 }

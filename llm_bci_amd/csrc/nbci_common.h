@@ -102,6 +102,10 @@ __device__ __forceinline__ float* rep_ptr(float* p, RepCfg rc, unsigned blk) {
     return rc.n > 1 ? p + (long long)(blk % (unsigned)rc.n) * rc.stride : p;
 }
 
+// optional fused tail of the LayerNorm backward: out = dropout(dx_new) in the GEMM operand dtype,
+// colsum += column sums of out (the bias gradient of the Linear that produced the residual branch)
+struct LnCast { void* out; int bf16; unsigned thr; float scale; uint32_t key; float* colsum; };
+
 // ---- wave64 reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -428,6 +428,16 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     float* rep = (float*)(ws + w.rep);
     const RepCfg rc{p.compact_total, NREP};
     auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };  // replica-0 slot of a 1-D param's grad
+    // The f32 gradient stream dx is consumed by GEMMs in the operand dtype: the LayerNorm backward that
+    // finalises dx also writes that (dropout-masked) copy into ws.dA and sums its columns (bias grad).
+    const bool need_cast = !(dt == NBCI_F32 && p_lay == 0.f && p_emb == 0.f);
+    auto cast_for = [&](int layer_below) -> LnCast {   // consumer = MLP backward of `layer_below`, or the embedder if < 0
+        if (!need_cast) return LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr};
+        const float pp = layer_below >= 0 ? p_lay : p_emb;
+        const uint32_t site = layer_below >= 0 ? 18 + 4 * layer_below : 3;
+        return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
+                      RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb)};
+    };
 
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
         if (seg == c.n_layers + 1) {
@@ -440,18 +450,17 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
-                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc));
+                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1)));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
             const LayerOff& lo = p.L[l];
             // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
-            const void* dm;  // d(down output) in the GEMM operand dtype; bias grad fused into the cast pass
-            if (dt == NBCI_F32 && p_lay == 0.f) {
+            const void* dm;  // d(down output) in the GEMM operand dtype (written by the previous LayerNorm backward)
+            if (!need_cast) {
                 dm = dx;
                 TRY(colsum_launch(dm, dt, H, M, H, RG(lo.dnb), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_lay, io->seed, 18 + 4 * l, RG(lo.dnb), s, rc));
                 dm = ws + w.dA;
             }
             TRY(wgrad(s, dt, H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
@@ -467,15 +476,16 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
-                                     (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc));
+                                     (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
+                                     dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
+                                                    : LnCast{ws + w.dA, 1, 0u, 1.f, 0u, RG(lo.ob)}));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
             if (dt == NBCI_F32) {
                 dxc = dx;
                 TRY(colsum_launch(dx, NBCI_F32, H, M, H, RG(lo.ob), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, 0.f, 0, 0, RG(lo.ob), s, rc));
-                dxc = ws + w.dA;
+                dxc = ws + w.dA;   // bf16 copy + out_proj bias grad came out of the LayerNorm backward above
             }
             TRY(wgrad(s, dt, H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
             {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
@@ -532,16 +542,15 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
-                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc));
+                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1)));
         } else {
             // ---- embedder backward (ndt1.py:160-203)
             const int KS = c.stack_size * D;
             const void* dx0;
-            if (dt == NBCI_F32 && p_emb == 0.f) {
+            if (!need_cast) {
                 dx0 = dx;
                 TRY(colsum_launch(dx0, dt, H, M, H, RG(p.stkb), s, rc));
             } else {
-                TRY(dropcast2d_launch(dx, ws + w.dA, dt, M, H, p_emb, io->seed, 3, RG(p.stkb), s, rc));
                 dx0 = ws + w.dA;
             }
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));

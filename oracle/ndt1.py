@@ -190,7 +190,7 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
     xs = smooth(spikes, gaussian_taps(cfg["smooth_sd"])) if cfg["smooth_sd"] is not None else spikes.copy()
     if train and cfg["noise"]:
         if cfg["white_noise_sd"] is not None:
-            xs = xs + f(cfg["white_noise_sd"]) * R.normal(seed, R.SITE_NOISE_WHITE, B * T * N).reshape(B, T, N).astype(f)
+            xs = xs + f(cfg["white_noise_sd"]) * R.white_noise(seed, B, T, N).astype(f)
         if cfg["constant_offset_sd"] is not None:
             xs = xs + f(cfg["constant_offset_sd"]) * R.normal(seed, R.SITE_NOISE_OFFSET, B * N).reshape(B, 1, N).astype(f)
     c["xs"] = xs

@@ -65,8 +65,26 @@ def normal(seed, site, n):
     return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)).astype(np.float32)
 
 
-# dropout / noise call sites of one NDT1 train step (shared numbering with csrc/ndt1.hip)
 SITE_NOISE_WHITE = 1
+
+
+def white_noise(seed, B, T, N):
+    """(B,T,N) standard normals as the smoothing kernel draws them: bins (t, t+1) of one (batch, channel)
+    share one Box-Muller transform (cos -> even bin, sin -> odd bin); pair index =
+    (b*N + n) * ceil(T/2) + t//2, site 1."""
+    npair = (T + 1) // 2
+    idx = np.arange(B * N * npair, dtype=np.uint32)
+    a = rng_u32(seed, SITE_NOISE_WHITE, idx)
+    b = rng_u32((int(seed) ^ 0x5BD1E995) & 0xFFFFFFFF, (SITE_NOISE_WHITE + 0x1000193) & 0xFFFFFFFF, idx)
+    u1 = ((a >> U32(8)).astype(np.float32) + np.float32(1)) * np.float32(1.0 / 16777216.0)
+    u2 = ((b >> U32(8)).astype(np.float32) + np.float32(1)) * np.float32(1.0 / 16777216.0)
+    rad = np.sqrt(np.float32(-2.0) * np.log(u1))
+    ang = np.float32(6.283185307179586) * u2
+    z = np.stack([rad * np.cos(ang), rad * np.sin(ang)], -1).reshape(B, N, 2 * npair)[:, :, :T]
+    return np.ascontiguousarray(z.transpose(0, 2, 1)).astype(np.float32)
+
+
+# dropout / noise call sites of one NDT1 train step (shared numbering with csrc/ndt1.hip)
 SITE_NOISE_OFFSET = 2
 SITE_EMBED_DROP = 3
 

@@ -146,7 +146,7 @@ def test_smooth_noise_matches_oracle():
     np.testing.assert_allclose(out.cpu().numpy(), O.smooth(x, O.gaussian_taps(2)), atol=2e-6)
     check(l.nbci_smooth_noise(vp(xd), vp(out), 0, B, T, N, vp(tapd), len(taps), C.c_float(1.0), C.c_float(0.2), 5, st()), "smooth")
     torch.cuda.synchronize()
-    ref = O.smooth(x, O.gaussian_taps(2)) + R.normal(5, 1, B * T * N).reshape(B, T, N) + 0.2 * R.normal(5, 2, B * N).reshape(B, 1, N)
+    ref = O.smooth(x, O.gaussian_taps(2)) + R.white_noise(5, B, T, N) + 0.2 * R.normal(5, 2, B * N).reshape(B, 1, N)
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-4)
     noise = out.cpu().numpy() - O.smooth(x, O.gaussian_taps(2))
     assert abs(noise.std() - np.sqrt(1 + 0.04)) < 0.05 and abs(noise.mean()) < 0.05
