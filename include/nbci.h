@@ -109,6 +109,9 @@ typedef struct nbci_gemm_desc {
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);
+/* n <= 6 independent GEMMs of one operand layout in ONE launch (a layer's weight gradients: few output
+ * tiles each, K = all tokens). Problems that do not qualify run one launch each. */
+int nbci_gemm_grouped(const nbci_gemm_desc* descs, int32_t n, nbci_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------

@@ -17,6 +17,9 @@ int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream) {
     return nbci::gemm_launch(*d, (hipStream_t)stream);
 }
 
+int nbci_gemm_grouped(const nbci_gemm_desc* descs, int32_t n, nbci_stream_t stream) {
+    return nbci::gemm_grouped_launch(descs, n, (hipStream_t)stream);
+}
 int nbci_smooth_noise(const float* spikes, void* out, int32_t out_dtype, int32_t B, int32_t T, int32_t N, const float* taps,
                       int32_t ntaps, float white_sd, float offset_sd, uint32_t seed, nbci_stream_t stream) {
     return nbci::smooth_noise_launch(spikes, out, out_dtype, B, T, N, taps, ntaps, white_sd, offset_sd, seed, (hipStream_t)stream);

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
 // ---- host side ---------------------------------------------------------------------------
 bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k);
 int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
+int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream);
 static bool operand_vec_ok(const nbci_operand& o, int E, size_t esz) {
     if (((uintptr_t)o.ptr) % 16) return false;
     if (o.ld % E) return false;
@@ -138,7 +139,7 @@ static int launch_layout(const GemmK& k, bool ak, bool bk, dim3 grid, hipStream_
     return launch_inst<T, false, false>(k, grid, s);
 }
 
-int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
+static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     NBCI_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, NBCI_ESHAPE, "gemm: M,N,K must be positive");
     NBCI_REQUIRE(d.A.ptr && d.B.ptr && d.C, NBCI_EINVAL, "gemm: null operand");
     NBCI_REQUIRE(d.in_dtype == NBCI_F32 || d.in_dtype == NBCI_BF16, NBCI_EINVAL, "gemm: bad in_dtype");
@@ -154,7 +155,6 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     const size_t csz = d.c_dtype == NBCI_BF16 ? 2 : 4;
     NBCI_REQUIRE(((uintptr_t)d.C) % csz == 0, NBCI_EALIGN, "gemm: C misaligned");
 
-    GemmK k;
     k.M = d.M; k.N = d.N; k.K = d.K;
     const int E = d.in_dtype == NBCI_BF16 ? 8 : 4;
     const int BK = d.in_dtype == NBCI_BF16 ? 64 : 16;
@@ -186,11 +186,39 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     if (d.bias) cvec = cvec && (((uintptr_t)d.bias) % 16 == 0);
     if (d.residual) cvec = cvec && (d.ldr % 4 == 0) && (((uintptr_t)d.residual) % 16 == 0);
     k.cvec = cvec ? 1 : 0;
+    return NBCI_OK;
+}
 
+int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
+    GemmK k;
+    int rc = build_gemmk(d, k);
+    if (rc != NBCI_OK) return rc;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const int splitk = d.splitk > 1 ? d.splitk : 1;
     if (d.in_dtype == NBCI_BF16 && glds_eligible(d, k)) return gemm_glds_launch(d, k, stream);
     dim3 grid(k.tiles_m * k.tiles_n * (splitk > 1 ? splitk : 1), splitk > 1 ? 1 : batch);
     if (d.in_dtype == NBCI_BF16) return launch_layout<bf16_t>(k, d.A.kmajor != 0, d.B.kmajor != 0, grid, stream);
     return launch_layout<float>(k, d.A.kmajor != 0, d.B.kmajor != 0, grid, stream);
+}
+
+// Up to 6 independent bf16 GEMMs of one layout in one launch; falls back to one launch each when a
+// problem does not qualify for the direct-to-LDS kernel.
+int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream) {
+    NBCI_REQUIRE(descs && n >= 1, NBCI_EINVAL, "gemm grouped: no problems");
+    GemmK ks[6];
+    bool ok = n <= 6;
+    for (int i = 0; i < n && ok; ++i) {
+        int rc = build_gemmk(descs[i], ks[i]);
+        if (rc != NBCI_OK) return rc;
+        ok = descs[i].in_dtype == NBCI_BF16 && ks[i].splitk == 1 && descs[i].batch <= 1 && glds_eligible(descs[i], ks[i]) &&
+             (descs[i].A.kmajor != 0) == (descs[0].A.kmajor != 0) && (descs[i].B.kmajor != 0) == (descs[0].B.kmajor != 0);
+    }
+    if (ok) return gemm_group_launch(descs, ks, n, stream);
+    for (int i = 0; i < n; ++i) {
+        int rc = gemm_launch(descs[i], stream);
+        if (rc != NBCI_OK) return rc;
+    }
+    return NBCI_OK;
 }
 
 }  // namespace nbci
@@ -220,6 +248,20 @@ int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream) {
 }
 
 // out[kind] = {total ms, total flops, launches} for kind = dtype*4 + A.kmajor*2 + B.kmajor (8 kinds)
+int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream) {
+    if (!g_prof_on) return gemm_grouped_launch(descs, n, stream);
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return fail(NBCI_EHIP, "event create");
+    r.flops = 0.0;
+    for (int i = 0; i < n; ++i) r.flops += 2.0 * descs[i].M * (double)descs[i].N * descs[i].K;
+    r.kind = (descs[0].in_dtype == NBCI_BF16 ? 4 : 0) + (descs[0].A.kmajor ? 2 : 0) + (descs[0].B.kmajor ? 1 : 0);
+    (void)hipEventRecord(r.a, stream);
+    const int rc = gemm_grouped_launch(descs, n, stream);
+    (void)hipEventRecord(r.b, stream);
+    g_prof.push_back(r);
+    return rc;
+}
+
 int gemm_profile_collect(double* out24) {
     for (int i = 0; i < 24; ++i) out24[i] = 0.0;
     for (auto& r : g_prof) {

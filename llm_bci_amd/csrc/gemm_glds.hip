@@ -91,8 +91,7 @@ __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x, const int block_y, char* smem) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     static_assert(BN == 128, "B tile is always 128 wide");
     static_assert(AK || BM == 128, "row-major-in-k A needs 256-byte tile rows");
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
     const int nitems = nwg * (d.splitk > 1 ? d.splitk : 1);
     int item;
     {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nitems >> 3, r = nitems & 7;
+        const int orig = block_x, xcd = orig & 7, q = nitems >> 3, r = nitems & 7;
         item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int wg = item % nwg;
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int z = d.splitk > 1 ? zsplit : (int)blockIdx.y;
+    const int z = d.splitk > 1 ? zsplit : block_y;
     const int ktiles = (d.K + 63) / 64;
     int kt_begin = 0, kt_end = ktiles;
     OperandK A = d.A, B = d.B;
@@ -193,6 +192,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
     gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
 }
 
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_glds_body<AK, BKM, WM, WN, MI, NI>(d, blockIdx.x, blockIdx.y, smem);
+}
+
+// Several independent GEMMs of one layout in ONE launch (block ranges by prefix sums). Used for the
+// weight gradients of a layer: each is only 64-192 output tiles with K = all tokens, so alone it
+// either leaves CUs idle or needs split-K (atomics at ~1.3 TB/s); together they fill the chip with
+// full-K tiles, no atomics, deterministic sums.
+constexpr int GEMM_GROUP_MAX = 6;
+struct GemmGroup {
+    int n;
+    int start[GEMM_GROUP_MAX + 1];
+    GemmK sub[GEMM_GROUP_MAX];
+};
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_group_kernel(GemmGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_GROUP_MAX; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.start[i]) gi = i;
+    gemm_glds_body<AK, BKM, 2, 2, 4, 4>(grp.sub[gi], blockIdx.x - grp.start[gi], 0, smem);
+}
+
 // ---- host --------------------------------------------------------------------------------------
 static bool glds_operand_ok(const nbci_operand& o, int R) {
     if (((uintptr_t)o.ptr) % 16) return false;
@@ -235,6 +261,32 @@ static int launch_glds_layout(const GemmK& k, bool ak, bool bk, dim3 grid, hipSt
         if (bk) return launch_glds<true, true, WM, WN, MI, NI>(k, grid, s);
         return launch_glds<true, false, WM, WN, MI, NI>(k, grid, s);
     }
+}
+
+int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream) {
+    NBCI_REQUIRE(n >= 1 && n <= GEMM_GROUP_MAX, NBCI_EINVAL, "gemm group: 1..6 problems");
+    GemmGroup grp;
+    grp.n = n;
+    grp.start[0] = 0;
+    const bool ak = descs[0].A.kmajor != 0, bk = descs[0].B.kmajor != 0;
+    for (int i = 0; i < n; ++i) {
+        NBCI_REQUIRE((descs[i].A.kmajor != 0) == ak && (descs[i].B.kmajor != 0) == bk, NBCI_EINVAL, "gemm group: mixed layouts");
+        NBCI_REQUIRE(ks[i].splitk == 1 && (descs[i].batch <= 1), NBCI_EINVAL, "gemm group: no split-K / batch");
+        NBCI_REQUIRE(glds_eligible(descs[i], ks[i]), NBCI_EALIGN, "gemm group: operand not eligible for the direct-to-LDS path");
+        grp.sub[i] = ks[i];
+        grp.sub[i].tiles_m = (descs[i].M + 127) / 128;
+        grp.start[i + 1] = grp.start[i] + grp.sub[i].tiles_m * grp.sub[i].tiles_n;
+    }
+    for (int i = n; i < GEMM_GROUP_MAX; ++i) grp.start[i + 1] = grp.start[n];
+    dim3 grid(grp.start[n]);
+    constexpr int lds = 65536;
+    if (ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, grp);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<false, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
+    else hipLaunchKernelGGL((gemm_glds_group_kernel<false, false>), grid, dim3(GEMM_THREADS), lds, stream, grp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm group launch: ") + hipGetErrorString(e));
+    return NBCI_OK;
 }
 
 int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {

@@ -8,6 +8,8 @@ namespace nbci {
 
 int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream);
 int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream);  // = gemm_launch unless profiling is on
+int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream);        // <= 6 problems, one launch
+int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream);
 void gemm_profile_enable(bool on);
 int gemm_profile_collect(double* out24);
 

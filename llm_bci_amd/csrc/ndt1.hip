@@ -136,7 +136,7 @@ struct WS {
     std::vector<LayerWS> L;
     size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
-    size_t dx, dtmp, dA, dB, dqkv, dS, dwin, dpre, rep;
+    size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
     size_t bytes;
     int Tp, M, ldS, ldP, vpad;
 };
@@ -192,7 +192,9 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.dx = bump(cur, M * H * 4);
     w.dtmp = bump(cur, M * H * 4);
     w.dA = bump(cur, M * H * es);
+    w.dA2 = bump(cur, M * H * es);
     w.dB = bump(cur, M * std::max(H, I) * es);
+    w.dB2 = bump(cur, M * H * es);
     w.dqkv = bump(cur, M * 3 * H * es);
     w.dS = bump(cur, nP * es);
     w.dwin = bump(cur, M * (size_t)c.stack_size * D * es);
@@ -240,6 +242,28 @@ static int wgrad(hipStream_t s, int dtype, int M, int N, int K, nbci_operand A, 
     if (d.splitk == 1) d.beta = 1.f;
     return gemm_launch_timed(d, s);
 }
+
+// A layer's weight gradients are queued and issued as ONE grouped launch (full-K tiles, beta = 1, no
+// split-K atomics) once all their operands exist; in f32 mode they run one by one as before.
+struct WgradQueue {
+    nbci_gemm_desc d[6];
+    int n = 0;
+    int dtype;
+    hipStream_t s;
+    int push(int M, int N, int K, nbci_operand A, nbci_operand B, float* dW, int64_t ldw) {
+        if (dtype != NBCI_BF16 || n >= 6) return wgrad(s, dtype, M, N, K, A, B, dW, ldw);
+        d[n] = gd(M, N, K, dtype, A, B, dW, ldw, NBCI_F32);
+        d[n].beta = 1.f;
+        ++n;
+        return NBCI_OK;
+    }
+    int flush() {
+        if (n == 0) return NBCI_OK;
+        const int rc = gemm_grouped_launch_timed(d, n, s);
+        n = 0;
+        return rc;
+    }
+};
 
 #define TRY(x)                    \
     do {                          \
@@ -455,6 +479,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
             const LayerOff& lo = p.L[l];
+            WgradQueue wq; wq.dtype = dt; wq.s = s;
             // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
             const void* dm;  // d(down output) in the GEMM operand dtype (written by the previous LayerNorm backward)
             if (!need_cast) {
@@ -463,14 +488,14 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             } else {
                 dm = ws + w.dA;
             }
-            TRY(wgrad(s, dt, H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
+            TRY(wq.push(H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
             {   // du = (dm W_down) * act'(u)
                 nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
                 d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
                 d.colsum = RG(lo.upb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;  // up_proj bias grad = column sums of du
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(wgrad(s, dt, I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
+            TRY(wq.push(I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
             {
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
                 TRY(gemm_launch_timed(d, s));
@@ -478,18 +503,18 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
                                      (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
                                      dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
-                                                    : LnCast{ws + w.dA, 1, 0u, 1.f, 0u, RG(lo.ob)}));
+                                                    : LnCast{ws + w.dA2, 1, 0u, 1.f, 0u, RG(lo.ob)}));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
             if (dt == NBCI_F32) {
                 dxc = dx;
                 TRY(colsum_launch(dx, NBCI_F32, H, M, H, RG(lo.ob), s, rc));
             } else {
-                dxc = ws + w.dA;   // bf16 copy + out_proj bias grad came out of the LayerNorm backward above
+                dxc = ws + w.dA2;  // bf16 copy + out_proj bias grad came out of the LayerNorm backward above
             }
-            TRY(wgrad(s, dt, H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
+            TRY(wq.push(H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
             {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
-                nbci_gemm_desc d = gd(M, H, H, dt, op(dxc, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dB, H, dt);
+                nbci_gemm_desc d = gd(M, H, H, dt, op(dxc, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dB2, H, dt);
                 d.drop_p = p_lay; d.seed = io->seed; d.site = 17 + 4 * l;
                 TRY(gemm_launch_timed(d, s));
             }
@@ -497,19 +522,19 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
             const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
-                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + w.dB, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
+                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
                                     nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
             } else {
                 {   // dPd = da v^T   (f32, reuses the score buffer)
-                    nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB, es, 0, H, 1, 0, 0, az1, hd),
+                    nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB2, es, 0, H, 1, 0, 0, az1, hd),
                                           op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
                     d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * Tp * w.ldS; d.czs2 = (int64_t)Tp * w.ldS;
                     TRY(gemm_launch_timed(d, s));
                 }
                 {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
                     nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
-                                          op(ws + w.dB, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
+                                          op(ws + w.dB2, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
                     d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
                     if (!c.use_rope) d.colsum = RG(lo.vb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
                     TRY(gemm_launch_timed(d, s));
@@ -535,7 +560,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
             if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
                 TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
-            TRY(wgrad(s, dt, 3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
+            TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
+            TRY(wq.flush());   // all four operand pairs exist now; the LayerNorm backward below overwrites dA
             {
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
                                       NBCI_F32);
