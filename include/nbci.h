@@ -101,7 +101,8 @@ typedef struct nbci_gemm_desc {
     int32_t residual_first;       /* 1: residual is added BEFORE act/dropout */
     const void* gate;             /* optional [M][ldg] in in_dtype: result *= act'(gate) (GELU/softsign backward) */
     int64_t ldg;
-    int32_t gate_act;
+    int32_t gate_act;             /* < 0: gate already holds act' (see c2_grad): plain multiply */
+    int32_t c2_grad;              /* 1: C2 receives act'(pre-activation) instead of the pre-activation */
     float* colsum;                /* optional f32 [N]: colsum[n] += sum_m C[m][n] of the STORED values (bias
                                      gradient fused into the GEMM that produces the activation gradient) */
     int64_t colsum_rep_stride;    /* colsum replicas (to spread same-address atomics): replica r at colsum + r*stride */

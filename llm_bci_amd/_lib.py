@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (keep this import BEFORE loading libnbci.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnbci.so")
+LIB_PATH = os.environ.get("NBCI_LIB") or os.path.join(_HERE, "csrc", "libnbci.so")  # NBCI_LIB: A/B a variant build
 
 NBCI_F32, NBCI_BF16 = 0, 1
 ACT = {"identity": 0, None: 0, "none": 0, "softsign": 1, "gelu": 2, "relu": 3, "tanh": 4}
@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
                 ("act", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32),
                 ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
-                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32),
+                ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32), ("c2_grad", C.c_int32),
                 ("colsum", C.c_void_p), ("colsum_rep_stride", C.c_int64), ("colsum_nrep", C.c_int32)]
 
 

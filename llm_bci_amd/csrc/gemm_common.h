@@ -69,6 +69,7 @@ struct GemmK {
     int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
     const void* gate; long long ldg; int gate_act;  // v *= act'(gate[m][n]) (gate in the input dtype)
     int gate_bf16;
+    int c2_grad;   // C2 receives act'(pre-activation) instead of the pre-activation
     int cvec;  // vector C/residual accesses legal
 };
 
@@ -273,24 +274,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
                     for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.bias[n + e];
                 }
             }
+            float dact[4] = {1.f, 1.f, 1.f, 1.f};
+            bool act_done = false;
+            if (d.C2 && d.c2_grad) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(d.act, v[e], y, dact[e]); v[e] = y; }
+                act_done = true;
+            }
             if (d.C2) {
+                const float* src = d.c2_grad ? dact : v;
                 if (d.c_bf16) {
                     bf16_t* c2 = (bf16_t*)d.C2 + cidx;
-                    if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c2 = o; }
-                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(v[e]); }
+                    if (full) { bf16x4 o = {f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3])}; *(bf16x4*)c2 = o; }
+                    else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(src[e]); }
                 } else {
                     float* c2 = (float*)d.C2 + cidx;
-                    if (full) *(float4*)c2 = make_float4(v[0], v[1], v[2], v[3]);
-                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = v[e]; }
+                    if (full) *(float4*)c2 = make_float4(src[0], src[1], src[2], src[3]);
+                    else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = src[e]; }
                 }
             }
             if (d.residual && d.residual_first) {
                 const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
                 const float* r = d.residual + rr * d.ldr + n;
                 if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+                else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
             }
-            if (d.act != ACT_NONE) {
+            if (d.act != ACT_NONE && !act_done) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
             }
@@ -300,7 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
                 for (int e = 0; e < 4; ++e) {
                     if (n + e < d.N) {
                         const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
-                        v[e] *= act_bwd(d.gate_act, gv);
+                        v[e] *= (d.gate_act < 0) ? gv : act_bwd(d.gate_act, gv);   // gate_act < 0: gate already holds act'
                     }
                 }
             }
@@ -319,7 +334,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
                 const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
                 const float* r = d.residual + rr * d.ldr + n;
                 if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+                else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
             }
             if (d.colsum) {
 #pragma unroll
@@ -328,15 +345,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
             if (d.c_bf16) {
                 bf16_t* c = (bf16_t*)d.C + cidx;
                 if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
-                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
+                else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
             } else {
                 float* c = (float*)d.C + cidx;
                 if (d.beta != 0.f) {
                     if (full) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
-                    else { for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
+                    else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
                 }
                 if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                else { for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
+                else {
+_Pragma("unroll")
+                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
             }
         }
     }

@@ -15,6 +15,8 @@
 // Tile height is a template parameter (BM = 16*MI*WM): for the token-major GEMMs of the train step
 // (M = B*T' = 9152) BM = 144 gives 64 x 8 = 512 tiles = exactly two per CU, where 128 x 128 tiles
 // need a second, 12 %-full round.
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 namespace nbci {
@@ -22,9 +24,9 @@ namespace nbci {
 typedef __attribute__((address_space(1))) void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 
-template <bool KMAJOR, int NPIECES>
+template <bool KMAJOR, int NPIECES, int NW = 4>
 struct GldsOperand {
-    static constexpr int PER_WAVE = (NPIECES + 3) / 4;
+    static constexpr int PER_WAVE = (NPIECES + NW - 1) / NW;
     const bf16_t* base;        // operand base (batch offset applied)
     long long off[PER_WAVE];   // per-piece element offset of this lane's chunk at k-tile 0
     long long step;            // element step per K tile (kmajor: 64; else 64 * ld), 0 if recomputed
@@ -33,12 +35,12 @@ struct GldsOperand {
 };
 
 // per-lane source offsets for the pieces this wave stages
-template <bool KMAJOR, int NPIECES>
-__device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES>& g, const OperandK& o, int row0, int R, int w, int lane) {
+template <bool KMAJOR, int NPIECES, int NW = 4>
+__device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, int row0, int R, int w, int lane) {
     g.base = (const bf16_t*)o.ptr;
 #pragma unroll
-    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES>::PER_WAVE; ++i) {
-        const int p = w + 4 * i;
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
+        const int p = w + NW * i;
         if constexpr (KMAJOR) {
             const int rl = 8 * p + (lane >> 3);
             int row = row0 + rl;
@@ -58,11 +60,11 @@ __device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES>& g, cons
     g.step = KMAJOR ? 64 : 64 * o.ld;
 }
 
-template <bool KMAJOR, int NPIECES>
-__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES>& g, const OperandK& o, char* lds, int kt, int w) {
+template <bool KMAJOR, int NPIECES, int NW = 4>
+__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
 #pragma unroll
-    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES>::PER_WAVE; ++i) {
-        const int p = w + 4 * i;
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
+        const int p = w + NW * i;
         if (p < NPIECES) {
             const bf16_t* src;
             if (!KMAJOR && o.rpb > 0) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
@@ -219,6 +221,89 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_group_kernel(GemmGroup
     gemm_glds_body<AK, BKM, 2, 2, 4, 4>(grp.sub[gi], blockIdx.x - grp.start[gi], 0, smem);
 }
 
+
+// ---- 3-stage variant: 288 x 128 tile, 8 waves (2 x 4, each 144 x 32), two K tiles in flight ------------
+// The 2-stage kernel keeps one 35 KB tile in flight per workgroup and tops out near 30 GB/s of L2->LDS
+// traffic per CU; at K = 1024 that, not the MFMA pipe, sets the pace. Here one workgroup per CU owns a
+// 288-row tile (88 FLOP/B instead of 68), stages tile t+2 while computing tile t, and waits with a
+// COUNTED s_waitcnt vmcnt (never 0 inside the loop) + raw s_barrier so the LDS-DMA stays in flight
+// across barriers. M = 9152 gives 32 x 8 = 256 tiles: exactly one per CU.
+constexpr int G3_BM = 288, G3_STAGE = G3_BM * 128 + 16384, G3_THREADS = 512;
+
+template <bool BKM>
+__global__ __launch_bounds__(G3_THREADS) void gemm_glds3_kernel(GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPA = G3_BM / 8, NPB = 16;          // 36 A pieces (waves 0-3 stage 5, waves 4-7 stage 4), 16 B pieces (2 each)
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int nwg = d.tiles_m * d.tiles_n;
+    int wg;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int tm, tn;
+    {
+        const int per_group = 8 * d.tiles_n;
+        const int grp = wg / per_group, in_grp = wg % per_group;
+        const int first_m = grp * 8;
+        const int gsize = min(8, d.tiles_m - first_m);
+        tm = first_m + in_grp % gsize;
+        tn = in_grp / gsize;
+    }
+    const int m0 = tm * G3_BM, n0 = tn * 128;
+    OperandK A = d.A, B = d.B;
+    const int z = blockIdx.y;
+    const int z1 = z / d.zdiv, z2 = z % d.zdiv;
+    A.ptr = (const bf16_t*)A.ptr + z1 * d.azs1 + z2 * d.azs2;
+    B.ptr = (const bf16_t*)B.ptr + z1 * d.bzs1 + z2 * d.bzs2;
+    const long long coff = z1 * d.czs1 + z2 * d.czs2;
+    const int nt = d.K / 64;
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    GldsOperand<true, NPA, 8> ga;
+    GldsOperand<BKM, NPB, 8> gb;
+    glds_setup<true, NPA, 8>(ga, A, m0, d.M, w, lane);
+    glds_setup<BKM, NPB, 8>(gb, B, n0, d.N, w, lane);
+
+    glds_stage<true, NPA, 8>(ga, A, smem, 0, w);
+    glds_stage<BKM, NPB, 8>(gb, B, smem + G3_BM * 128, 0, w);
+    if (nt > 1) {
+        glds_stage<true, NPA, 8>(ga, A, smem + G3_STAGE, 1, w);
+        glds_stage<BKM, NPB, 8>(gb, B, smem + G3_STAGE + G3_BM * 128, 1, w);
+    }
+    int cur = 0, nxt2 = 2;   // stage holding tile kt ; stage that tile kt+2 goes to
+    for (int kt = 0; kt < nt; ++kt) {
+        // tile kt has landed once at most the loads of tile kt+1 (7 per wave 0-3, 6 per wave 4-7) remain
+        if (kt + 1 < nt) {
+            if (w < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();          // all pieces of tile kt visible; everyone is done reading stage nxt2
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nt) {
+            char* nx = smem + nxt2 * G3_STAGE;
+            glds_stage<true, NPA, 8>(ga, A, nx, kt + 2, w);
+            glds_stage<BKM, NPB, 8>(gb, B, nx + G3_BM * 128, kt + 2, w);
+        }
+        const char* sA = smem + cur * G3_STAGE;
+        compute_tile_g<true, BKM, 9, 2>(sA, sA + G3_BM * 128, acc, wm * 144, wn * 32, lane);
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    }
+    __syncthreads();   // (epilogue may reuse LDS)
+    gemm_epilogue<9, 2>(d, acc, m0 + wm * 144, n0 + wn * 32, coff, lane, w, smem);
+}
+
 // ---- host --------------------------------------------------------------------------------------
 static bool glds_operand_ok(const nbci_operand& o, int R) {
     if (((uintptr_t)o.ptr) % 16) return false;
@@ -296,11 +381,16 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     // whole K tiles and no split-K.
     int bm = 128;
     if (d.A.kmajor && d.K % 64 == 0 && splitk == 1) {
-        long best = -1;
-        const int cands[2] = {128, 144};  // (160 / 192 rows spill accumulators to scratch with hipcc 7.2: not offered)
+        // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel
+        // runs one workgroup per CU (rounds of 256 tiles) but streams ~1.5x faster per row.
+        double best = -1;
+        const int cands[3] = {128, 144, 288};  // (160 / 192 rows spill accumulators to scratch with hipcc 7.2: not offered)
+        static const bool g3_off = [] { const char* e = getenv("NBCI_GEMM3"); return !(e && e[0] == '1'); }();  // opt-in: measured no faster than the 2-stage kernel
         for (int c : cands) {
+            if (c == 288 && (g3_off || d.K < 192)) continue;
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
-            const long cost = ((tiles + 511) / 512) * c;
+            if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
+            const double cost = c == 288 ? (double)((tiles + 255) / 256) * c / 2.0 / 1.5 : (double)((tiles + 511) / 512) * c;
             if (best < 0 || cost < best) { best = cost; bm = c; }
         }
     }
@@ -309,6 +399,21 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
     switch (bm) {
         case 144: return launch_glds_layout<1, 4, 9, 2>(k, ak, bk, grid, stream);
+        case 288: {
+            constexpr int lds = 3 * G3_STAGE;
+            static bool attr = false;
+            if (!attr) {
+                hipError_t e1 = hipFuncSetAttribute((const void*)gemm_glds3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipError_t e2 = hipFuncSetAttribute((const void*)gemm_glds3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e1 != hipSuccess || e2 != hipSuccess) return fail(NBCI_EHIP, "gemm_glds3: LDS attribute");
+                attr = true;
+            }
+            if (bk) hipLaunchKernelGGL((gemm_glds3_kernel<true>), grid, dim3(G3_THREADS), lds, stream, k);
+            else hipLaunchKernelGGL((gemm_glds3_kernel<false>), grid, dim3(G3_THREADS), lds, stream, k);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds3 launch: ") + hipGetErrorString(e));
+            return NBCI_OK;
+        }
         default: return launch_glds_layout<2, 2, 4, 4>(k, ak, bk, grid, stream);
     }
 }

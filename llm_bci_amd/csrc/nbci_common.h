@@ -140,6 +140,24 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
         default: return x;
     }
 }
+__device__ __forceinline__ float act_bwd(int act, float x);
+// activation and its derivative in one go (shares the erf / exp of the GELU): the forward GEMM can then
+// store act'(pre) instead of pre, and the backward gate is a plain multiply
+__device__ __forceinline__ void act_fwd_bwd(int act, float x, float& y, float& dy) {
+    if (act == ACT_GELU) {
+        const float z = x * 0.70710678118654752f, az = fabsf(z);
+        const float t = __frcp_rn(1.0f + 0.3275911f * az);
+        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float ex = __expf(-az * az);                 // = exp(-x^2 / 2)
+        const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * ex, x));
+        y = x * cdf;
+        dy = cdf + x * 0.3989422804014327f * ex;
+    } else {
+        y = act_fwd(act, x);
+        dy = act_bwd(act, x);
+    }
+}
+
 // derivative wrt the pre-activation x
 __device__ __forceinline__ float act_bwd(int act, float x) {
     switch (act) {

@@ -393,7 +393,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
                                  (float*)(ws + lw.rstd2), M, H, s));
         {
             nbci_gemm_desc d = gd(M, I, H, dt, op(ws + lw.h2, es, 0, H, 1), op(x.W(lo.upw), es, 0, H, 1), ws + lw.g, I, dt);
-            d.bias = params + lo.upb; d.act = c.mlp_act; d.C2 = ws + lw.u;
+            d.bias = params + lo.upb; d.act = c.mlp_act; d.C2 = ws + lw.u; d.c2_grad = 1;   // lw.u holds act'(u)
             TRY(gemm_launch_timed(d, s));
         }
         {
@@ -491,7 +491,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(wq.push(H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
             {   // du = (dm W_down) * act'(u)
                 nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
-                d.gate = ws + lw.u; d.ldg = I; d.gate_act = c.mlp_act;
+                d.gate = ws + lw.u; d.ldg = I; d.gate_act = -1;   // lw.u already holds act'(u) (stored by the forward up_proj GEMM)
                 d.colsum = RG(lo.upb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;  // up_proj bias grad = column sums of du
                 TRY(gemm_launch_timed(d, s));
             }

@@ -222,3 +222,46 @@ def test_big_random_tolerance(dtype):
     ref = xd.double().cpu() @ wd.double().cpu().t()
     err = (out.double().cpu() - ref).abs().max().item()
     assert err < (1e-3 if dtype == torch.float32 else 1e-2), err
+
+
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("shape", [(9152, 1024, 1024), (9000, 640, 192), (7000, 1024, 256)])
+def test_three_stage_288_tile_kernel_exact(bk, shape):
+    """shapes that select the 3-stage 288 x 128 kernel (counted vmcnt pipeline): exact integer data,
+    repeated 3 times to catch staging races."""
+    ops = _ops()
+    M, N, K = shape
+    a = _ints((M, K), lo=-2, hi=3, seed=11)
+    b = _ints((N, K), lo=-2, hi=3, seed=12)
+    ad = a.to(DEV, torch.bfloat16)
+    bd = (b if bk else b.t().contiguous()).to(DEV, torch.bfloat16)
+    ref = (a.double() @ b.double().t())
+    for _ in range(3):
+        out = torch.zeros(M, N, device=DEV)
+        ops.gemm(M, N, K, ops.operand(ad, K, True), ops.operand(bd, bd.stride(0), bk), out, N, in_dtype=ops.NBCI_BF16,
+                 c_dtype=ops.NBCI_F32)
+        torch.cuda.synchronize()
+        assert torch.equal(out.double().cpu(), ref)
+
+
+def test_grouped_gemm_matches_individual():
+    ops = _ops()
+    import ctypes as C
+    from llm_bci_amd._lib import GemmDesc, check, lib
+    K = 1000
+    probs = [(256, 128), (128, 384), (130, 128)]
+    descs = (GemmDesc * len(probs))()
+    keep, refs, outs = [], [], []
+    for i, (M, N) in enumerate(probs):
+        a = _ints((K, M), lo=-2, hi=3, seed=20 + i); b = _ints((K, N), lo=-2, hi=3, seed=30 + i)
+        ad, bd = a.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16)
+        out = torch.ones(M, N, device=DEV)
+        d = descs[i]
+        d.M, d.N, d.K, d.in_dtype = M, N, K, ops.NBCI_BF16
+        d.A, d.B = ops.operand(ad, M, False), ops.operand(bd, N, False)
+        d.C, d.ldc, d.c_dtype, d.batch, d.zdiv, d.splitk, d.alpha, d.beta = out.data_ptr(), N, ops.NBCI_F32, 1, 1, 1, 1.0, 1.0
+        keep += [ad, bd]; outs.append(out); refs.append(a.double().t() @ b.double() + 1)
+    check(lib().nbci_gemm_grouped(descs, len(probs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "grouped")
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert torch.equal(o.double().cpu(), r)
