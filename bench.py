@@ -147,8 +147,14 @@ def main():
         ms, fl, cnt, kid = max(kinds)
         peak = PEAK_BF16_TFLOPS if kid >= 4 else PEAK_F32_TFLOPS
         ach = fl / ms / 1e9
+        traffic = None   # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/), if present
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+            traffic = pmc["kind_avg_hbm_bytes_per_launch"].get(str(kid))
+        except Exception:
+            pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "kernel": f"gemm_kernel<{KIND_NAMES[kid]}>", "launches_per_step": cnt // nprof,
+                "traffic": traffic, "kernel": f"gemm_kernel<{KIND_NAMES[kid]}>", "launches_per_step": cnt // nprof,
                 "avg_launch_us": round(1e3 * ms / cnt, 2), "flop_per_launch": round(fl / cnt / 1e9, 3),
                 "share_of_gemm_time": round(ms / tot_ms, 3), "gemm_ms_per_step": round(tot_ms / nprof, 3),
                 "all_gemm_tflops": round(sum(k[1] for k in kinds) / tot_ms / 1e9, 1)}
