@@ -77,18 +77,28 @@ __device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW
 template <bool AK, bool BKM, int MI, int NI>
 __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
     const int i16 = lane & 15, g = lane >> 4;
+    // all fragment reads of BOTH k-steps are issued before the first MFMA: the second step's ds_reads
+    // stay in flight under the first step's MFMAs (lgkmcnt retires in order, hipcc waits per use)
+    bf16x8 af[2][MI], bf[2][NI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[MI], bf[NI];
 #pragma unroll
-        for (int sb = 0; sb < MI; ++sb) af[sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
+        for (int sb = 0; sb < NI; ++sb) bf[ks][sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
 #pragma unroll
-        for (int sb = 0; sb < NI; ++sb) bf[sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
+        for (int sb = 0; sb < MI; ++sb) af[ks][sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < NI; ++ni) {
+#if defined(NBCI_ABLATE) && NBCI_ABLATE == 1
+                asm volatile("" :: "v"(bf[ks][ni]), "v"(af[ks][mi]));
+#else
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
+#endif
+            }
     }
 }
 
@@ -168,7 +178,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     }
     __syncthreads();  // drains the LDS-DMA (hipcc emits vmcnt(0) ahead of the barrier)
     for (int kt = kt_begin; kt < kt_full_end; ++kt) {
+#if defined(NBCI_ABLATE) && NBCI_ABLATE == 2
+        if (false) {
+#else
         if (kt + 1 < kt_full_end) {
+#endif
             char* nx = smem + (cur ^ 1) * STAGE;
             glds_stage<AK, NPA>(ga, A, nx, kt + 1, w);
             glds_stage<BKM, NPB>(gb, B, nx + A_BYTES, kt + 1, w);

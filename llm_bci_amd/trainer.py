@@ -118,3 +118,50 @@ class NativeTrainer:
     def end_epoch(self):
         if isinstance(self.sched, StepDecay):
             self.sched.end_epoch()
+
+    # ------------------------------------------------------------------------------------- eval
+    @torch.no_grad()
+    def evaluate(self, batches):
+        """Reference Trainer.evaluate (trainer.py:273-309): eval mode, sum-loss / sum-examples and the
+        mean of per-batch PER ratios over `batches` (an iterable of device batches)."""
+        m = self.model
+        was_training = m.training
+        m.eval()
+        acc = torch.zeros(4, dtype=torch.float64, device=m._flat.device)
+        for batch in batches:
+            loss_vec, _ = m._run_forward(batch, want_grad=False)
+            acc[0] += loss_vec.sum().double()
+            acc[1] += loss_vec.numel()
+            if self.compute_per and batch.get("targets") is not None:
+                acc[2] += self._per(batch)
+                acc[3] += 1
+        m.train(was_training)
+        s = reduce_stats(acc, self.group).cpu()
+        return {"loss": (s[0] / s[1]).item() if s[1] > 0 else 0.0, "PER": (s[2] / s[3]).item() if s[3] > 0 else None}
+
+    # ------------------------------------------------------------------------------------- resume
+    def save_checkpoint(self, save_dir, rank=0):
+        """Model files exactly as the reference writes them (ndt1.py:685-688) plus `trainer_state.pth`
+        with what the reference never saved ("todo optimizer states", configs/trainer.yaml:11): Adam
+        moments, step counters, scheduler position, RNG stream position -> exact resume. Rank 0 only."""
+        import os
+        if rank != 0:
+            return
+        self.model.save_checkpoint(save_dir)
+        m = self.model
+        state = {"layout": [(n, o, k) for (n, o, k, _s, _g) in m._layout], "m": self.m.cpu(), "v": self.v.cpu(),
+                 "global_step": self.global_step, "opt_step": self.opt_step, "step_seed": m._step_seed,
+                 "sched_epoch": getattr(self.sched, "epoch", 0), "grads": self.grads.cpu()}
+        torch.save(state, os.path.join(save_dir, "trainer_state.pth"))
+
+    def load_checkpoint(self, load_dir):
+        import os
+        self.model.load_checkpoint(load_dir)
+        st = torch.load(os.path.join(load_dir, "trainer_state.pth"), weights_only=False)
+        if [(n, o, k) for (n, o, k, _s, _g) in self.model._layout] != [tuple(x) for x in st["layout"]]:
+            raise ValueError("trainer_state.pth was written for a different parameter layout")
+        self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.grads.copy_(st["grads"])
+        self.global_step, self.opt_step = st["global_step"], st["opt_step"]
+        self.model._step_seed = st["step_seed"]
+        if hasattr(self.sched, "epoch"):
+            self.sched.epoch = st["sched_epoch"]

@@ -74,3 +74,31 @@ def test_bf16_training_reduces_loss_and_keeps_shadow_in_sync():
     assert losses[-1] < 0.7 * losses[0], losses
     assert torch.equal(m._flat_lp, m._flat.bfloat16())
     assert all(np.isfinite(losses))
+
+
+def test_resume_reproduces_training(tmp_path):
+    """save after 2 steps, keep training 2 more; a fresh trainer restored from the checkpoint and fed the same
+    batches reproduces the weights (same dropout streams: the RNG position is part of the state) up to the
+    summation-order noise of the f32 atomics used for bias / LayerNorm / split-K gradient sums."""
+    from llm_bci_amd.trainer import NativeTrainer
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    bd = _to_dev(_rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2]))
+    m = _model(over, 11).to(DEV)
+    tr = NativeTrainer(m, total_steps=20)
+    for _ in range(2):
+        tr.train_step(bd)
+    tr.save_checkpoint(str(tmp_path))
+    for _ in range(2):
+        tr.train_step(bd)
+    torch.cuda.synchronize()
+    ref = m._flat.clone()
+    m2 = _model(over, 11, seed=5).to(DEV)
+    tr2 = NativeTrainer(m2, total_steps=20)
+    tr2.load_checkpoint(str(tmp_path))
+    for _ in range(2):
+        tr2.train_step(bd)
+    torch.cuda.synchronize()
+    assert torch.allclose(m2._flat, ref, atol=2e-5, rtol=0), (m2._flat - ref).abs().max()
+    ev = tr2.evaluate([bd])
+    assert ev["loss"] > 0 and ev["PER"] is not None
