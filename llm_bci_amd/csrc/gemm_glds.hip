@@ -87,6 +87,10 @@ __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f
 #pragma unroll
         for (int sb = 0; sb < MI; ++sb) af[ks][sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
     }
+    // hipcc otherwise sinks each pair of ds_reads next to its 4 MFMAs with an lgkmcnt(0) in front (to save
+    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs;
+    // the compiler's counted lgkmcnt waits let the MFMAs start as the fragments arrive, in order.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -236,22 +240,42 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_group_kernel(GemmGroup
 }
 
 
-// ---- 3-stage variant: 288 x 128 tile, 8 waves (2 x 4, each 144 x 32), two K tiles in flight ------------
-// The 2-stage kernel keeps one 35 KB tile in flight per workgroup and tops out near 30 GB/s of L2->LDS
-// traffic per CU; at K = 1024 that, not the MFMA pipe, sets the pace. Here one workgroup per CU owns a
-// 288-row tile (88 FLOP/B instead of 68), stages tile t+2 while computing tile t, and waits with a
-// COUNTED s_waitcnt vmcnt (never 0 inside the loop) + raw s_barrier so the LDS-DMA stays in flight
-// across barriers. M = 9152 gives 32 x 8 = 256 tiles: exactly one per CU.
-constexpr int G3_BM = 288, G3_STAGE = G3_BM * 128 + 16384, G3_THREADS = 512;
+// ---- multi-stage variant: NSTAGE LDS stages, NSTAGE-1 K tiles in flight, counted vmcnt -----------------
+// The 2-stage kernel has one K tile in flight per workgroup: fine when two workgroups share a CU and the
+// grid fills the chip, but a workgroup that is ALONE on its CU (small M: few tiles) then pays a full
+// L2/HBM round trip per K tile (~3 us measured at 72 workgroups). Here tile t+NSTAGE-1 is staged while
+// tile t is computed; the wait before each barrier is a COUNTED s_waitcnt vmcnt (never 0 inside the loop)
+// and the barrier is a raw s_barrier, so the LDS-DMA stays in flight across barriers.
+//   <.., 2,2,4,4, 4>: 128 x 128 tile, 4 waves, 4 stages (128 KB LDS): small grids (<= 1 workgroup per CU)
+//   <.., 2,4,9,2, 3>: 288 x 128 tile, 8 waves, 3 stages (156 KB LDS): opt-in (NBCI_GEMM3=1), measured no
+//                     faster than the 2-stage 144-row kernel on the full-chip shapes
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 
-template <bool BKM>
-__global__ __launch_bounds__(G3_THREADS) void gemm_glds3_kernel(GemmK d) {
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NPA = G3_BM / 8, NPB = 16;          // 36 A pieces (waves 0-3 stage 5, waves 4-7 stage 4), 16 B pieces (2 each)
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    static_assert(BN == 128, "B tile is always 128 wide");
+    static_assert(AK || BM == 128, "row-major-in-k A needs 256-byte tile rows");
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 16384;
+    constexpr int NPA = A_BYTES / 1024, NPB = 16;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = w / WN, wn = w % WN;
     const int nwg = d.tiles_m * d.tiles_n;
     int wg;
     {
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm_glds3_kernel(GemmK d) {
         tm = first_m + in_grp % gsize;
         tn = in_grp / gsize;
     }
-    const int m0 = tm * G3_BM, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * 128;
     OperandK A = d.A, B = d.B;
     const int z = blockIdx.y;
     const int z1 = z / d.zdiv, z2 = z % d.zdiv;
@@ -276,46 +300,59 @@ __global__ __launch_bounds__(G3_THREADS) void gemm_glds3_kernel(GemmK d) {
     const long long coff = z1 * d.czs1 + z2 * d.czs2;
     const int nt = d.K / 64;
 
-    f32x4 acc[9][2];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    GldsOperand<true, NPA, 8> ga;
-    GldsOperand<BKM, NPB, 8> gb;
-    glds_setup<true, NPA, 8>(ga, A, m0, d.M, w, lane);
-    glds_setup<BKM, NPB, 8>(gb, B, n0, d.N, w, lane);
+    GldsOperand<AK, NPA, NW> ga;
+    GldsOperand<BKM, NPB, NW> gb;
+    glds_setup<AK, NPA, NW>(ga, A, m0, d.M, w, lane);
+    glds_setup<BKM, NPB, NW>(gb, B, n0, d.N, w, lane);
+    const int lw = (NPA - w + NW - 1) / NW + (NPB - w + NW - 1) / NW;   // LDS-DMA instructions this wave issues per tile
 
-    glds_stage<true, NPA, 8>(ga, A, smem, 0, w);
-    glds_stage<BKM, NPB, 8>(gb, B, smem + G3_BM * 128, 0, w);
-    if (nt > 1) {
-        glds_stage<true, NPA, 8>(ga, A, smem + G3_STAGE, 1, w);
-        glds_stage<BKM, NPB, 8>(gb, B, smem + G3_STAGE + G3_BM * 128, 1, w);
-    }
-    int cur = 0, nxt2 = 2;   // stage holding tile kt ; stage that tile kt+2 goes to
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nt) {
+            glds_stage<AK, NPA, NW>(ga, A, smem + p * STAGE, p, w);
+            glds_stage<BKM, NPB, NW>(gb, B, smem + p * STAGE + A_BYTES, p, w);
+        }
+    int cur = 0, nxt = NSTAGE - 1;   // stage holding tile kt ; stage that tile kt + NSTAGE - 1 goes to
     for (int kt = 0; kt < nt; ++kt) {
-        // tile kt has landed once at most the loads of tile kt+1 (7 per wave 0-3, 6 per wave 4-7) remain
-        if (kt + 1 < nt) {
-            if (w < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();          // all pieces of tile kt visible; everyone is done reading stage nxt2
+        // tile kt has landed once only the younger tiles' loads (already issued: kt+1 .. kt+NSTAGE-2) remain
+        const int ahead = min(NSTAGE - 2, nt - 1 - kt);
+        wait_vmcnt(lw * ahead);
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are visible; stage `nxt` is no longer read
         asm volatile("" ::: "memory");
-        if (kt + 2 < nt) {
-            char* nx = smem + nxt2 * G3_STAGE;
-            glds_stage<true, NPA, 8>(ga, A, nx, kt + 2, w);
-            glds_stage<BKM, NPB, 8>(gb, B, nx + G3_BM * 128, kt + 2, w);
+        if (kt + NSTAGE - 1 < nt) {
+            char* nx = smem + nxt * STAGE;
+            glds_stage<AK, NPA, NW>(ga, A, nx, kt + NSTAGE - 1, w);
+            glds_stage<BKM, NPB, NW>(gb, B, nx + A_BYTES, kt + NSTAGE - 1, w);
         }
-        const char* sA = smem + cur * G3_STAGE;
-        compute_tile_g<true, BKM, 9, 2>(sA, sA + G3_BM * 128, acc, wm * 144, wn * 32, lane);
-        cur = (cur == 2) ? 0 : cur + 1;
-        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+        const char* sA = smem + cur * STAGE;
+        compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
     }
-    __syncthreads();   // (epilogue may reuse LDS)
-    gemm_epilogue<9, 2>(d, acc, m0 + wm * 144, n0 + wn * 32, coff, lane, w, smem);
+    __syncthreads();   // (the split-K epilogue reuses LDS; harmless otherwise)
+    gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
+}
+
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
+static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
+    constexpr int lds = NSTAGE * (WM * MI * 16 * 128 + 16384);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms: LDS attribute: ") + hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>), grid, dim3(WM * WN * 64), lds, s, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms launch: ") + hipGetErrorString(e));
+    return NBCI_OK;
 }
 
 // ---- host --------------------------------------------------------------------------------------
@@ -411,23 +448,18 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     k.tiles_m = (d.M + bm - 1) / bm;
     dim3 grid(k.tiles_m * k.tiles_n * (splitk > 1 ? splitk : 1), splitk > 1 ? 1 : batch);
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
+    // small grids (at most one workgroup per CU): nothing else hides the per-tile load latency -> 4-stage pipeline
+    static const bool ms_off = [] { const char* e = getenv("NBCI_GEMM_MS"); return e && e[0] == '0'; }();
+    if (!ms_off && bm == 128 && splitk == 1 && d.K % 64 == 0 && d.K >= 256 && (long)grid.x * grid.y <= 256) {
+        if (ak && bk) return launch_ms<true, true, 2, 2, 4, 4, 4>(k, grid, stream);
+        if (ak && !bk) return launch_ms<true, false, 2, 2, 4, 4, 4>(k, grid, stream);
+        if (!ak && bk) return launch_ms<false, true, 2, 2, 4, 4, 4>(k, grid, stream);
+        return launch_ms<false, false, 2, 2, 4, 4, 4>(k, grid, stream);
+    }
     switch (bm) {
         case 144: return launch_glds_layout<1, 4, 9, 2>(k, ak, bk, grid, stream);
-        case 288: {
-            constexpr int lds = 3 * G3_STAGE;
-            static bool attr = false;
-            if (!attr) {
-                hipError_t e1 = hipFuncSetAttribute((const void*)gemm_glds3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipError_t e2 = hipFuncSetAttribute((const void*)gemm_glds3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                if (e1 != hipSuccess || e2 != hipSuccess) return fail(NBCI_EHIP, "gemm_glds3: LDS attribute");
-                attr = true;
-            }
-            if (bk) hipLaunchKernelGGL((gemm_glds3_kernel<true>), grid, dim3(G3_THREADS), lds, stream, k);
-            else hipLaunchKernelGGL((gemm_glds3_kernel<false>), grid, dim3(G3_THREADS), lds, stream, k);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds3 launch: ") + hipGetErrorString(e));
-            return NBCI_OK;
-        }
+        case 288:
+            return bk ? launch_ms<true, true, 2, 4, 9, 2, 3>(k, grid, stream) : launch_ms<true, false, 2, 4, 9, 2, 3>(k, grid, stream);
         default: return launch_glds_layout<2, 2, 4, 4>(k, ak, bk, grid, stream);
     }
 }

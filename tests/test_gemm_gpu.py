@@ -265,3 +265,24 @@ def test_grouped_gemm_matches_individual():
     torch.cuda.synchronize()
     for o, r in zip(outs, refs):
         assert torch.equal(o.double().cpu(), r)
+
+
+@pytest.mark.parametrize("ak", [True, False])
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("shape", [(300, 256, 512), (1144, 1024, 1024), (128, 128, 256), (700, 384, 4096)])
+def test_multistage_small_grid_kernel_exact(ak, bk, shape):
+    """<= 256 workgroups and K % 64 == 0 selects the 4-stage counted-vmcnt kernel: exact integer data,
+    all four layouts, repeated to catch staging races."""
+    ops = _ops()
+    M, N, K = shape
+    a = _ints((M, K), lo=-2, hi=3, seed=41)
+    b = _ints((N, K), lo=-2, hi=3, seed=42)
+    ad = (a if ak else a.t().contiguous()).to(DEV, torch.bfloat16)
+    bd = (b if bk else b.t().contiguous()).to(DEV, torch.bfloat16)
+    ref = a.double() @ b.double().t()
+    for _ in range(3):
+        out = torch.zeros(M, N, device=DEV)
+        ops.gemm(M, N, K, ops.operand(ad, ad.stride(0), ak), ops.operand(bd, bd.stride(0), bk), out, N,
+                 in_dtype=ops.NBCI_BF16, c_dtype=ops.NBCI_F32)
+        torch.cuda.synchronize()
+        assert torch.equal(out.double().cpu(), ref)
