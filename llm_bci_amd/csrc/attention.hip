@@ -32,7 +32,7 @@ __device__ __forceinline__ int img_off(int row, int ch) {
 
 // global (rows x 128 bf16, row stride ld elements) -> LDS image, rows >= nrows zero-filled
 __device__ __forceinline__ void load_image(char* img, const bf16_t* src, long long ld, int nrows, int tid) {
-    for (int i = tid; i < AT_TPAD * 16; i += AT_THREADS) {
+    for (int i = tid; i < AT_TPAD * 16; i += (int)blockDim.x) {
         const int row = i >> 4, ch = i & 15;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < nrows) v = *(const uint4*)(src + (long long)row * ld + ch * 8);
@@ -133,7 +133,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
     return o;
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = smem + AT_TPAD * 256;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
     __syncthreads();
     const int nqb = (a.Tp + 15) / 16;
-    for (int qb = wave; qb < nqb; qb += AT_THREADS / 64) {
+    for (int qb = wave; qb < nqb; qb += (int)(blockDim.x >> 6)) {
         const int query = 16 * qb + i16;
         const int qrow = query < a.Tp ? query : a.Tp - 1;
         bf16x8 qf[4];
@@ -298,7 +298,7 @@ __device__ __forceinline__ int ximg_off(int row, int col) {  // byte offset of e
 }
 
 // grid (B*nh, 2): z = 0 -> dk = dS^T q ; z = 1 -> dv = Pd^T da.  out[key][d] = sum_q X[q][key] Y[q][d]
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnArgs a) {   // one wave per 16-key block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sY = smem;                          // [160][128] image
     char* sX = smem + AT_TPAD * 256;          // [160][160]
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bf16_t* X = (which == 0 ? a.dS : a.Pd) + (long long)blockIdx.x * a.Tp * a.ldP;
     if (which == 0) load_image(sY, a.qkv + (long long)b * a.Tp * ld3 + h * AT_HD, ld3, a.Tp, tid);
     else load_image(sY, a.da + (long long)b * a.Tp * a.H + h * AT_HD, a.H, a.Tp, tid);
-    for (int i = tid; i < AT_TPAD * 20; i += AT_THREADS) {
+    for (int i = tid; i < AT_TPAD * 20; i += (int)blockDim.x) {
         const int row = i / 20, ch = i % 20;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < a.Tp && ch * 8 < a.ldP) v = *(const uint4*)(X + (long long)row * a.ldP + ch * 8);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     __syncthreads();
     const int q = i16 >> 2, p = i16 & 3;
-    for (int kb = wave; kb < (a.Tp + 15) / 16; kb += AT_THREADS / 64) {
+    for (int kb = wave; kb < (a.Tp + 15) / 16; kb += (int)(blockDim.x >> 6)) {
         f32x4 o[8];
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -394,7 +394,8 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int 
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
     a.ad = (bf16_t*)ad;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(AT_THREADS), lds, s, a);
+    const int nblk = (Tp + 15) / 16;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_fwd: ") + hipGetErrorString(e));
     return NBCI_OK;
@@ -415,7 +416,8 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void*
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.da = (const bf16_t*)da; a.dS = (bf16_t*)dS; a.Pd = (bf16_t*)Pd; a.ldP = ldP; a.dqkv = (bf16_t*)dqkv; a.bias_grad = bias_grad; a.rc = rc;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(AT_THREADS), lds1, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(AT_THREADS), lds2, s, a);
+    const int nblk = (Tp + 15) / 16;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(64 * (nblk < 2 ? 2 : nblk)), lds2, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_bwd: ") + hipGetErrorString(e));
     return NBCI_OK;
