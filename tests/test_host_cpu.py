@@ -98,3 +98,29 @@ def test_schedules_match_golden_lr_and_momentum():
     for s in range(2):
         lr, b1 = oc.at(s)
         assert abs(lr - float(fx[f"lr_step{s}"])) < 1e-12 and abs(b1 - float(fx[f"beta1_step{s}"])) < 1e-12
+
+
+def test_product_collate_matches_reference_fixture_and_oracle():
+    """llm_bci_amd.collate reproduces the reference's pad_collate_fn output stored in the golden fixture, and the
+    oracle's restatement on left/right padding, truncate and min_length."""
+    from llm_bci_amd import collate as PC
+    from oracle import collate as OC
+    from test_oracle_golden import load
+    fx = load("g_tiny")
+    g = np.random.default_rng(0)
+    rows = []
+    for L, S in zip([30, 22, 17], [5, 4, 2]):
+        rows.append({"spikes": g.standard_normal((L, 16)).astype(np.float32), "phonemes_idx": g.integers(1, 11, (S,)).astype(np.int64),
+                     "sentence": "x"})
+    items = [PC.item_from_row(r, targets_name="phonemes_idx") for r in rows]
+    names = ["spikes", "spikes_mask", "spikes_timestamp", "spikes_lengths", "targets", "targets_lengths"]
+    batch, unused = PC.pad_collate_fn(items, names, OC.CTC_PAD)
+    for k in names:
+        assert np.array_equal(batch[k].numpy(), fx["in_" + k]), k
+    assert unused["sentence"] == ["x"] * 3 and "targets_mask" in unused
+    arrs = [np.arange(n * 2, dtype=np.float32).reshape(n, 2) + 1 for n in (5, 3, 7)]
+    for kw in (dict(side="left"), dict(side="right", truncate=4), dict(side="left", truncate=6, min_length=2),
+               dict(side="right", min_length=9, truncate=10), dict(side="left", value=-1, min_length=8, truncate=8)):
+        a = PC.padded_array(arrs, dim=0, **kw).numpy()
+        b = OC.padded_array(arrs, dim=0, **kw)
+        assert np.array_equal(a, b), kw
