@@ -91,11 +91,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)          # (rehearsal: several ranks may share one GPU with NBCI_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NBCI_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from llm_bci_amd._lib import check, lib
@@ -106,7 +112,7 @@ def main():
     over = {"encoder": {"embedder": {"n_channels": args.channels}}}
     model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    total_steps = args.steps + args.warmup + 16
+    total_steps = args.steps + args.warmup + 16   # OneCycle horizon covers warm-up + timed + the 3 profiling steps
     tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=total_steps, warmup_pct=0.0,
                        div_factor=25)
     _, batch = make_batch(args.batch, args.bins, args.channels, args.target_len, 41, dev, seed=rank)
@@ -131,14 +137,17 @@ def main():
     stats = tr.read_stats()
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        # per-launch HIP-event timing of every GEMM over 3 more steps (own pass: events perturb the step)
+    if not args.no_roofline:
+        # per-launch HIP-event timing of every GEMM over 3 more steps (own pass: events perturb the step).
+        # Every rank runs the steps (they contain collectives); only rank 0 records and reports.
         l = lib()
-        check(l.nbci_profile_enable(1), "profile_enable")
+        if rank == 0:
+            check(l.nbci_profile_enable(1), "profile_enable")
         nprof = 3
         for i in range(nprof):
             tr.train_step(batch, seed=5000 + i)
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         out = (C.c_double * 24)()
         check(l.nbci_profile_collect(out), "profile_collect")
         check(l.nbci_profile_enable(0), "profile_enable")

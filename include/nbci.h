@@ -154,6 +154,16 @@ int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d
                        void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H, int32_t ctx_forward,
                        int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream);
 
+/* BCI coupler splice (models/bci.py:143-166): per example b, out[b] = cat(text[b,:d_b], spikes[b], text[b,d_b:]) for
+ * embeddings (B,Lt,H)+(B,Ts,H) -> (B,Lt+Ts,H) in `dtype`, the attention mask (text mask / spike validity) and the
+ * targets (-100 over the spike span). int64 masks/targets as the reference collates them. text/targets may be NULL.
+ * The backward scatters d_out back to d_text (optional) and d_spikes. */
+int nbci_coupler_splice_fwd(const void* text, const void* spikes, void* out, int32_t dtype, const int64_t* text_mask,
+                            const int64_t* spikes_valid, int64_t* mask_out, const int64_t* targets, int64_t* targets_out,
+                            const int64_t* split, int32_t B, int32_t Lt, int32_t Ts, int32_t H, nbci_stream_t stream);
+int nbci_coupler_splice_bwd(const void* d_out, void* d_text, void* d_spikes, int32_t dtype, const int64_t* split, int32_t B,
+                            int32_t Lt, int32_t Ts, int32_t H, nbci_stream_t stream);
+
 /* nn.LogSoftmax(-1) of the decoder (ndt1.py:499) + argmax path (main.py:69) */
 int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V,
                     nbci_stream_t stream);
@@ -227,6 +237,10 @@ typedef struct nbci_ndt1_io {
     float* loss;                        /* out (B) per-sample CTC loss (sum it for NDT1Output.loss) */
     int32_t* argmax;                    /* out (B,T') greedy path or NULL */
     void* hidden_out;                   /* out (B,T',H) encoder output in cfg.dtype, or NULL */
+    int32_t* token_mask_out;            /* out (B,T') stacked validity mask (ndt1.py:182-183), or NULL */
+    const float* d_hidden;              /* backward: d loss / d hidden_out, f32 (B,T',H). When set, the head segment
+                                           starts from it (encoder used as a feature extractor, models/bci.py:125)
+                                           instead of the CTC gradient; decoder gradients are not touched. */
     void* workspace;
     int64_t workspace_bytes;
 } nbci_ndt1_io;

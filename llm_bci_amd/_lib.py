@@ -61,6 +61,7 @@ class NDT1IO(C.Structure):
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
                 ("preds", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
+                ("token_mask_out", C.c_void_p), ("d_hidden", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
@@ -99,6 +100,8 @@ _SIGNATURES = {
                                                                                                C.c_uint32, C.c_void_p]),
     "nbci_attention_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +
                            [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nbci_coupler_splice_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]),
+    "nbci_coupler_splice_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "nbci_profile_enable": (C.c_int, [C.c_int32]),
     "nbci_profile_collect": (C.c_int, [C.POINTER(C.c_double)]),
     "nbci_per": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

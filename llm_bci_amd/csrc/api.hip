@@ -76,6 +76,16 @@ int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d
     return nbci::attn_bwd_launch(qkv, token_mask, d_out, dS_ws, Pd_ws, ldP, dqkv, bias_grad, B, n_heads, Tp, H, ctx_forward, ctx_backward,
                                  drop_p, seed, site_prob, (hipStream_t)stream, nbci::RepCfg{0, 1});
 }
+int nbci_coupler_splice_fwd(const void* text, const void* spikes, void* out, int32_t dtype, const int64_t* text_mask,
+                            const int64_t* spikes_valid, int64_t* mask_out, const int64_t* targets, int64_t* targets_out,
+                            const int64_t* split, int32_t B, int32_t Lt, int32_t Ts, int32_t H, nbci_stream_t stream) {
+    return nbci::splice_fwd_launch(text, spikes, out, dtype, text_mask, spikes_valid, mask_out, targets, targets_out, split, B, Lt, Ts, H,
+                                   (hipStream_t)stream);
+}
+int nbci_coupler_splice_bwd(const void* d_out, void* d_text, void* d_spikes, int32_t dtype, const int64_t* split, int32_t B, int32_t Lt,
+                            int32_t Ts, int32_t H, nbci_stream_t stream) {
+    return nbci::splice_bwd_launch(d_out, d_text, d_spikes, dtype, split, B, Lt, Ts, H, (hipStream_t)stream);
+}
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");

@@ -81,6 +81,13 @@ int adamw_launch(float* p, const float* g, float* m, float* v, void* p_lp, int64
 
 int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s);
 
+// BCI coupler splice (models/bci.py:143-166)
+int splice_fwd_launch(const void* text, const void* spikes, void* out, int dtype, const int64_t* tmask, const int64_t* svalid,
+                      int64_t* mask_out, const int64_t* targets, int64_t* targets_out, const int64_t* split, int B, int Lt, int Ts,
+                      int H, hipStream_t s);
+int splice_bwd_launch(const void* dout, void* dtext, void* dspikes, int dtype, const int64_t* split, int B, int Lt, int Ts, int H,
+                      hipStream_t s);
+
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
 int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,

@@ -887,6 +887,66 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
 }
 
 // ------------------------------------------------------------------------------------------
+// BCI coupler splice (models/bci.py:143-166)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void splice_fwd_kernel(const T* __restrict__ text, const T* __restrict__ spikes, T* __restrict__ out,
+                                                         const int64_t* __restrict__ tmask, const int64_t* __restrict__ svalid,
+                                                         int64_t* __restrict__ mask_out, const int64_t* __restrict__ targets,
+                                                         int64_t* __restrict__ targets_out, const int64_t* __restrict__ split,
+                                                         int B, int Lt, int Ts, int H) {
+    const int L = Lt + Ts;
+    const int row = blockIdx.x;           // (b, pos)
+    const int b = row / L, pos = row % L;
+    int d = (int)split[b];
+    d = d < 0 ? 0 : (d > Lt ? Lt : d);
+    const bool is_spike = pos >= d && pos < d + Ts;
+    const int src = is_spike ? pos - d : (pos < d ? pos : pos - Ts);
+    const T* s = is_spike ? spikes + ((long long)b * Ts + src) * H : (text ? text + ((long long)b * Lt + src) * H : nullptr);
+    T* o = out + (long long)row * H;
+    for (int c = threadIdx.x; c < H; c += 256) o[c] = s ? s[c] : (T)0.0f;
+    if (threadIdx.x == 0) {
+        if (mask_out) mask_out[row] = is_spike ? (svalid ? svalid[b * Ts + src] : 1) : (tmask ? tmask[b * Lt + src] : 1);
+        if (targets_out) targets_out[row] = is_spike ? -100 : (targets ? targets[b * Lt + src] : -100);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splice_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dtext, T* __restrict__ dspikes,
+                                                         const int64_t* __restrict__ split, int B, int Lt, int Ts, int H) {
+    const int L = Lt + Ts;
+    const int row = blockIdx.x;
+    const int b = row / L, pos = row % L;
+    int d = (int)split[b];
+    d = d < 0 ? 0 : (d > Lt ? Lt : d);
+    const bool is_spike = pos >= d && pos < d + Ts;
+    const int src = is_spike ? pos - d : (pos < d ? pos : pos - Ts);
+    T* dst = is_spike ? dspikes + ((long long)b * Ts + src) * H : (dtext ? dtext + ((long long)b * Lt + src) * H : nullptr);
+    if (!dst) return;
+    const T* g = dout + (long long)row * H;
+    for (int c = threadIdx.x; c < H; c += 256) dst[c] = g[c];
+}
+
+int splice_fwd_launch(const void* text, const void* spikes, void* out, int dtype, const int64_t* tmask, const int64_t* svalid,
+                      int64_t* mask_out, const int64_t* targets, int64_t* targets_out, const int64_t* split, int B, int Lt, int Ts,
+                      int H, hipStream_t s) {
+    NBCI_REQUIRE(spikes && out && split && B > 0 && Ts > 0 && Lt >= 0 && H > 0, NBCI_EINVAL, "splice: bad arguments");
+    DISPATCH_DTYPE(dtype, TT,
+                   hipLaunchKernelGGL((splice_fwd_kernel<TT>), dim3(B * (Lt + Ts)), dim3(256), 0, s, (const TT*)text, (const TT*)spikes,
+                                      (TT*)out, tmask, svalid, mask_out, targets, targets_out, split, B, Lt, Ts, H));
+    return check_launch("splice_fwd");
+}
+
+int splice_bwd_launch(const void* dout, void* dtext, void* dspikes, int dtype, const int64_t* split, int B, int Lt, int Ts, int H,
+                      hipStream_t s) {
+    NBCI_REQUIRE(dout && dspikes && split, NBCI_EINVAL, "splice: bad arguments");
+    DISPATCH_DTYPE(dtype, TT,
+                   hipLaunchKernelGGL((splice_bwd_kernel<TT>), dim3(B * (Lt + Ts)), dim3(256), 0, s, (const TT*)dout, (TT*)dtext,
+                                      (TT*)dspikes, split, B, Lt, Ts, H));
+    return check_launch("splice_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
 // fold the replicated small-vector accumulators into the flat gradient buffer and clear them
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void fold_replicas_kernel(float* __restrict__ rep, long long stride, int nrep,

@@ -414,6 +414,8 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     }
     int32_t* amax = io->argmax ? io->argmax : (int32_t*)(ws + w.argmax);
     TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, M, c.vocab, s));
+    if (io->token_mask_out)
+        NBCI_CHECK_HIP(hipMemcpyAsync(io->token_mask_out, ws + w.tmask, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
     if (io->hidden_out)  // optional copy-out of the encoder output (B,T',H) for BCI-style couplers
         NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, ws + w.xo, (size_t)M * H * es, hipMemcpyDeviceToDevice, s));
     if (io->targets) {
@@ -465,15 +467,20 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
 
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
         if (seg == c.n_layers + 1) {
-            // ---- head: decoder Linear + out_norm
-            const void* dl = ws + w.dlogits;
-            TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
-            TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
-            {
-                nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
-                TRY(gemm_launch_timed(d, s));
+            // ---- head: decoder Linear + out_norm (or an external gradient of the encoder output)
+            const float* d_xo = dtmp;
+            if (io->d_hidden) {
+                d_xo = io->d_hidden;
+            } else {
+                const void* dl = ws + w.dlogits;
+                TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
+                TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
+                {
+                    nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
+                    TRY(gemm_launch_timed(d, s));
+                }
             }
-            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
+            TRY(layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
                                      (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1)));
         } else if (seg >= 1) {
             const int l = seg - 1;

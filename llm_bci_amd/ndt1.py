@@ -292,7 +292,7 @@ class NDT1(nn.Module):
         return lib().nbci_ndt1_tokens(self._plan, T)
 
     # ------------------------------------------------------------------ forward / backward
-    def _run_forward(self, batch, want_grad, seed=None, grad_scale=1.0, hidden_out=None):
+    def _run_forward(self, batch, want_grad, seed=None, grad_scale=1.0, hidden_out=None, token_mask_out=None):
         spikes = batch["spikes"]
         if not spikes.is_cuda:
             raise _lib.NbciUnavailable("NDT1 (HIP path) needs tensors on a ROCm device; there is no CPU fallback")
@@ -334,7 +334,7 @@ class NDT1(nn.Module):
                 self._rope = (emb.cos().contiguous(), emb.sin().contiguous())
             io.rope_cos, io.rope_sin = _ptr(self._rope[0]), _ptr(self._rope[1])
         io.train = 1 if self.training else 0
-        io.want_grad = 1 if (want_grad and tg is not None) else 0
+        io.want_grad = 1 if (want_grad and (tg is not None or hidden_out is not None)) else 0
         if seed is None:
             self._step_seed = (self._step_seed * 1664525 + 1013904223) & 0xFFFFFFFF
             seed = self._step_seed
@@ -342,16 +342,19 @@ class NDT1(nn.Module):
         io.grad_scale = grad_scale
         io.preds, io.loss, io.argmax = _ptr(preds), _ptr(loss), _ptr(argmax)
         io.hidden_out = _ptr(hidden_out)
+        io.token_mask_out = _ptr(token_mask_out)
+        io.d_hidden = None
         io.workspace, io.workspace_bytes = _ptr(ws), need
         check(lib().nbci_ndt1_forward(self._plan, _ptr(self._flat), _ptr(self._flat_lp), C.byref(io), _stream()),
               "nbci_ndt1_forward")
         # keep every borrowed tensor alive until the backward of this step has been queued
-        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax)
+        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out)
         self.last_argmax = argmax
         return loss, preds
 
-    def _run_backward(self, grads, seg_hi=None, seg_lo=0):
+    def _run_backward(self, grads, seg_hi=None, seg_lo=0, d_hidden=None):
         io = self._io_keepalive[0]
+        io.d_hidden = _ptr(d_hidden)   # f32 (B,T',H): backward starts from the encoder output instead of the CTC head
         if not io.want_grad:
             raise RuntimeError("backward called but the forward pass ran without want_grad/targets")
         if seg_hi is None:

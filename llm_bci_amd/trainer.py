@@ -16,12 +16,15 @@ from .dp import GradReducer, reduce_stats, shard_batch
 from .ndt1 import NDT1, _ptr, _stream
 from .schedule import LinearWarmup, OneCycle, StepDecay
 
-NAME2MODEL = {"NDT1": NDT1}
+from .bci import BCI  # noqa: E402
+
+NAME2MODEL = {"NDT1": NDT1, "BCI": BCI}
 
 
 def register_into(reference_trainer_module):
     """Registry swap: make the reference's Trainer build the HIP NDT1 for model_class 'NDT1'."""
     reference_trainer_module.NAME2MODEL["NDT1"] = NDT1
+    reference_trainer_module.NAME2MODEL["BCI"] = BCI
 
 
 class NativeTrainer:

@@ -236,7 +236,7 @@ def misc_cases():
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--bci" not in sys.argv:
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
@@ -245,3 +245,57 @@ if __name__ == "__main__":
     ctc_cases()
     metric_cases()
     misc_cases()
+
+
+def bci_case():
+    """BCI.prepare_embeds (models/bci.py:107-168) with the debug tiny Llama: embeddings / mask / targets after the
+    splice, and gradients of sum(input_embeds * R) wrt projector + encoder parameters."""
+    import types
+    peft = types.ModuleType("peft"); peft.LoraConfig = None; peft.get_peft_model = None
+    sys.modules["peft"] = peft
+    from models.bci import BCI
+    enc = tiny()["encoder"]
+    enc = json.loads(json.dumps(enc))
+    enc.setdefault("smooth_and_noise", {})["noise"] = False
+    enc["embedder"]["dropout"] = 0.0; enc["transformer"]["dropout"] = 0.0
+    cfg = {"projector": {"stacking": 2, "inter_size": 48, "bias": True, "act": "relu"}, "ndt1": {"encoder": enc}}
+    torch.manual_seed(3)
+    m = BCI(cfg, llm_path=None, debug=True, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    m.llm.float()   # keep the text embeddings exact for the fixture (the reference runs them in fp16)
+    m.eval()
+    g = np.random.default_rng(4)
+    B, T, Lt = 3, 32, 6     # T' = 15 -> padded to 16 for stacking 2
+    lens = [32, 26, 19]
+    spikes = g.standard_normal((B, T, 16)).astype(np.float32)
+    smask = np.zeros((B, T), np.int64); ts = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):
+        spikes[b, L:] = 0; smask[b, :L] = 1; ts[b, :L] = np.arange(L)
+    input_ids = g.integers(0, 100, (B, Lt)).astype(np.int64)
+    amask = np.ones((B, Lt), np.int64); amask[2, 4:] = 0
+    split = np.array([1, 3, 0], np.int64)
+    targets = g.integers(0, 100, (B, Lt)).astype(np.int64); targets[:, :2] = -100
+    tt = lambda a: torch.from_numpy(a)
+    emb, mask, tg = m.prepare_embeds(tt(input_ids), tt(amask), tt(split), tt(spikes), tt(smask), tt(ts), tt(np.array(lens)), None, None,
+                                     tt(targets))
+    R = torch.from_numpy(g.standard_normal(tuple(emb.shape)).astype(np.float32))
+    (emb * R).sum().backward()
+    fx = {"spikes": spikes, "spikes_mask": smask, "spikes_timestamp": ts, "spikes_lengths": np.array(lens), "input_ids": input_ids,
+          "attention_mask": amask, "input_split": split, "targets": targets, "R": R.numpy(),
+          "out_embeds": emb.detach().numpy(), "out_mask": mask.numpy(), "out_targets": tg.numpy(),
+          "embed_table": m.llm.get_input_embeddings().weight.detach().numpy()[:100].copy(),
+          "config_json": np.array(json.dumps(cfg))}
+    for k, v in m.ndt1.state_dict().items():
+        fx["w:ndt1." + k] = v.numpy()
+    for k, v in m.projector.state_dict().items():
+        fx["w:projector." + k] = v.numpy()
+    for k, p in m.projector.named_parameters():
+        fx["g:projector." + k] = p.grad.numpy()
+    for k, p in m.ndt1.named_parameters():
+        if p.grad is not None and any(s in k for s in ("out_norm", "layers.1.mlp.down_proj", "embed_spikes", "layers.0.attn.query")):
+            fx["g:ndt1." + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g_bci.npz"), **fx)
+    print("g_bci", emb.shape, mask.tolist(), tg.tolist()[0])
+
+
+if __name__ == "__main__" and "--bci" in sys.argv:
+    bci_case()
