@@ -236,7 +236,7 @@ def misc_cases():
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
 
-if __name__ == "__main__" and "--bci" not in sys.argv:
+if __name__ == "__main__" and "--bci" not in sys.argv and "--itr" not in sys.argv:
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
@@ -299,3 +299,154 @@ def bci_case():
 
 if __name__ == "__main__" and "--bci" in sys.argv:
     bci_case()
+
+
+# ------------------------------------------------------------------------------------------------
+# iTransformer SSL (models/itransformer.py mlm branch, masker.py) — `--itr`
+# ------------------------------------------------------------------------------------------------
+def _install_torchvision_mlp():
+    """torchvision is not installed here. torchvision.ops.MLP (third party, version unpinned by the
+    reference) is, by its published definition, Sequential[Linear, (norm), act, Dropout]* + Linear + Dropout."""
+    import types
+
+    class MLP(torch.nn.Sequential):
+        def __init__(self, in_channels, hidden_channels, norm_layer=None, activation_layer=torch.nn.ReLU, inplace=None,
+                     bias=True, dropout=0.0):
+            params = {} if inplace is None else {"inplace": inplace}
+            layers, d = [], in_channels
+            for h in hidden_channels[:-1]:
+                layers.append(torch.nn.Linear(d, h, bias=bias))
+                if norm_layer is not None:
+                    layers.append(norm_layer(h))
+                layers.append(activation_layer(**params))
+                layers.append(torch.nn.Dropout(dropout, **params))
+                d = h
+            layers.append(torch.nn.Linear(d, hidden_channels[-1], bias=bias))
+            layers.append(torch.nn.Dropout(dropout, **params))
+            super().__init__(*layers)
+
+    tv = types.ModuleType("torchvision"); ops = types.ModuleType("torchvision.ops")
+    ops.MLP = MLP; tv.ops = ops
+    sys.modules["torchvision"] = tv; sys.modules["torchvision.ops"] = ops
+
+
+def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisson_nll", spacestamp=False):
+    from models.itransformer import iTransformer
+    cfg = update_config("configs/itransformer.yaml", over)
+    torch.manual_seed(1)
+    model = iTransformer(cfg, method_name="mlm", log_input=log_input, loss=loss)
+    T = model.config.encoder.embedder.max_n_bins
+    g = np.random.default_rng(0)
+    spikes = g.poisson(0.5, (B, T, N)).astype(np.float32)
+    smask = np.zeros((B, T), np.int64); ts = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):          # left padding (trainer_ssl_itransformer.yaml:66-90)
+        spikes[b, :T - L] = 0; smask[b, T - L:] = 1; ts[b, T - L:] = np.arange(L)
+    batch = {"spikes": torch.from_numpy(spikes), "spikes_mask": torch.from_numpy(smask), "spikes_timestamp": torch.from_numpy(ts)}
+    if spacestamp:
+        ss = np.stack([g.permutation(model.config.encoder.max_n_channels)[:N] for _ in range(B)]).astype(np.int64)
+        batch["spikes_spacestamp"] = torch.from_numpy(ss)
+    fx = {"in_" + k: v.numpy() for k, v in batch.items()}
+    inter, masks = {}, []
+
+    def hook(nm):
+        def f(mod, inp, out):
+            inter[nm] = out
+        return f
+
+    enc = model.encoder
+    hs = [enc.embed.register_forward_hook(hook("embed")), enc.embed_dropout.register_forward_hook(hook("tokens")),
+          enc.transformer.register_forward_hook(hook("encoder"))]
+    for i, lyr in enumerate(enc.transformer.layers):
+        hs.append(lyr.register_forward_hook(hook(f"layer{i}")))
+    for mk in model.masker.values():
+        hs.append(mk.register_forward_hook(lambda mod, inp, out: masks.append(out[1].numpy().copy())))
+    model.eval()
+    with torch.no_grad():
+        out = model(**{k: v.clone() for k, v in batch.items()})
+    cut = (lambda a: a) if full else (lambda a: a[..., ::37])
+    fx["eval_raw_mask"] = masks[-1]
+    fx["eval_loss"] = out.loss.numpy(); fx["eval_n_examples"] = out.n_examples.numpy()
+    fx["eval_mask"] = out.mask.numpy()
+    fx["eval_preds"] = out.preds.numpy() if full else out.preds.numpy()[:, ::3, ::5]
+    fx["eval_targets_sum"] = np.float64(out.targets.double().sum().item())
+    fx["embed"] = cut(inter["embed"].numpy()); fx["tokens"] = cut(inter["tokens"].numpy())
+    for i in range(len(enc.transformer.layers)):
+        fx[f"layer{i}_out"] = cut(inter[f"layer{i}"].numpy())
+    fx["encoder_out"] = cut(inter["encoder"].numpy())
+    for h in hs[:-len(model.masker)]:
+        h.remove()
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=100, max_lr=1e-4, pct_start=0.15, div_factor=25)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for s in range(steps):
+        fx[f"lr_step{s}"] = np.float64(opt.param_groups[0]["lr"]); fx[f"beta1_step{s}"] = np.float64(opt.param_groups[0]["betas"][0])
+        out = model(**{k: v.clone() for k, v in batch.items()})
+        fx[f"raw_mask_step{s}"] = masks[-1]
+        out.loss.backward()
+        fx[f"loss_step{s}"] = out.loss.detach().numpy(); fx[f"n_examples_step{s}"] = out.n_examples.numpy()
+        if s == 0:
+            for k, p in model.named_parameters():
+                if full:
+                    fx["grad:" + k] = p.grad.numpy().copy()
+                else:
+                    sm = summarise(p.grad)
+                    fx["gsum:" + k] = np.array([sm["sum"], sm["abssum"]]); fx["gidx:" + k], fx["gval:" + k] = sm["idx"], sm["val"]
+        opt.step(); sched.step(); opt.zero_grad()
+    for k, v in model.state_dict().items():
+        if full:
+            fx["w0:" + k] = sd0[k].numpy(); fx["w2:" + k] = v.numpy()
+        else:
+            a, b = summarise(sd0[k]), summarise(v)
+            fx["w0sum:" + k] = np.array([a["sum"], a["abssum"]]); fx["w0idx:" + k], fx["w0val:" + k] = a["idx"], a["val"]
+            fx["w2val:" + k] = b["val"]
+    fx["config_json"] = np.array(json.dumps(over)); fx["lens"] = np.array(lens)
+    fx["kwargs_json"] = np.array(json.dumps({"log_input": log_input, "loss": loss}))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(name, "eval loss", float(fx["eval_loss"]), "n", int(fx["eval_n_examples"]), "train loss", float(fx["loss_step0"]),
+          "params", sum(p.numel() for p in model.parameters()), [k for k in sd0][:6])
+
+
+def masker_cases():
+    """Masker.forward (models/masker.py:44-104): shapes / value rules per mode, recorded from the reference with a fixed torch seed.
+    (The draws themselves are torch's Philox/MT stream and are not reproducible elsewhere; the fixture pins the STRUCTURE:
+    which axes a mask is constant along, zero/random replacement rules, eval/inactive pass-through, expand_timesteps.)"""
+    from models.masker import Masker
+    from utils.config_utils import DictConfig
+    fx = {}
+    g = np.random.default_rng(5)
+    spikes = g.poisson(2.0, (4, 20, 12)).astype(np.float32)
+    base = dict(force_active=True, active=True, ratio=0.3, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1,
+                regions=None, channels=None)
+    for mode, extra in (("temporal", {}), ("neuron", {}), ("random", {}), ("co-smooth", {"channels": [1, 5, 7]}),
+                        ("temporal_expand", {"mode": "temporal", "expand_prob": 1.0, "max_timespan": 3}),
+                        ("random_mixed", {"mode": "random", "zero_ratio": 0.5, "random_ratio": 0.5})):
+        c = dict(base); c["mode"] = mode; c.update(extra)
+        torch.manual_seed(7)
+        mk = Masker(DictConfig(c)); mk.train()
+        out, mask = mk(torch.from_numpy(spikes.copy()))
+        fx[mode + "_out"] = out.numpy(); fx[mode + "_mask"] = mask.numpy(); fx[mode + "_cfg"] = np.array(json.dumps(c))
+    w = torch.zeros(2, 11); w[0, 3] = 1; w[1, 0] = 1; w[1, 10] = 1
+    for width in (1, 2, 3, 4):
+        fx[f"expand_{width}"] = Masker.expand_timesteps(w, width).numpy()
+    fx["expand_in"] = w.numpy(); fx["spikes"] = spikes
+    np.savez_compressed(os.path.join(OUT, "masker_cases.npz"), **fx)
+    print("masker_cases", {k: v.shape for k, v in fx.items() if k.endswith("_mask")})
+
+
+def itr_tiny(**enc_extra):
+    enc = {"embedder": {"max_n_bins": 12, "dropout": 0.0}, "hidden_size": 32, "n_heads": 2, "n_layers": 2, "dropout": 0.0,
+           "max_n_channels": 16, "embed_region": False}
+    enc.update(enc_extra)
+    return {"encoder": enc, "masker": {"main": {"active": True, "regions": None, "ratio": 0.3}}}
+
+
+if __name__ == "__main__" and "--itr" in sys.argv:
+    _install_torchvision_mlp()
+    itr_case("g_itr_tiny", itr_tiny(), 3, 10, [12, 9, 7], full=True)
+    itr_case("g_itr_tiny_ss", itr_tiny(), 3, 10, [12, 12, 5], full=True, spacestamp=True)
+    itr_case("g_itr_tiny_rate", itr_tiny(), 3, 10, [12, 9, 7], full=True, log_input=False)
+    itr_case("g_itr_tiny_mse", itr_tiny(), 3, 10, [12, 9, 7], full=True, loss="mse")
+    itr_case("g_itr_c3", {"encoder": {"embedder": {"dropout": 0.0}, "dropout": 0.0, "embed_region": False},
+                          "masker": {"main": {"active": True, "regions": None}}}, 4, 64, [100, 100, 80, 61], full=False)
+    masker_cases()

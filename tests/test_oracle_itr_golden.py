@@ -1,0 +1,144 @@
+"""Pins oracle/itransformer.py (iTransformer SSL: masker rules, encoder, mlm head, losses, backward, AdamW) to fixtures
+generated from the REFERENCE (tests/golden/make_golden.py --itr). CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import itransformer as OI
+from oracle import optim as OO
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def itr_cfg(fx):
+    over = json.loads(str(fx["config_json"]))
+    kw = json.loads(str(fx["kwargs_json"]))
+    enc = over.get("encoder", {})
+    c = dict(embed_dropout=0.0, dropout=0.0, log_input=kw["log_input"], loss=kw["loss"])
+    for src, dst in (("hidden_size", "hidden"), ("n_heads", "n_heads"), ("n_layers", "n_layers"), ("max_n_channels", "max_n_channels")):
+        if src in enc:
+            c[dst] = enc[src]
+    if "max_n_bins" in enc.get("embedder", {}):
+        c["max_n_bins"] = enc["embedder"]["max_n_bins"]
+    return OI.make_config(**c)
+
+
+def itr_batch(fx):
+    return {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
+
+
+def masked_of(spikes, mask):
+    out = spikes.copy()
+    out[mask.astype(bool)] = 0      # zero_ratio = 1.0 in the fixtures' masker config
+    return out
+
+
+@pytest.mark.parametrize("name", ["g_itr_tiny", "g_itr_tiny_ss", "g_itr_tiny_rate", "g_itr_tiny_mse"])
+def test_itr_tiny_forward_backward_adamw(name):
+    fx = load(name)
+    cfg = itr_cfg(fx)
+    p = {k[3:]: fx[k] for k in fx.files if k.startswith("w0:")}
+    batch = itr_batch(fx)
+    m = fx["eval_raw_mask"]
+    out, _ = OI.forward(cfg, p, batch, masked_of(batch["spikes"], m), m, train=False)
+    np.testing.assert_allclose(out["embed"], fx["embed"], atol=2e-5)
+    np.testing.assert_allclose(out["tokens"], fx["tokens"], atol=2e-5)
+    for l in range(cfg["n_layers"]):
+        np.testing.assert_allclose(out["layer_out"][l], fx[f"layer{l}_out"], atol=5e-5)
+    np.testing.assert_allclose(out["encoder_out"], fx["encoder_out"], atol=5e-5)
+    np.testing.assert_allclose(out["preds"], fx["eval_preds"], atol=1e-4)
+    assert np.array_equal(out["mask"], fx["eval_mask"])
+    assert int(out["n_examples"]) == int(fx["eval_n_examples"])
+    np.testing.assert_allclose(out["loss"], fx["eval_loss"], rtol=2e-5)
+    # two train steps (each with the mask the reference drew that step) vs torch AdamW + OneCycleLR
+    m_, v_ = {k: np.zeros_like(x) for k, x in p.items()}, {k: np.zeros_like(x) for k, x in p.items()}
+    p = {k: x.copy() for k, x in p.items()}
+    for s in range(2):
+        mk = fx[f"raw_mask_step{s}"]
+        out, cache = OI.forward(cfg, p, batch, masked_of(batch["spikes"], mk), mk, train=True)
+        np.testing.assert_allclose(out["loss"], fx[f"loss_step{s}"], rtol=3e-5)
+        assert int(out["n_examples"]) == int(fx[f"n_examples_step{s}"])
+        g = OI.backward(cache)
+        if s == 0:
+            for k in p:
+                ref = fx["grad:" + k]
+                np.testing.assert_allclose(g[k], ref, atol=2e-5 + 2e-4 * np.abs(ref).max(), err_msg=k)
+        lr, b1 = OO.onecycle(s, 100, 1e-4, 0.15, 25.0)
+        assert abs(lr - float(fx[f"lr_step{s}"])) < 1e-12 and abs(b1 - float(fx[f"beta1_step{s}"])) < 1e-9
+        for k in p:
+            OO.adamw_step(p[k], g[k], m_[k], v_[k], s + 1, lr, b1, 0.999, 1e-8, 0.01)
+    for k in p:
+        # Adam normalises: a gradient at the rounding floor may flip the sign of a 1e-4-sized update
+        d = np.abs(p[k] - fx["w2:" + k])
+        assert np.mean(d > 2e-5) < 0.02 and d.max() < 5e-4, (k, d.max())
+
+
+def test_itr_c3_real_shapes():
+    fx = load("g_itr_c3")
+    cfg = itr_cfg(fx)
+    import torch
+    from llm_bci_amd.itransformer import reference_order_init   # host-side init (pure torch CPU): bit-equal to the reference
+    p = reference_order_init(cfg_shapes=dict(T=cfg["max_n_bins"], H=cfg["hidden"], L=cfg["n_layers"], nh=cfg["n_heads"],
+                                             C=cfg["max_n_channels"], use_cls=True, mlp_decoder=True), seed=1)
+    p = {k: v.numpy() for k, v in p.items()}
+    for k in p:
+        idx = fx["w0idx:" + k]
+        assert np.array_equal(p[k].reshape(-1)[idx], fx["w0val:" + k]), k
+    batch = itr_batch(fx)
+    m = fx["eval_raw_mask"]
+    out, _ = OI.forward(cfg, p, batch, masked_of(batch["spikes"], m), m, train=False)
+    np.testing.assert_allclose(out["preds"][:, ::3, ::5], fx["eval_preds"], atol=1e-3)
+    np.testing.assert_allclose(out["encoder_out"][..., ::37], fx["encoder_out"], atol=1e-3)
+    np.testing.assert_allclose(out["loss"], fx["eval_loss"], rtol=1e-4)
+    assert int(out["n_examples"]) == int(fx["eval_n_examples"])
+    mk = fx["raw_mask_step0"]
+    out, cache = OI.forward(cfg, p, batch, masked_of(batch["spikes"], mk), mk, train=True)
+    np.testing.assert_allclose(out["loss"], fx["loss_step0"], rtol=1e-4)
+    g = OI.backward(cache)
+    for k in p:
+        gs = fx["gsum:" + k]
+        ref = fx["gval:" + k]
+        got = g[k].reshape(-1)[fx["gidx:" + k]]
+        np.testing.assert_allclose(got, ref, atol=1e-5 + 1e-3 * max(np.abs(ref).max(), gs[1] / g[k].size), err_msg=k)
+
+
+def test_masker_rules_match_reference_structure():
+    """The reference's draws are torch's; what is pinned: axis structure of each mode, replacement rules, expand_timesteps."""
+    fx = load("masker_cases")
+    sp = fx["spikes"]
+    for w in (1, 2, 3, 4):
+        assert np.array_equal(OI.expand_timesteps(fx["expand_in"].astype(bool), w), fx[f"expand_{w}"]), w
+    base = dict(active=True, force_active=True, ratio=0.3, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1)
+    for mode in ("temporal", "neuron", "random", "co-smooth"):
+        mc = dict(base, mode=mode, channels=[1, 5, 7])
+        out, mask = OI.masker(mc, sp, True, seed=11, site=OI.SITE_MASKER)
+        ref_mask, ref_out = fx[mode + "_mask"], fx[mode + "_out"]
+        for mm, oo in ((mask, out), (ref_mask, ref_out)):      # same structural invariants on both
+            if mode == "temporal":
+                assert (mm == mm[:, :, :1]).all()
+            if mode == "neuron":
+                assert (mm == mm[:, :1, :]).all()
+            if mode == "co-smooth":
+                assert (mm == mm[:1, :1, :]).all() and set(np.nonzero(mm[0, 0])[0]) == {1, 5, 7}
+            assert (oo[mm.astype(bool)] == 0).all() and np.array_equal(oo[~mm.astype(bool)], sp[~mm.astype(bool)])
+        if mode != "co-smooth":
+            assert 0.1 < mask.mean() < 0.55
+    mc = dict(base, mode="random", zero_ratio=0.5, random_ratio=0.5)
+    out, mask = OI.masker(mc, sp, True, seed=3, site=OI.SITE_MASKER)
+    for mm, oo in ((mask, out), (fx["random_mixed_mask"], fx["random_mixed_out"])):
+        mb = mm.astype(bool)
+        assert np.array_equal(oo[~mb], sp[~mb])
+        changed = oo[mb] != sp[mb]
+        assert 0.3 < (oo[mb] == 0).mean() < 0.85 and changed.any()
+        assert oo.max() <= sp.max() + 1e-6
+    # inactive / eval pass-through (masker.py:50-51)
+    out, mask = OI.masker(dict(base, mode="neuron", force_active=False), sp, False, 1, OI.SITE_MASKER)
+    assert np.array_equal(out, sp) and mask.sum() == 0
+    out, mask = OI.masker(dict(base, mode="temporal", expand_prob=1.0, max_timespan=3), sp, True, 5, OI.SITE_MASKER)
+    assert (mask == mask[:, :, :1]).all()
