@@ -265,6 +265,89 @@ int nbci_ndt1_forward(nbci_ndt1_plan plan, const float* params, const void* para
 int nbci_ndt1_backward(nbci_ndt1_plan plan, const float* params, const void* params_lp, const nbci_ndt1_io* io,
                        float* grads, int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Masker.forward (models/masker.py:44-104) on the device. The mask bit of an element comes from the counter RNG
+ * (site), keyed by the index the mode makes it constant along: temporal = (b,t) (widened by `timespan`, the
+ * reference's expand_timesteps :107-110), neuron = (b,n), random = (b,t,n); TABLE_BN / TABLE_N take the
+ * Bernoulli probability from `probs` ((B,N): `region` mode, the host maps region names; (N): `co-smooth`);
+ * GIVEN uses `ext_mask` as is (tests, replay). Then zero_ratio of the masked elements are zeroed (site+1) and
+ * random_ratio of the remaining masked ones become U(0, max(out)) (site+2, site+3). `out` may alias `in` (the
+ * reference mutates its input); `mask` is overwritten, or OR-ed into when `accumulate` (itransformer.py:324-326).
+ * scratch: 4 bytes of device memory. */
+enum { NBCI_MASK_TEMPORAL = 0, NBCI_MASK_NEURON = 1, NBCI_MASK_RANDOM = 2, NBCI_MASK_TABLE_BN = 3, NBCI_MASK_TABLE_N = 4,
+       NBCI_MASK_GIVEN = 5 };
+typedef struct nbci_masker_desc {
+    int32_t B, T, N;
+    int32_t mode;
+    float ratio;               /* Bernoulli probability (temporal: already divided by timespan, masker.py:59) */
+    int32_t timespan;          /* temporal mode: width of the expansion (1 = none) */
+    float zero_ratio, random_ratio;
+    const float* probs;
+    const int64_t* ext_mask;   /* (B,T,N) for NBCI_MASK_GIVEN */
+    uint32_t seed, site;
+    const float* in;           /* (B,T,N) f32 */
+    float* out;                /* (B,T,N) f32 */
+    int64_t* mask;             /* (B,T,N) int64 0/1 */
+    int32_t accumulate;
+    void* scratch;
+} nbci_masker_desc;
+int nbci_masker(const nbci_masker_desc* desc, nbci_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * iTransformer SSL model level: iTransformerEncoder.forward (`mlp` embedder) + iTransformer.forward, method
+ * "mlm" (models/itransformer.py:175-210, 312-359) and their autograd graph. Maskers run before it (nbci_masker).
+ * Post-norm torch.nn.TransformerEncoderLayer semantics (packed in_proj, dropout on attention probabilities,
+ * dropout1/2, inner FFN dropout), no attention mask, CLS token first, mlm decoder on the channel tokens.
+ */
+enum { NBCI_LOSS_POISSON_LOG = 0, NBCI_LOSS_POISSON_RATE = 1, NBCI_LOSS_MSE = 2 };
+typedef struct nbci_itr_config { /* configs/itransformer.yaml, flattened */
+    int32_t max_n_bins;              /* T: the embedding MLP's input width (must be a multiple of 4) */
+    int32_t hidden, n_heads, n_layers;
+    int32_t max_n_channels;          /* 0: no channel embeddings */
+    int32_t n_regions;               /* 0: embed_region false */
+    int32_t act;                     /* NBCI_ACT_RELU (encoder + embedder activation) */
+    int32_t dec_act;
+    float embed_dropout, dropout;
+    int32_t use_cls, mlp_decoder;
+    int32_t loss;                    /* NBCI_LOSS_* (poisson_nll with log_input true/false, mse) */
+    int32_t dtype;
+} nbci_itr_config;
+
+typedef struct nbci_itr_io {
+    int32_t B, N;                       /* batch, channels (tokens = N + use_cls) */
+    const float* spikes;                /* (B,T,N) f32 untouched input = the mlm targets (itransformer.py:319) */
+    const float* masked;                /* (B,T,N) f32 after the maskers */
+    const int64_t* mask;                /* (B,T,N) OR of the maskers' masks */
+    const int64_t* spikes_mask;         /* (B,T) padding mask */
+    const int64_t* spikes_spacestamp;   /* (B,N) channel ids or NULL = arange(N) */
+    const int64_t* region_idx;          /* (B,N) region ids when n_regions > 0 */
+    int32_t train, want_grad;
+    uint32_t seed;
+    float grad_scale;
+    float* preds;                       /* out (B,T,N) f32 */
+    int64_t* mask_out;                  /* out (B,T,N): mask & spikes_mask (itransformer.py:343) */
+    float* loss;                        /* out (1): masked loss sum */
+    int64_t* n_examples;                /* out (1): mask_out.sum() */
+    void* hidden_out;                   /* out (B,S,H) final-norm output in cfg.dtype, or NULL */
+    void* workspace;
+    int64_t workspace_bytes;
+} nbci_itr_io;
+
+typedef void* nbci_itr_plan;
+int nbci_itr_plan_create(const nbci_itr_config* cfg, nbci_itr_plan* out);
+void nbci_itr_plan_destroy(nbci_itr_plan plan);
+/* flat parameter buffer as for NDT1: segment 0 = embedding side, 1..L = layers, L+1 = final norm + decoder */
+int64_t nbci_itr_param_count(nbci_itr_plan plan);
+int32_t nbci_itr_num_params(nbci_itr_plan plan);
+int32_t nbci_itr_num_segments(nbci_itr_plan plan);
+int nbci_itr_param_info(nbci_itr_plan plan, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
+                        int32_t* rows, int32_t* cols, int32_t* segment);
+int nbci_itr_segment_range(nbci_itr_plan plan, int32_t seg, int64_t* begin, int64_t* end);
+int64_t nbci_itr_workspace_bytes(nbci_itr_plan plan, int32_t B, int32_t N);
+int nbci_itr_forward(nbci_itr_plan plan, const float* params, const void* params_lp, const nbci_itr_io* io, nbci_stream_t stream);
+int nbci_itr_backward(nbci_itr_plan plan, const float* params, const void* params_lp, const nbci_itr_io* io, float* grads,
+                      int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

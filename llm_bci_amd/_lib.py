@@ -65,7 +65,45 @@ class NDT1IO(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
+class MaskerDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("mode", C.c_int32), ("ratio", C.c_float),
+                ("timespan", C.c_int32), ("zero_ratio", C.c_float), ("random_ratio", C.c_float), ("probs", C.c_void_p),
+                ("ext_mask", C.c_void_p), ("seed", C.c_uint32), ("site", C.c_uint32), ("in_", C.c_void_p), ("out", C.c_void_p),
+                ("mask", C.c_void_p), ("accumulate", C.c_int32), ("scratch", C.c_void_p)]
+
+
+MASK_MODE = {"temporal": 0, "neuron": 1, "random": 2, "region": 3, "co-smooth": 4, "given": 5}
+LOSS_KIND = {("poisson_nll", True): 0, ("poisson_nll", False): 1, ("mse", True): 2, ("mse", False): 2}
+
+
+class ItrConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("max_n_bins", "hidden", "n_heads", "n_layers", "max_n_channels", "n_regions", "act",
+                                         "dec_act")] + [("embed_dropout", C.c_float), ("dropout", C.c_float)] + [
+        (n, C.c_int32) for n in ("use_cls", "mlp_decoder", "loss", "dtype")]
+
+
+class ItrIO(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("spikes", C.c_void_p), ("masked", C.c_void_p), ("mask", C.c_void_p),
+                ("spikes_mask", C.c_void_p), ("spikes_spacestamp", C.c_void_p), ("region_idx", C.c_void_p),
+                ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
+                ("preds", C.c_void_p), ("mask_out", C.c_void_p), ("loss", C.c_void_p), ("n_examples", C.c_void_p),
+                ("hidden_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 _SIGNATURES = {
+    "nbci_masker": (C.c_int, [C.POINTER(MaskerDesc), C.c_void_p]),
+    "nbci_itr_plan_create": (C.c_int, [C.POINTER(ItrConfig), C.POINTER(C.c_void_p)]),
+    "nbci_itr_plan_destroy": (None, [C.c_void_p]),
+    "nbci_itr_param_count": (C.c_int64, [C.c_void_p]),
+    "nbci_itr_num_params": (C.c_int32, [C.c_void_p]),
+    "nbci_itr_num_segments": (C.c_int32, [C.c_void_p]),
+    "nbci_itr_param_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "nbci_itr_segment_range": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nbci_itr_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "nbci_itr_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ItrIO), C.c_void_p]),
+    "nbci_itr_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ItrIO), C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
     "nbci_ndt1_plan_create": (C.c_int, [C.POINTER(NDT1Config), C.POINTER(C.c_void_p)]),
     "nbci_ndt1_plan_destroy": (None, [C.c_void_p]),
     "nbci_ndt1_param_count": (C.c_int64, [C.c_void_p]),

@@ -82,3 +82,20 @@ def ndt1_config(config):
     """Model defaults merged with `config`, preferring a cwd-relative configs/ndt1.yaml if present."""
     base = "configs/ndt1.yaml" if os.path.exists("configs/ndt1.yaml") else ndt1_defaults()
     return update_config(base, config if config is not None else {})
+
+
+def itransformer_defaults():
+    """Built-in iTransformer model defaults (values of the reference's configs/itransformer.yaml)."""
+    masker = dict(force_active=True, mode="neuron", ratio=0.1, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1,
+                  channels=None, timesteps=None, mask_regions=None, target_regions=None, n_mask_regions=1)
+    enc = dict(from_pt=None,
+               embedder=dict(mode="mlp", activation="relu", dropout=0.2, n_heads=4, hidden_size=128, n_layers=4, max_n_bins=100),
+               hidden_size=768, activation="relu", bias=True, dropout=0.4, n_heads=8, n_layers=5, max_n_channels=1500,
+               embed_region=True, embed_depth=False, regions=None)
+    return dict(model_class="iTransformer", masker=dict(main=masker), encoder=enc,
+                decoder=dict(from_pt=None, mlp_decoder=True, activation="relu", use_cls=True))
+
+
+def itransformer_config(config):
+    base = "configs/itransformer.yaml" if os.path.exists("configs/itransformer.yaml") else itransformer_defaults()
+    return update_config(base, config if config is not None else {})

@@ -1,0 +1,360 @@
+// itr_kernels.hip — the non-GEMM kernels that only the iTransformer SSL path needs (models/masker.py,
+// models/itransformer.py). All HBM-bound: one pass over the (B,T,N) spike tensor each, transposes go
+// through a padded LDS tile so both sides stay coalesced. See kernels.h for the launch API.
+#include "kernels.h"
+
+namespace nbci {
+
+template <typename T> __device__ __forceinline__ void stv(T* p, long long i, float v);
+template <> __device__ __forceinline__ void stv<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stv<bf16_t>(bf16_t* p, long long i, float v) { p[i] = f2bf(v); }
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+// 24-bit uniform in [0,1) from the counter RNG (mirrored by oracle/itransformer.py uniform())
+__device__ __forceinline__ float uni24(uint32_t seed, uint32_t site, uint32_t idx) {
+    return (float)(rng_u32(seed, site, idx) >> 8) * (1.0f / 16777216.0f);
+}
+// order-preserving float <-> uint map, so the tensor maximum can use atomicMax
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+// ------------------------------------------------------------------------------------------
+// Masker.forward (models/masker.py:44-104)
+// ------------------------------------------------------------------------------------------
+// pass 1: mask bit per element (constant along the axes the mode says), zero `zero_ratio` of the masked
+// elements, tensor maximum of the result (needed by the random replacement, masker.py:101).
+__global__ __launch_bounds__(256) void masker_zero_kernel(nbci_masker_desc d, unsigned* __restrict__ maxbits) {
+    const long long n = (long long)d.B * d.T * d.N;
+    float mx = -INFINITY;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % d.N);
+        const long long bt = i / d.N;
+        const int t = (int)(bt % d.T), b = (int)(bt / d.T);
+        bool m = false;
+        switch (d.mode) {
+            case NBCI_MASK_TEMPORAL: {   // bernoulli over (B,T), optionally widened: conv1d(..., ones(span), 'same') >= 1
+                const int left = (d.timespan - 1) / 2;
+                for (int j = 0; j < d.timespan; ++j) {
+                    const int tt = t - left + j;
+                    if (tt >= 0 && tt < d.T) m = m || (uni24(d.seed, d.site, (uint32_t)(b * d.T + tt)) < d.ratio);
+                }
+                break;
+            }
+            case NBCI_MASK_NEURON: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.ratio; break;
+            case NBCI_MASK_RANDOM: m = uni24(d.seed, d.site, (uint32_t)i) < d.ratio; break;
+            case NBCI_MASK_TABLE_BN: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.probs[b * d.N + c]; break;
+            case NBCI_MASK_TABLE_N: m = uni24(d.seed, d.site, (uint32_t)c) < d.probs[c]; break;
+            default: m = d.ext_mask[i] != 0; break;   // NBCI_MASK_GIVEN
+        }
+        float v = d.in[i];
+        if (m && uni24(d.seed, d.site + 1, (uint32_t)i) < d.zero_ratio) v = 0.f;
+        d.out[i] = v;
+        d.mask[i] = d.accumulate ? (d.mask[i] | (long long)m) : (long long)m;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, f2ord(mx));
+}
+
+// pass 2: of the masked elements that were not zeroed, `random_ratio` become U(0, max) (masker.py:100-102)
+__global__ __launch_bounds__(256) void masker_random_kernel(nbci_masker_desc d, const unsigned* __restrict__ maxbits) {
+    const long long n = (long long)d.B * d.T * d.N;
+    const float mx = ord2f(*maxbits);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % d.N);
+        const long long bt = i / d.N;
+        const int t = (int)(bt % d.T), b = (int)(bt / d.T);
+        bool m = false;
+        switch (d.mode) {
+            case NBCI_MASK_TEMPORAL: {
+                const int left = (d.timespan - 1) / 2;
+                for (int j = 0; j < d.timespan; ++j) {
+                    const int tt = t - left + j;
+                    if (tt >= 0 && tt < d.T) m = m || (uni24(d.seed, d.site, (uint32_t)(b * d.T + tt)) < d.ratio);
+                }
+                break;
+            }
+            case NBCI_MASK_NEURON: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.ratio; break;
+            case NBCI_MASK_RANDOM: m = uni24(d.seed, d.site, (uint32_t)i) < d.ratio; break;
+            case NBCI_MASK_TABLE_BN: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.probs[b * d.N + c]; break;
+            case NBCI_MASK_TABLE_N: m = uni24(d.seed, d.site, (uint32_t)c) < d.probs[c]; break;
+            default: m = d.ext_mask[i] != 0; break;
+        }
+        if (!m) continue;
+        if (uni24(d.seed, d.site + 1, (uint32_t)i) < d.zero_ratio) continue;   // zeroed in pass 1
+        if (uni24(d.seed, d.site + 2, (uint32_t)i) < d.random_ratio) d.out[i] = mx * uni24(d.seed, d.site + 3, (uint32_t)i);
+    }
+}
+
+int masker_launch(const nbci_masker_desc& d, hipStream_t s) {
+    NBCI_REQUIRE(d.B > 0 && d.T > 0 && d.N > 0, NBCI_ESHAPE, "masker: B, T, N must be positive");
+    NBCI_REQUIRE(d.in && d.out && d.mask && d.scratch, NBCI_EINVAL, "masker: in, out, mask and scratch are required");
+    NBCI_REQUIRE(d.mode >= NBCI_MASK_TEMPORAL && d.mode <= NBCI_MASK_GIVEN, NBCI_EINVAL, "masker: unknown mode");
+    NBCI_REQUIRE(!((d.mode == NBCI_MASK_TABLE_BN || d.mode == NBCI_MASK_TABLE_N) && !d.probs), NBCI_EINVAL, "masker: probs table required");
+    NBCI_REQUIRE(!(d.mode == NBCI_MASK_GIVEN && !d.ext_mask), NBCI_EINVAL, "masker: ext_mask required");
+    NBCI_REQUIRE(d.mode != NBCI_MASK_TEMPORAL || (d.timespan >= 1 && d.timespan <= 64), NBCI_EINVAL, "masker: timespan must be in 1..64");
+    NBCI_REQUIRE((long long)d.B * d.T * d.N < (1ll << 32), NBCI_ESHAPE, "masker: tensor too large for the 32-bit RNG counter");
+    const long long n = (long long)d.B * d.T * d.N;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    NBCI_CHECK_HIP(hipMemsetAsync(d.scratch, 0, 4, s));   // ordered-uint encoding: 0 < every float
+    hipLaunchKernelGGL(masker_zero_kernel, dim3(blocks), dim3(256), 0, s, d, (unsigned*)d.scratch);
+    int rc = check_launch("masker_zero");
+    if (rc != NBCI_OK) return rc;
+    if (d.random_ratio > 0.f && d.zero_ratio < 1.f) {
+        hipLaunchKernelGGL(masker_random_kernel, dim3(blocks), dim3(256), 0, s, d, (const unsigned*)d.scratch);
+        rc = check_launch("masker_random");
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// (B,T,N) -> (B*N, T) f32: the channel-as-token view the embedding MLP reads (itransformer.py:187)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void btn_to_bnt_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int N) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, n = n0 + tx;
+        tile[r][tx] = (t < T && n < N) ? in[((long long)b * T + t) * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, t = t0 + tx;
+        if (n < N && t < T) out[((long long)b * N + n) * T + t] = tile[tx][r];
+    }
+}
+
+int btn_to_bnt_launch(const float* in, float* out, int B, int T, int N, hipStream_t s) {
+    hipLaunchKernelGGL(btn_to_bnt_kernel, dim3((N + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, in, out, T, N);
+    return check_launch("btn_to_bnt");
+}
+
+// ------------------------------------------------------------------------------------------
+// token assembly (itransformer.py:187-209): row (b,0) = cls; row (b,1+n) = LN_e(t2[b,n]) + LN_c(E_c)[ss[b,n]]
+// (+ region table), then embed dropout over the whole (B,S,H) tensor. One wave per row.
+// ------------------------------------------------------------------------------------------
+template <int NV, typename TO>
+__global__ __launch_bounds__(256) void itr_assemble_fwd_kernel(const float* __restrict__ t2, const float* __restrict__ w,
+                                                               const float* __restrict__ bia, const float* __restrict__ tab1,
+                                                               const long long* __restrict__ idx1, const float* __restrict__ tab2,
+                                                               const long long* __restrict__ idx2, const float* __restrict__ cls,
+                                                               float* __restrict__ x32, TO* __restrict__ xb, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int B, int N, int H, int use_cls,
+                                                               unsigned thr, float dscale, uint32_t key) {
+    const int lane = threadIdx.x & 63;
+    const int S = N + use_cls;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * S) return;
+    const int b = (int)(row / S), sidx = (int)(row % S);
+    float4 v[NV];
+    if (use_cls && sidx == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            v[k] = (c < H) ? *(const float4*)(cls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        const long long r0 = (long long)b * N + (sidx - use_cls);
+        const float* xr = t2 + r0 * H;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            v[k] = (c < H) ? *(const float4*)(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sum += v[k].x + v[k].y + v[k].z + v[k].w;
+        }
+        const float mu = wave_sum(sum) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            if (c < H) {
+                const float a = v[k].x - mu, b2 = v[k].y - mu, c2 = v[k].z - mu, d2 = v[k].w - mu;
+                q += a * a + b2 * b2 + c2 * c2 + d2 * d2;
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+        if (lane == 0) { mean[r0] = mu; rstd[r0] = rs; }
+        const float* e1 = tab1 ? tab1 + idx1[r0] * H : nullptr;
+        const float* e2 = tab2 ? tab2 + idx2[r0] * H : nullptr;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 64 + lane) * 4;
+            if (c < H) {
+                const float4 ww = *(const float4*)(w + c), bv = *(const float4*)(bia + c);
+                float4 r = make_float4((v[k].x - mu) * rs * ww.x + bv.x, (v[k].y - mu) * rs * ww.y + bv.y,
+                                       (v[k].z - mu) * rs * ww.z + bv.z, (v[k].w - mu) * rs * ww.w + bv.w);
+                if (e1) { const float4 e = *(const float4*)(e1 + c); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
+                if (e2) { const float4 e = *(const float4*)(e2 + c); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
+                v[k] = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < H) {
+            const long long o = row * H + c;
+            float r[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            if (thr) drop4(key, thr, (unsigned)o, dscale, r);
+            *(float4*)(x32 + o) = make_float4(r[0], r[1], r[2], r[3]);
+            stv<TO>(xb, o + 0, r[0]); stv<TO>(xb, o + 1, r[1]); stv<TO>(xb, o + 2, r[2]); stv<TO>(xb, o + 3, r[3]);
+        }
+    }
+}
+
+int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, const float* tab1, const int64_t* idx1, const float* tab2,
+                            const int64_t* idx2, const float* cls, float* x32, void* xb, int xb_dtype, float* mean, float* rstd, int B,
+                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "itr assemble: hidden must be a multiple of 4 and <= 4096");
+    NBCI_REQUIRE((long long)B * (N + use_cls) * H < (1ll << 32), NBCI_ESHAPE, "itr assemble: tensor too large for the dropout counter");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const long long rows = (long long)B * (N + use_cls);
+    dim3 g((unsigned)((rows + 3) / 4));
+    const int nv = (H + 255) / 256;
+#define ASM(NVV, TO)                                                                                                        \
+    hipLaunchKernelGGL((itr_assemble_fwd_kernel<NVV, TO>), g, dim3(256), 0, s, t2, w, b, tab1, (const long long*)idx1, tab2,    \
+                       (const long long*)idx2, cls, x32, (TO*)xb, mean, rstd, B, N, H, use_cls, thr, dscale, drop_key(seed, site))
+    if (xb_dtype == NBCI_BF16) { if (nv <= 4) ASM(4, bf16_t); else ASM(16, bf16_t); }
+    else { if (nv <= 4) ASM(4, float); else ASM(16, float); }
+#undef ASM
+    return check_launch("itr_assemble_fwd");
+}
+
+// backward of the assembly: d = dx0 * keepmask; cls grad += sum_b d[b,0]; dtok[(b,n)] = d[b,1+n]; dtab[idx[b,n]] += d[b,1+n]
+__global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const float* __restrict__ dx0, float* __restrict__ dtok,
+                                                               float* __restrict__ dtab1, const long long* __restrict__ idx1,
+                                                               float* __restrict__ dtab2, const long long* __restrict__ idx2,
+                                                               float* __restrict__ dcls, RepCfg rc, int B, int N, int H, int use_cls,
+                                                               unsigned thr, float dscale, uint32_t key) {
+    const int S = N + use_cls;
+    const long long row = (long long)blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= H) return;
+    const int b = (int)(row / S), sidx = (int)(row % S);
+    const long long o = row * H + c;
+    const float4 g4 = *(const float4*)(dx0 + o);
+    float r[4] = {g4.x, g4.y, g4.z, g4.w};
+    if (thr) drop4(key, thr, (unsigned)o, dscale, r);
+    if (use_cls && sidx == 0) {
+        float* dc = rep_ptr(dcls, rc, (unsigned)b) + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dc + e, r[e]);
+        return;
+    }
+    const long long r0 = (long long)b * N + (sidx - use_cls);
+    *(float4*)(dtok + r0 * H + c) = make_float4(r[0], r[1], r[2], r[3]);
+    if (dtab1) {
+        float* p = dtab1 + idx1[r0] * H + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(p + e, r[e]);
+    }
+    if (dtab2) {
+        float* p = dtab2 + idx2[r0] * H + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(p + e, r[e]);
+    }
+}
+
+int itr_assemble_bwd_launch(const float* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
+                            float* dcls, RepCfg rc, int B, int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site,
+                            hipStream_t s) {
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    dim3 g((H / 4 + 255) / 256, (unsigned)((long long)B * (N + use_cls)));
+    hipLaunchKernelGGL(itr_assemble_bwd_kernel, g, dim3(256), 0, s, dx0, dtok, dtab1, (const long long*)idx1, dtab2,
+                       (const long long*)idx2, dcls, rc, B, N, H, use_cls, thr, dscale, drop_key(seed, site));
+    return check_launch("itr_assemble_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// mlm head tail (itransformer.py:339-352): pred[(b,1+n), t] -> preds (B,T,N); masked Poisson-NLL / MSE sum;
+// n_examples; d(loss)/d(pred) back in the token-row layout (operand dtype, zero in CLS rows and pad columns).
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void itr_mlm_loss_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ targets,
+                                                           const long long* __restrict__ mask, const long long* __restrict__ smask,
+                                                           float* __restrict__ preds_out, long long* __restrict__ mask_out,
+                                                           TO* __restrict__ dpred, float* __restrict__ loss,
+                                                           unsigned long long* __restrict__ nex, int T, int N, int use_cls, int kind,
+                                                           float gscale) {
+    __shared__ float tp[32][33];   // [n][t] raw prediction
+    __shared__ float tg[32][33];   // [n][t] gradient
+    __shared__ float red[4];
+    __shared__ unsigned cnt[4];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int S = N + use_cls;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {   // read rows n, lanes along t (contiguous in the GEMM output)
+        const int n = n0 + r, t = t0 + tx;
+        tp[r][tx] = (n < N && t < T) ? pred[((long long)b * S + use_cls + n) * ldp + t] : 0.f;
+    }
+    __syncthreads();
+    float lsum = 0.f;
+    unsigned lcnt = 0;
+    for (int r = ty; r < 32; r += 8) {   // rows t, lanes along n (contiguous in (B,T,N))
+        const int t = t0 + r, n = n0 + tx;
+        float g = 0.f;
+        if (t < T && n < N) {
+            const long long i = ((long long)b * T + t) * N + n;
+            const float raw = tp[tx][r];
+            const float y = targets[i];
+            const long long m = mask[i] & smask[(long long)b * T + t];
+            float p = raw, el, dl;
+            if (kind == NBCI_LOSS_POISSON_LOG) { const float e = expf(p); el = e - y * p; dl = e - y; }
+            else if (kind == NBCI_LOSS_POISSON_RATE) { p = fmaxf(raw, 0.f); el = p - y * logf(p + 1e-8f); dl = (raw > 0.f) ? 1.f - y / (p + 1e-8f) : 0.f; }
+            else { const float df = p - y; el = df * df; dl = 2.f * df; }
+            preds_out[i] = p;
+            mask_out[i] = m;
+            if (m) { lsum += el; ++lcnt; g = dl * gscale; }
+        }
+        tg[tx][r] = g;
+    }
+    __syncthreads();
+    if (dpred) {
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, t = t0 + tx;
+            if (n < N && t < T) stv<TO>(dpred, ((long long)b * S + use_cls + n) * ldp + t, tg[r][tx]);
+        }
+    }
+    lsum = wave_sum(lsum);
+    float fc = wave_sum((float)lcnt);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lsum; cnt[threadIdx.x >> 6] = (unsigned)fc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(nex, (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));
+    }
+}
+
+int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const int64_t* mask, const int64_t* smask, float* preds_out,
+                        int64_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int N, int use_cls,
+                        int kind, float grad_scale, hipStream_t s) {
+    NBCI_REQUIRE(kind >= NBCI_LOSS_POISSON_LOG && kind <= NBCI_LOSS_MSE, NBCI_EINVAL, "mlm loss: unknown loss kind");
+    NBCI_CHECK_HIP(hipMemsetAsync(loss, 0, 4, s));
+    NBCI_CHECK_HIP(hipMemsetAsync(n_examples, 0, 8, s));
+    if (dpred)   // CLS rows and the pad columns (ldp > T) must read as zeros in the backward GEMMs
+        NBCI_CHECK_HIP(hipMemsetAsync(dpred, 0, (size_t)B * (N + use_cls) * ldp * (d_dtype == NBCI_BF16 ? 2 : 4), s));
+    dim3 g((N + 31) / 32, (T + 31) / 32, B);
+    if (d_dtype == NBCI_BF16)
+        hipLaunchKernelGGL((itr_mlm_loss_kernel<bf16_t>), g, dim3(256), 0, s, pred, ldp, targets, (const long long*)mask,
+                           (const long long*)smask, preds_out, (long long*)mask_out, (bf16_t*)dpred, loss,
+                           (unsigned long long*)n_examples, T, N, use_cls, kind, grad_scale);
+    else
+        hipLaunchKernelGGL((itr_mlm_loss_kernel<float>), g, dim3(256), 0, s, pred, ldp, targets, (const long long*)mask,
+                           (const long long*)smask, preds_out, (long long*)mask_out, (float*)dpred, loss,
+                           (unsigned long long*)n_examples, T, N, use_cls, kind, grad_scale);
+    return check_launch("itr_mlm_loss");
+}
+
+}  // namespace nbci

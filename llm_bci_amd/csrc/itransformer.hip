@@ -1,0 +1,607 @@
+// itransformer.hip — host-side orchestration of the iTransformer SSL (mlm) forward/backward on one stream.
+//
+// Replaces iTransformerEncoder.forward in `mlp` embedder mode + iTransformer.forward, method "mlm"
+// (models/itransformer.py:175-210, 312-359) and their autograd graph: channel-as-token embedding MLP,
+// LayerNorm'd channel/region embeddings, CLS token, post-norm torch.nn.TransformerEncoderLayer stack
+// (itransformer.py:158-173), final norm, mlm decoder, masked Poisson-NLL / MSE. The maskers run before it
+// (nbci_masker). Same conventions as ndt1.hip: ONE flat f32 parameter buffer (+ bf16 shadow), caller-owned
+// workspace, gradient segments [embedding | layer 0..L-1 | final norm + decoder] = RCCL buckets.
+//
+// Post-norm data flow per layer (x = layer input, f32 copy in a ping-pong scratch + operand-dtype copy saved):
+//   qkv = x W_in^T + b            r1 = x + drop1(attn(qkv) W_o^T + b_o)      x1 = LN1(r1)
+//   g = drop(relu(x1 W_1^T + b1)) r2 = x1 + drop2(g W_2^T + b2)              x' = LN2(r2)
+// Saved for backward: operand-dtype x, qkv, P/Pd, attn out, x1, g; f32 r1, r2 with their LN statistics.
+#include <cmath>
+#include <cstdlib>
+
+#include "plan_common.h"
+
+namespace nbci {
+
+struct ItrLayerOff {
+    int64_t inw, inb, ow, ob, w1, b1, w2, b2, n1w, n1b, n2w, n2b;
+};
+
+struct ItrPlan {
+    nbci_itr_config c;
+    std::vector<PInfo> params;
+    std::vector<ItrLayerOff> L;
+    int64_t e0w, e0b, e3w, e3b, enw, enb, chw, chnw, chnb, rgw, rgnw, rgnb, cls, fnw, fnb, d0w, d0b, d2w, d2b;
+    int64_t total;
+    std::vector<std::pair<int64_t, int64_t>> seg;
+    std::vector<int> flat_of;
+    std::vector<std::pair<int, int>> cseg;
+    std::vector<std::pair<int64_t, int>> cmap;
+    int* d_flat_of;
+    int compact_total;
+    int compact_of(int64_t flat_off) const {
+        for (size_t i = 0; i < cmap.size(); ++i) if (cmap[i].first == flat_off) return cmap[i].second;
+        return -1;
+    }
+};
+
+static int64_t itr_add(ItrPlan& p, int64_t& cur, const std::string& name, int rows, int cols, int seg) {
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    const int64_t off = cur;
+    const int64_t n = (int64_t)rows * (cols > 0 ? cols : 1);
+    p.params.push_back({name, off, n, rows, cols, seg});
+    cur += n;
+    return off;
+}
+
+static void itr_layout(ItrPlan& p) {
+    const auto& c = p.c;
+    const int H = c.hidden, T = c.max_n_bins, F = 4 * H;
+    int64_t cur = 0;
+    p.e0w = itr_add(p, cur, "encoder.embed.0.0.weight", H, T, 0);
+    p.e0b = itr_add(p, cur, "encoder.embed.0.0.bias", H, 0, 0);
+    p.e3w = itr_add(p, cur, "encoder.embed.0.3.weight", H, H, 0);
+    p.e3b = itr_add(p, cur, "encoder.embed.0.3.bias", H, 0, 0);
+    p.enw = itr_add(p, cur, "encoder.embed.1.weight", H, 0, 0);
+    p.enb = itr_add(p, cur, "encoder.embed.1.bias", H, 0, 0);
+    p.chw = p.chnw = p.chnb = p.rgw = p.rgnw = p.rgnb = p.cls = -1;
+    if (c.max_n_channels > 0) {
+        p.chw = itr_add(p, cur, "encoder.channel_embeddings.0.weight", c.max_n_channels, H, 0);
+        p.chnw = itr_add(p, cur, "encoder.channel_embeddings.1.weight", H, 0, 0);
+        p.chnb = itr_add(p, cur, "encoder.channel_embeddings.1.bias", H, 0, 0);
+    }
+    if (c.n_regions > 0) {
+        p.rgw = itr_add(p, cur, "encoder.region_embeddings.0.weight", c.n_regions, H, 0);
+        p.rgnw = itr_add(p, cur, "encoder.region_embeddings.1.weight", H, 0, 0);
+        p.rgnb = itr_add(p, cur, "encoder.region_embeddings.1.bias", H, 0, 0);
+    }
+    if (c.use_cls) p.cls = itr_add(p, cur, "encoder.cls_embed.weight", H, 0, 0);   // (1,H): summed like a bias
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    p.seg.push_back({0, cur});
+    for (int l = 0; l < c.n_layers; ++l) {
+        const int64_t begin = cur;
+        const std::string pre = "encoder.transformer.layers." + std::to_string(l) + ".";
+        ItrLayerOff o;
+        o.inw = itr_add(p, cur, pre + "self_attn.in_proj_weight", 3 * H, H, l + 1);
+        o.inb = itr_add(p, cur, pre + "self_attn.in_proj_bias", 3 * H, 0, l + 1);
+        o.ow = itr_add(p, cur, pre + "self_attn.out_proj.weight", H, H, l + 1);
+        o.ob = itr_add(p, cur, pre + "self_attn.out_proj.bias", H, 0, l + 1);
+        o.w1 = itr_add(p, cur, pre + "linear1.weight", F, H, l + 1);
+        o.b1 = itr_add(p, cur, pre + "linear1.bias", F, 0, l + 1);
+        o.w2 = itr_add(p, cur, pre + "linear2.weight", H, F, l + 1);
+        o.b2 = itr_add(p, cur, pre + "linear2.bias", H, 0, l + 1);
+        o.n1w = itr_add(p, cur, pre + "norm1.weight", H, 0, l + 1);
+        o.n1b = itr_add(p, cur, pre + "norm1.bias", H, 0, l + 1);
+        o.n2w = itr_add(p, cur, pre + "norm2.weight", H, 0, l + 1);
+        o.n2b = itr_add(p, cur, pre + "norm2.bias", H, 0, l + 1);
+        cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+        p.L.push_back(o);
+        p.seg.push_back({begin, cur});
+    }
+    const int64_t begin = cur;
+    const int hs = c.n_layers + 1;
+    p.fnw = itr_add(p, cur, "encoder.transformer.norm.weight", H, 0, hs);
+    p.fnb = itr_add(p, cur, "encoder.transformer.norm.bias", H, 0, hs);
+    p.d2w = p.d2b = -1;
+    if (c.mlp_decoder) {
+        p.d0w = itr_add(p, cur, "decoder.0.weight", H, H, hs);
+        p.d0b = itr_add(p, cur, "decoder.0.bias", H, 0, hs);
+        p.d2w = itr_add(p, cur, "decoder.2.weight", T, H, hs);
+        p.d2b = itr_add(p, cur, "decoder.2.bias", T, 0, hs);
+    } else {
+        p.d0w = itr_add(p, cur, "decoder.0.weight", T, H, hs);
+        p.d0b = itr_add(p, cur, "decoder.0.bias", T, 0, hs);
+    }
+    cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
+    p.seg.push_back({begin, cur});
+    p.total = cur;
+    int cc = 0;
+    p.cseg.assign(p.seg.size(), {0, 0});
+    int cur_seg = -1;
+    for (const PInfo& pi : p.params) {
+        if (pi.seg != cur_seg) {
+            if (cur_seg >= 0) p.cseg[cur_seg].second = cc;
+            cur_seg = pi.seg;
+            p.cseg[cur_seg].first = cc;
+        }
+        if (pi.cols != 0) continue;
+        p.cmap.push_back({pi.off, cc});
+        for (int i = 0; i < pi.rows; ++i) p.flat_of.push_back((int)(pi.off + i));
+        cc += pi.rows;
+        while (cc % 4) { p.flat_of.push_back(-1); ++cc; }
+    }
+    if (cur_seg >= 0) p.cseg[cur_seg].second = cc;
+    p.compact_total = cc;
+}
+
+// ---- workspace -------------------------------------------------------------------------------
+struct ItrLayerWS {
+    size_t xb, qkv, P, Pd, ad, r1, mean1, rstd1, x1b, g, r2, mean2, rstd2;
+};
+struct ItrWS {
+    size_t xs, h0, t2, mean_e, rstd_e, chtab, mean_c, rstd_c, dchtab, rgtab, mean_r, rstd_r, drgtab, ssidx;
+    std::vector<ItrLayerWS> L;
+    size_t yA, yB, xlast_b, mean_o, rstd_o, xo, d1, pred, dpred, scores;
+    size_t dY, dR, cA, cA2, dU, dAtt, dqkv, dS, dtok, dH0, rep;
+    size_t bytes;
+    int S, M, M0, ldS, ldP, ldT;
+};
+
+static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
+    const auto& c = p.c;
+    NBCI_REQUIRE(B > 0 && N > 0, NBCI_ESHAPE, "itransformer: B and N must be positive");
+    const int S = N + (c.use_cls ? 1 : 0);
+    NBCI_REQUIRE(S <= 2048, NBCI_ESHAPE, "itransformer: at most 2048 tokens per sample");
+    const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
+    const size_t H = c.hidden, F = 4 * H, T = c.max_n_bins;
+    const size_t M = (size_t)B * S, M0 = (size_t)B * N;
+    NBCI_REQUIRE(M * F < (1ull << 32), NBCI_ESHAPE, "itransformer: batch too large for the 32-bit dropout counter");
+    w.S = S; w.M = (int)M; w.M0 = (int)M0;
+    w.ldS = (S + 3) / 4 * 4;
+    w.ldP = (S + 7) / 8 * 8;
+    w.ldT = ((int)T + 7) / 8 * 8;
+    NBCI_REQUIRE((size_t)B * c.n_heads * S * (size_t)S < (1ull << 32), NBCI_ESHAPE, "itransformer: attention too large for the 32-bit dropout counter");
+    size_t cur = 0;
+    w.xs = bump(cur, M0 * T * 4);
+    w.h0 = bump(cur, M0 * H * es);
+    w.t2 = bump(cur, M0 * H * 4);
+    w.mean_e = bump(cur, M0 * 4); w.rstd_e = bump(cur, M0 * 4);
+    const size_t C = c.max_n_channels, R = c.n_regions;
+    w.chtab = bump(cur, C * H * 4); w.mean_c = bump(cur, C * 4 + 4); w.rstd_c = bump(cur, C * 4 + 4); w.dchtab = bump(cur, C * H * 4);
+    w.rgtab = bump(cur, R * H * 4); w.mean_r = bump(cur, R * 4 + 4); w.rstd_r = bump(cur, R * 4 + 4); w.drgtab = bump(cur, R * H * 4);
+    w.ssidx = bump(cur, M0 * 8);
+    w.L.resize(c.n_layers);
+    const size_t nP = (size_t)B * c.n_heads * S * w.ldP;
+    for (auto& l : w.L) {
+        l.xb = bump(cur, M * H * es);
+        l.qkv = bump(cur, M * 3 * H * es);
+        l.P = bump(cur, nP * es);
+        l.Pd = bump(cur, nP * es);
+        l.ad = bump(cur, M * H * es);
+        l.r1 = bump(cur, M * H * 4);
+        l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
+        l.x1b = bump(cur, M * H * es);
+        l.g = bump(cur, M * F * es);
+        l.r2 = bump(cur, M * H * 4);
+        l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
+    }
+    w.yA = bump(cur, M * H * 4);
+    w.yB = bump(cur, M * H * 4);
+    w.xlast_b = bump(cur, M * H * es);
+    w.mean_o = bump(cur, M * 4); w.rstd_o = bump(cur, M * 4);
+    w.xo = bump(cur, M * H * es);
+    w.d1 = bump(cur, M * H * es);
+    w.pred = bump(cur, M * w.ldT * 4);
+    w.dpred = bump(cur, M * w.ldT * es);
+    w.scores = bump(cur, (size_t)B * c.n_heads * S * w.ldS * 4);
+    w.dY = bump(cur, M * H * 4);
+    w.dR = bump(cur, M * H * 4);
+    w.cA = bump(cur, M * H * es);
+    w.cA2 = bump(cur, M * H * es);
+    w.dU = bump(cur, M * F * es);
+    w.dAtt = bump(cur, M * H * es);
+    w.dqkv = bump(cur, M * 3 * H * es);
+    w.dS = bump(cur, nP * es);
+    w.dtok = bump(cur, M0 * H * 4);
+    w.dH0 = bump(cur, M0 * H * 4);
+    w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
+    w.bytes = (cur + 255) / 256 * 256;
+    return NBCI_OK;
+}
+
+static int itr_validate(const ItrPlan& p, const nbci_itr_io* io) {
+    NBCI_REQUIRE(io, NBCI_EINVAL, "itransformer: null io");
+    NBCI_REQUIRE(io->spikes && io->masked && io->mask && io->spikes_mask, NBCI_EINVAL,
+                 "itransformer: spikes, masked, mask and spikes_mask are required");
+    NBCI_REQUIRE(io->workspace, NBCI_EWORKSPACE, "itransformer: null workspace");
+    NBCI_REQUIRE(((uintptr_t)io->workspace) % 256 == 0, NBCI_EALIGN, "itransformer: workspace must be 256-byte aligned");
+    NBCI_REQUIRE(!(p.c.n_regions > 0 && !io->region_idx), NBCI_EINVAL, "itransformer: region_idx required when embed_region is on");
+    NBCI_REQUIRE(io->N <= p.c.max_n_channels || p.c.max_n_channels == 0 || io->spikes_spacestamp, NBCI_ESHAPE,
+                 "itransformer: more channels than max_n_channels");
+    return NBCI_OK;
+}
+
+__global__ void itr_iota_kernel(long long* out, int B, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * N) out[i] = i % N;
+}
+
+struct ItrCtx {
+    const ItrPlan& p;
+    const float* pf;
+    const void* pw;
+    size_t es;
+    char* ws;
+    ItrWS w;
+    hipStream_t s;
+    const void* W(int64_t off) const { return (const char*)pw + off * (int64_t)es; }
+};
+
+int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, const nbci_itr_io* io, hipStream_t s) {
+    TRY(itr_validate(p, io));
+    const auto& c = p.c;
+    NBCI_REQUIRE(params, NBCI_EINVAL, "itransformer: null params");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || params_lp, NBCI_EINVAL, "itransformer: bf16 mode needs the bf16 parameter shadow");
+    NBCI_REQUIRE(io->preds && io->loss && io->n_examples && io->mask_out, NBCI_EINVAL, "itransformer: preds, mask_out, loss, n_examples outputs are required");
+    ItrCtx x{p, params, c.dtype == NBCI_BF16 ? params_lp : (const void*)params, (size_t)(c.dtype == NBCI_BF16 ? 2 : 4),
+             (char*)io->workspace, {}, s};
+    const int B = io->B, N = io->N;
+    TRY(itr_carve(p, B, N, x.w));
+    NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "itransformer: workspace too small");
+    const ItrWS& w = x.w;
+    const int S = w.S, M = w.M, M0 = w.M0, H = c.hidden, F = 4 * H, T = c.max_n_bins, nh = c.n_heads, hd = H / nh;
+    const int dt = c.dtype;
+    const size_t es = x.es;
+    const bool train = io->train != 0;
+    const float pe = train ? c.embed_dropout : 0.f, pl = train ? c.dropout : 0.f;
+    char* ws = x.ws;
+
+    if (io->want_grad) {
+        NBCI_CHECK_HIP(hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * p.compact_total * 4, s));
+        if (c.max_n_channels > 0) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dchtab, 0, (size_t)c.max_n_channels * H * 4, s));
+        if (c.n_regions > 0) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.drgtab, 0, (size_t)c.n_regions * H * 4, s));
+    }
+    // 0. channel-as-token view of the masked spikes (itransformer.py:187)
+    TRY(btn_to_bnt_launch(io->masked, (float*)(ws + w.xs), B, T, N, s));
+    // 1. embedding MLP (torchvision MLP: Linear, act, Dropout, Linear, Dropout; itransformer.py:110-116). The first
+    //    Linear has K = max_n_bins (100: rows of the bf16 shadow would not be 16-byte aligned) and 0.1 % of the
+    //    FLOPs: it runs on the exact-f32 MFMA path straight from the f32 parameters.
+    {
+        nbci_gemm_desc d = gd(M0, H, T, NBCI_F32, op(ws + w.xs, 4, 0, T, 1), op(params, 4, p.e0w, T, 1), ws + w.h0, H, dt);
+        d.bias = params + p.e0b; d.act = c.act; d.drop_p = pe; d.seed = io->seed; d.site = 4;
+        TRY(gemm_launch_timed(d, s));
+    }
+    {
+        nbci_gemm_desc d = gd(M0, H, H, dt, op(ws + w.h0, es, 0, H, 1), op(x.W(p.e3w), es, 0, H, 1), ws + w.t2, H, NBCI_F32);
+        d.bias = params + p.e3b; d.drop_p = pe; d.seed = io->seed; d.site = 5;
+        TRY(gemm_launch_timed(d, s));
+    }
+    // 2. LayerNorm'd embedding tables (itransformer.py:125-139,192-201): normalise the whole table once per step
+    const int64_t* ss = io->spikes_spacestamp;
+    if (c.max_n_channels > 0) {
+        TRY(layernorm_fwd_launch(params + p.chw, params + p.chnw, params + p.chnb, ws + w.chtab, NBCI_F32, (float*)(ws + w.mean_c),
+                                 (float*)(ws + w.rstd_c), c.max_n_channels, H, s));
+        if (!ss) {
+            hipLaunchKernelGGL(itr_iota_kernel, dim3((M0 + 255) / 256), dim3(256), 0, s, (long long*)(ws + w.ssidx), B, N);
+            ss = (const int64_t*)(ws + w.ssidx);
+        }
+    }
+    if (c.n_regions > 0)
+        TRY(layernorm_fwd_launch(params + p.rgw, params + p.rgnw, params + p.rgnb, ws + w.rgtab, NBCI_F32, (float*)(ws + w.mean_r),
+                                 (float*)(ws + w.rstd_r), c.n_regions, H, s));
+    // 3. tokens = [cls | LN(t2) + channel (+ region)] -> embed dropout (itransformer.py:187-209)
+    void* xb0 = ws + (c.n_layers ? w.L[0].xb : w.xlast_b);
+    TRY(itr_assemble_fwd_launch((const float*)(ws + w.t2), params + p.enw, params + p.enb,
+                                c.max_n_channels > 0 ? (const float*)(ws + w.chtab) : nullptr, ss,
+                                c.n_regions > 0 ? (const float*)(ws + w.rgtab) : nullptr, io->region_idx,
+                                c.use_cls ? params + p.cls : nullptr, (float*)(ws + w.yA), xb0, dt, (float*)(ws + w.mean_e),
+                                (float*)(ws + w.rstd_e), B, N, H, c.use_cls ? 1 : 0, pe, io->seed, 6, s));
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* yA = (float*)(ws + w.yA);
+    float* yB = (float*)(ws + w.yB);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const ItrLayerWS& lw = w.L[l];
+        const ItrLayerOff& lo = p.L[l];
+        {
+            nbci_gemm_desc d = gd(M, 3 * H, H, dt, op(ws + lw.xb, es, 0, H, 1), op(x.W(lo.inw), es, 0, H, 1), ws + lw.qkv, 3 * H, dt);
+            d.bias = params + lo.inb;
+            TRY(gemm_launch_timed(d, s));
+        }
+        {   // scores = q k^T / sqrt(hd), batched over (b, head); no mask (itransformer.py:209)
+            nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)S * 3 * H, hd),
+                                  op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)S * 3 * H, hd), ws + w.scores, w.ldS, NBCI_F32);
+            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * S * w.ldS; d.czs2 = (int64_t)S * w.ldS; d.alpha = scale;
+            TRY(gemm_launch_timed(d, s));
+        }
+        TRY(softmax_fwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + (pl > 0.f ? lw.Pd : lw.P), dt, nullptr, B, nh, S, w.ldS,
+                               w.ldP, -2, -2, pl, io->seed, 16 + 4 * l, s));
+        {
+            const size_t pd = pl > 0.f ? lw.Pd : lw.P;
+            nbci_gemm_desc d = gd(S, hd, S, dt, op(ws + pd, es, 0, w.ldP, 1, 0, 0, (int64_t)nh * S * w.ldP, (int64_t)S * w.ldP),
+                                  op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)S * 3 * H, hd), ws + lw.ad, H, dt);
+            d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)S * H; d.czs2 = hd;
+            TRY(gemm_launch_timed(d, s));
+        }
+        {   // r1 = x + dropout1(out_proj(a))
+            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), ws + lw.r1, H, NBCI_F32);
+            d.bias = params + lo.ob; d.drop_p = pl; d.seed = io->seed; d.site = 17 + 4 * l; d.residual = yA; d.ldr = H;
+            TRY(gemm_launch_timed(d, s));
+        }
+        TRY(layernorm_fwd_launch((const float*)(ws + lw.r1), params + lo.n1w, params + lo.n1b, ws + lw.x1b, dt, (float*)(ws + lw.mean1),
+                                 (float*)(ws + lw.rstd1), M, H, s, yB));
+        {   // g = dropout(act(linear1(x1)))
+            nbci_gemm_desc d = gd(M, F, H, dt, op(ws + lw.x1b, es, 0, H, 1), op(x.W(lo.w1), es, 0, H, 1), ws + lw.g, F, dt);
+            d.bias = params + lo.b1; d.act = c.act; d.drop_p = pl; d.seed = io->seed; d.site = 18 + 4 * l;
+            TRY(gemm_launch_timed(d, s));
+        }
+        {   // r2 = x1 + dropout2(linear2(g))
+            nbci_gemm_desc d = gd(M, H, F, dt, op(ws + lw.g, es, 0, F, 1), op(x.W(lo.w2), es, 0, F, 1), ws + lw.r2, H, NBCI_F32);
+            d.bias = params + lo.b2; d.drop_p = pl; d.seed = io->seed; d.site = 19 + 4 * l; d.residual = yB; d.ldr = H;
+            TRY(gemm_launch_timed(d, s));
+        }
+        void* xb_next = ws + (l + 1 < c.n_layers ? w.L[l + 1].xb : w.xlast_b);
+        TRY(layernorm_fwd_launch((const float*)(ws + lw.r2), params + lo.n2w, params + lo.n2b, xb_next, dt, (float*)(ws + lw.mean2),
+                                 (float*)(ws + lw.rstd2), M, H, s, yA));
+    }
+    // final norm (TransformerEncoder(norm=...), itransformer.py:168-173); yA holds its f32 input until the next forward
+    TRY(layernorm_fwd_launch(yA, params + p.fnw, params + p.fnb, ws + w.xo, dt, (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
+    if (io->hidden_out)
+        NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, ws + w.xo, (size_t)M * H * es, hipMemcpyDeviceToDevice, s));
+    // decoder over every token row (the CLS rows are computed and ignored: 1/(N+1) extra work, no gather)
+    const void* dec_in = ws + w.xo;
+    int64_t ow = p.d0w, ob = p.d0b;
+    if (c.mlp_decoder) {
+        nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.xo, es, 0, H, 1), op(x.W(p.d0w), es, 0, H, 1), ws + w.d1, H, dt);
+        d.bias = params + p.d0b; d.act = c.dec_act;
+        TRY(gemm_launch_timed(d, s));
+        dec_in = ws + w.d1; ow = p.d2w; ob = p.d2b;
+    }
+    {
+        nbci_gemm_desc d = gd(M, T, H, dt, op(dec_in, es, 0, H, 1), op(x.W(ow), es, 0, H, 1), ws + w.pred, w.ldT, NBCI_F32);
+        d.bias = params + ob;
+        TRY(gemm_launch_timed(d, s));
+    }
+    TRY(itr_mlm_loss_launch((const float*)(ws + w.pred), w.ldT, io->spikes, io->mask, io->spikes_mask, io->preds, io->mask_out,
+                            io->want_grad ? ws + w.dpred : nullptr, dt, io->loss, io->n_examples, B, T, N, c.use_cls ? 1 : 0, c.loss,
+                            io->grad_scale, s));
+    return NBCI_OK;
+}
+
+int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, const nbci_itr_io* io, float* grads, int seg_hi, int seg_lo,
+                 hipStream_t s) {
+    TRY(itr_validate(p, io));
+    const auto& c = p.c;
+    NBCI_REQUIRE(params && grads, NBCI_EINVAL, "itransformer: null params/grads");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || params_lp, NBCI_EINVAL, "itransformer: bf16 mode needs the bf16 parameter shadow");
+    NBCI_REQUIRE(seg_hi <= c.n_layers + 1 && seg_lo >= 0 && seg_lo <= seg_hi, NBCI_EINVAL, "itransformer: bad segment range");
+    ItrCtx x{p, params, c.dtype == NBCI_BF16 ? params_lp : (const void*)params, (size_t)(c.dtype == NBCI_BF16 ? 2 : 4),
+             (char*)io->workspace, {}, s};
+    const int B = io->B, N = io->N;
+    TRY(itr_carve(p, B, N, x.w));
+    NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "itransformer: workspace too small");
+    const ItrWS& w = x.w;
+    const int S = w.S, M = w.M, M0 = w.M0, H = c.hidden, F = 4 * H, T = c.max_n_bins, nh = c.n_heads, hd = H / nh;
+    const int dt = c.dtype;
+    const size_t es = x.es;
+    const bool train = io->train != 0;
+    const float pe = train ? c.embed_dropout : 0.f, pl = train ? c.dropout : 0.f;
+    char* ws = x.ws;
+    float* dY = (float*)(ws + w.dY);
+    float* dR = (float*)(ws + w.dR);
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* rep = (float*)(ws + w.rep);
+    const RepCfg rc{p.compact_total, NREP};
+    auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };
+    auto cast_to = [&](size_t buf, float pp, uint32_t site, int64_t bias_off) -> LnCast {
+        return LnCast{ws + buf, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site), RG(bias_off)};
+    };
+    const LnCast no_cast{nullptr, 0, 0u, 1.f, 0u, nullptr};
+
+    for (int seg = seg_hi; seg >= seg_lo; --seg) {
+        if (seg == c.n_layers + 1) {
+            // ---- mlm decoder + final norm
+            const void* dp = ws + w.dpred;
+            const void* dec_in = c.mlp_decoder ? ws + w.d1 : ws + w.xo;
+            const int64_t ow = c.mlp_decoder ? p.d2w : p.d0w, ob = c.mlp_decoder ? p.d2b : p.d0b;
+            TRY(colsum_launch(dp, dt, w.ldT, M, T, RG(ob), s, rc));
+            TRY(wgrad(s, dt, T, H, M, op(dp, es, 0, w.ldT, 0), op(dec_in, es, 0, H, 0), grads + ow, H));
+            if (c.mlp_decoder) {
+                {   // dd1 = (dpred W_2) * act'(d1), decoder.0 bias grad = its column sums
+                    nbci_gemm_desc d = gd(M, H, T, dt, op(dp, es, 0, w.ldT, 1), op(x.W(p.d2w), es, 0, H, 0), ws + w.cA, H, dt);
+                    d.gate = ws + w.d1; d.ldg = H; d.gate_act = c.dec_act;
+                    d.colsum = RG(p.d0b); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                    TRY(gemm_launch_timed(d, s));
+                }
+                TRY(wgrad(s, dt, H, H, M, op(ws + w.cA, es, 0, H, 0), op(ws + w.xo, es, 0, H, 0), grads + p.d0w, H));
+                nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, NBCI_F32);
+                TRY(gemm_launch_timed(d, s));
+            } else {
+                nbci_gemm_desc d = gd(M, H, T, dt, op(dp, es, 0, w.ldT, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, NBCI_F32);
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(layernorm_bwd_launch(dR, (const float*)(ws + w.yA), params + p.fnw, (const float*)(ws + w.mean_o),
+                                     (const float*)(ws + w.rstd_o), dY, RG(p.fnw), RG(p.fnb), M, H, 0, s, rc, no_cast));
+        } else if (seg >= 1) {
+            const int l = seg - 1;
+            const ItrLayerWS& lw = w.L[l];
+            const ItrLayerOff& lo = p.L[l];
+            WgradQueue wq; wq.dtype = dt; wq.s = s;
+            // ---- x' = LN2(r2), r2 = x1 + dropout2(linear2(g)), g = dropout(act(linear1(x1)))
+            TRY(layernorm_bwd_launch(dY, (const float*)(ws + lw.r2), params + lo.n2w, (const float*)(ws + lw.mean2),
+                                     (const float*)(ws + lw.rstd2), dR, RG(lo.n2w), RG(lo.n2b), M, H, 0, s, rc,
+                                     cast_to(w.cA, pl, 19 + 4 * l, lo.b2)));
+            TRY(wq.push(H, F, M, op(ws + w.cA, es, 0, H, 0), op(ws + lw.g, es, 0, F, 0), grads + lo.w2, F));
+            {   // du = (c W_2) * act'(u) * keep: for ReLU both factors are read off g itself (g > 0 <=> u > 0 and kept)
+                nbci_gemm_desc d = gd(M, F, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(lo.w2), es, 0, F, 0), ws + w.dU, F, dt);
+                d.gate = ws + lw.g; d.ldg = F; d.gate_act = c.act;
+                d.drop_p = pl; d.seed = io->seed; d.site = 18 + 4 * l;
+                d.colsum = RG(lo.b1); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(wq.push(F, H, M, op(ws + w.dU, es, 0, F, 0), op(ws + lw.x1b, es, 0, H, 0), grads + lo.w1, H));
+            {   // d x1 = du W_1 + d r2
+                nbci_gemm_desc d = gd(M, H, F, dt, op(ws + w.dU, es, 0, F, 1), op(x.W(lo.w1), es, 0, H, 0), dY, H, NBCI_F32);
+                d.residual = dR; d.ldr = H;
+                TRY(gemm_launch_timed(d, s));
+            }
+            // ---- x1 = LN1(r1), r1 = x + dropout1(out_proj(attn(x)))
+            TRY(layernorm_bwd_launch(dY, (const float*)(ws + lw.r1), params + lo.n1w, (const float*)(ws + lw.mean1),
+                                     (const float*)(ws + lw.rstd1), dR, RG(lo.n1w), RG(lo.n1b), M, H, 0, s, rc,
+                                     cast_to(w.cA2, pl, 17 + 4 * l, lo.ob)));
+            TRY(wq.push(H, H, M, op(ws + w.cA2, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
+            {
+                nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.cA2, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dAtt, H, dt);
+                TRY(gemm_launch_timed(d, s));
+            }
+            const size_t pd = pl > 0.f ? lw.Pd : lw.P;
+            const int64_t pz1 = (int64_t)nh * S * w.ldP, pz2 = (int64_t)S * w.ldP;
+            const int64_t qz1 = (int64_t)S * 3 * H, az1 = (int64_t)S * H;
+            {   // dPd = da v^T (f32, reuses the score buffer)
+                nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + w.dAtt, es, 0, H, 1, 0, 0, az1, hd),
+                                      op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)nh * S * w.ldS; d.czs2 = (int64_t)S * w.ldS;
+                TRY(gemm_launch_timed(d, s));
+            }
+            {   // dv = Pd^T da
+                nbci_gemm_desc d = gd(S, hd, S, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2), op(ws + w.dAtt, es, 0, H, 0, 0, 0, az1, hd),
+                                      (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(softmax_bwd_launch((const float*)(ws + w.scores), ws + lw.P, ws + w.dS, dt, B, nh, S, w.ldS, w.ldP, pl, io->seed,
+                                   16 + 4 * l, s));
+            {   // dq = dS k * scale
+                nbci_gemm_desc d = gd(S, hd, S, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
+                                      op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                TRY(gemm_launch_timed(d, s));
+            }
+            {   // dk = dS^T q * scale
+                nbci_gemm_desc d = gd(S, hd, S, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
+                                      op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
+                d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.inb), s, rc));
+            TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.xb, es, 0, H, 0), grads + lo.inw, H));
+            TRY(wq.flush());
+            {   // d x = dqkv W_in + d r1
+                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.inw), es, 0, H, 0), dY, H, NBCI_F32);
+                d.residual = dR; d.ldr = H;
+                TRY(gemm_launch_timed(d, s));
+            }
+        } else {
+            // ---- embedding side (itransformer.py:187-209)
+            float* dtok = (float*)(ws + w.dtok);
+            const int64_t* ss = io->spikes_spacestamp ? io->spikes_spacestamp : (const int64_t*)(ws + w.ssidx);
+            TRY(itr_assemble_bwd_launch(dY, dtok, c.max_n_channels > 0 ? (float*)(ws + w.dchtab) : nullptr, ss,
+                                        c.n_regions > 0 ? (float*)(ws + w.drgtab) : nullptr, io->region_idx,
+                                        c.use_cls ? RG(p.cls) : nullptr, rc, B, N, H, c.use_cls ? 1 : 0, pe, io->seed, 6, s));
+            // embed.1 LayerNorm; its output gradient feeds embed.0.3 through the MLP's trailing Dropout (site 5)
+            TRY(layernorm_bwd_launch(dtok, (const float*)(ws + w.t2), params + p.enw, (const float*)(ws + w.mean_e),
+                                     (const float*)(ws + w.rstd_e), dR, RG(p.enw), RG(p.enb), M0, H, 0, s, rc, cast_to(w.cA, pe, 5, p.e3b)));
+            TRY(wgrad(s, dt, H, H, M0, op(ws + w.cA, es, 0, H, 0), op(ws + w.h0, es, 0, H, 0), grads + p.e3w, H));
+            {   // d u0 = (c W_3) * act'(u0) * keep -> f32 (the K = max_n_bins weight gradient runs on the f32 path)
+                nbci_gemm_desc d = gd(M0, H, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(p.e3w), es, 0, H, 0), ws + w.dH0, H, NBCI_F32);
+                d.gate = ws + w.h0; d.ldg = H; d.gate_act = c.act;
+                d.drop_p = pe; d.seed = io->seed; d.site = 4;
+                d.colsum = RG(p.e0b); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
+                TRY(gemm_launch_timed(d, s));
+            }
+            TRY(wgrad(s, NBCI_F32, H, T, M0, op(ws + w.dH0, 4, 0, H, 0), op(ws + w.xs, 4, 0, T, 0), grads + p.e0w, T));
+            // LayerNorm'd tables: the scatter-added table gradient goes back through the table's LayerNorm
+            if (c.max_n_channels > 0)
+                TRY(layernorm_bwd_launch((const float*)(ws + w.dchtab), params + p.chw, params + p.chnw, (const float*)(ws + w.mean_c),
+                                         (const float*)(ws + w.rstd_c), grads + p.chw, RG(p.chnw), RG(p.chnb), c.max_n_channels, H, 1, s, rc,
+                                         no_cast));
+            if (c.n_regions > 0)
+                TRY(layernorm_bwd_launch((const float*)(ws + w.drgtab), params + p.rgw, params + p.rgnw, (const float*)(ws + w.mean_r),
+                                         (const float*)(ws + w.rstd_r), grads + p.rgw, RG(p.rgnw), RG(p.rgnb), c.n_regions, H, 1, s, rc,
+                                         no_cast));
+        }
+        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
+    }
+    return NBCI_OK;
+}
+
+}  // namespace nbci
+
+using namespace nbci;
+
+extern "C" {
+
+int nbci_masker(const nbci_masker_desc* desc, nbci_stream_t stream) {
+    if (!desc) return fail(NBCI_EINVAL, "masker: null descriptor");
+    return masker_launch(*desc, (hipStream_t)stream);
+}
+
+int nbci_itr_plan_create(const nbci_itr_config* cfg, nbci_itr_plan* out) {
+    if (!cfg || !out) return fail(NBCI_EINVAL, "itr plan_create: null argument");
+    const nbci_itr_config& c = *cfg;
+    NBCI_REQUIRE(c.hidden > 0 && c.n_heads > 0 && c.hidden % c.n_heads == 0, NBCI_ESHAPE, "embed_dim must be divisible by num_heads");
+    NBCI_REQUIRE(c.hidden % 8 == 0 && (c.hidden / c.n_heads) % 8 == 0, NBCI_ESHAPE, "hidden and head size must be multiples of 8");
+    NBCI_REQUIRE(c.max_n_bins > 0 && c.max_n_bins % 4 == 0, NBCI_ESHAPE, "max_n_bins must be a positive multiple of 4");
+    NBCI_REQUIRE(c.n_layers >= 0 && c.max_n_channels >= 0 && c.n_regions >= 0, NBCI_ESHAPE, "bad iTransformer shape parameters");
+    NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.act == ACT_RELU && (!c.mlp_decoder || c.dec_act == ACT_RELU), NBCI_EINVAL,
+                 "iTransformer HIP path supports activation: relu (the backward reads act' off the saved outputs)");
+    NBCI_REQUIRE(c.loss >= NBCI_LOSS_POISSON_LOG && c.loss <= NBCI_LOSS_MSE, NBCI_EINVAL, "unknown loss");
+    ItrPlan* p = new ItrPlan();
+    p->c = c;
+    itr_layout(*p);
+    p->d_flat_of = nullptr;
+    hipError_t e = hipMalloc(&p->d_flat_of, std::max<size_t>(4, p->flat_of.size() * sizeof(int)));
+    if (e == hipSuccess && !p->flat_of.empty())
+        e = hipMemcpy(p->d_flat_of, p->flat_of.data(), p->flat_of.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete p; return fail(NBCI_EHIP, std::string("itr plan_create: ") + hipGetErrorString(e)); }
+    *out = (nbci_itr_plan)p;
+    return NBCI_OK;
+}
+
+void nbci_itr_plan_destroy(nbci_itr_plan plan) {
+    ItrPlan* p = (ItrPlan*)plan;
+    if (!p) return;
+    if (p->d_flat_of) (void)hipFree(p->d_flat_of);
+    delete p;
+}
+
+int64_t nbci_itr_param_count(nbci_itr_plan plan) { return plan ? ((ItrPlan*)plan)->total : -1; }
+int32_t nbci_itr_num_params(nbci_itr_plan plan) { return plan ? (int32_t)((ItrPlan*)plan)->params.size() : -1; }
+int32_t nbci_itr_num_segments(nbci_itr_plan plan) { return plan ? (int32_t)((ItrPlan*)plan)->seg.size() : -1; }
+
+int nbci_itr_param_info(nbci_itr_plan plan, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel, int32_t* rows,
+                        int32_t* cols, int32_t* segment) {
+    ItrPlan* p = (ItrPlan*)plan;
+    if (!p || index < 0 || index >= (int)p->params.size()) return fail(NBCI_EINVAL, "itr param_info: bad plan/index");
+    const PInfo& i = p->params[index];
+    if (name && name_cap > 0) { strncpy(name, i.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = i.off;
+    if (numel) *numel = i.numel;
+    if (rows) *rows = i.rows;
+    if (cols) *cols = i.cols;
+    if (segment) *segment = i.seg;
+    return NBCI_OK;
+}
+
+int nbci_itr_segment_range(nbci_itr_plan plan, int32_t seg, int64_t* begin, int64_t* end) {
+    ItrPlan* p = (ItrPlan*)plan;
+    if (!p || seg < 0 || seg >= (int)p->seg.size()) return fail(NBCI_EINVAL, "itr segment_range: bad plan/segment");
+    *begin = p->seg[seg].first; *end = p->seg[seg].second;
+    return NBCI_OK;
+}
+
+int64_t nbci_itr_workspace_bytes(nbci_itr_plan plan, int32_t B, int32_t N) {
+    ItrPlan* p = (ItrPlan*)plan;
+    if (!p) { fail(NBCI_EINVAL, "itr workspace_bytes: null plan"); return -1; }
+    ItrWS w;
+    if (itr_carve(*p, B, N, w) != NBCI_OK) return -1;
+    return (int64_t)w.bytes;
+}
+
+int nbci_itr_forward(nbci_itr_plan plan, const float* params, const void* params_lp, const nbci_itr_io* io, nbci_stream_t stream) {
+    if (!plan) return fail(NBCI_EINVAL, "itr forward: null plan");
+    return itr_forward(*(ItrPlan*)plan, params, params_lp, io, (hipStream_t)stream);
+}
+
+int nbci_itr_backward(nbci_itr_plan plan, const float* params, const void* params_lp, const nbci_itr_io* io, float* grads, int32_t seg_hi,
+                      int32_t seg_lo, nbci_stream_t stream) {
+    if (!plan) return fail(NBCI_EINVAL, "itr backward: null plan");
+    return itr_backward(*(ItrPlan*)plan, params, params_lp, io, grads, seg_hi, seg_lo, (hipStream_t)stream);
+}
+
+}  // extern "C"

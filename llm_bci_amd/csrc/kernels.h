@@ -23,13 +23,13 @@ int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* len
 
 // nn.LayerNorm (eps 1e-5, affine) forward: x f32 (M,H) -> y act dtype, saves mean/rstd
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean,
-                         float* rstd, int M, int H, hipStream_t s);
+                         float* rstd, int M, int H, hipStream_t s, float* y32 = nullptr);  // y32: optional f32 copy of y
 // backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
 int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s,
                          RepCfg rc = RepCfg{0, 1}, LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr});
 
-// masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437),
+// masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437; tmask NULL = all valid),
 // writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP
 int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int32_t* tmask, int B, int nh, int Tp,
                        int ldS, int ldP, int ctx_fwd, int ctx_bwd, float drop_p, uint32_t seed, uint32_t site,
@@ -87,6 +87,19 @@ int splice_fwd_launch(const void* text, const void* spikes, void* out, int dtype
                       int H, hipStream_t s);
 int splice_bwd_launch(const void* dout, void* dtext, void* dspikes, int dtype, const int64_t* split, int B, int Lt, int Ts, int H,
                       hipStream_t s);
+
+// ---- iTransformer SSL path (itr_kernels.hip) ----
+int masker_launch(const nbci_masker_desc& d, hipStream_t s);
+int btn_to_bnt_launch(const float* in, float* out, int B, int T, int N, hipStream_t s);
+int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, const float* tab1, const int64_t* idx1, const float* tab2,
+                            const int64_t* idx2, const float* cls, float* x32, void* xb, int xb_dtype, float* mean, float* rstd, int B,
+                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+int itr_assemble_bwd_launch(const float* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
+                            float* dcls, RepCfg rc, int B, int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site,
+                            hipStream_t s);
+int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const int64_t* mask, const int64_t* smask, float* preds_out,
+                        int64_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int N, int use_cls,
+                        int kind, float grad_scale, hipStream_t s);
 
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);

@@ -155,7 +155,8 @@ int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* len
 template <int NV, typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, TO* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int H) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int H,
+                                                     float* __restrict__ y32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -186,29 +187,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (c < H) {
             const float4 ww = *(const float4*)(w + c), bv = *(const float4*)(b + c);
             const long long o = (long long)row * H + c;
-            stf<TO>(y, o + 0, (v[k].x - mu) * rs * ww.x + bv.x);
-            stf<TO>(y, o + 1, (v[k].y - mu) * rs * ww.y + bv.y);
-            stf<TO>(y, o + 2, (v[k].z - mu) * rs * ww.z + bv.z);
-            stf<TO>(y, o + 3, (v[k].w - mu) * rs * ww.w + bv.w);
+            const float4 r = make_float4((v[k].x - mu) * rs * ww.x + bv.x, (v[k].y - mu) * rs * ww.y + bv.y,
+                                         (v[k].z - mu) * rs * ww.z + bv.z, (v[k].w - mu) * rs * ww.w + bv.w);
+            stf<TO>(y, o + 0, r.x); stf<TO>(y, o + 1, r.y); stf<TO>(y, o + 2, r.z); stf<TO>(y, o + 3, r.w);
+            if (y32) *(float4*)(y32 + o) = r;   // f32 copy for a following residual add (post-norm layers)
         }
     }
 }
 
 template <typename TO>
 static void ln_fwd_dispatch(int nv, dim3 g, hipStream_t s, const float* x, const float* w, const float* b, TO* y,
-                            float* mean, float* rstd, int M, int H) {
-    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
-    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
-    else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
-    else hipLaunchKernelGGL((ln_fwd_kernel<16, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H);
+                            float* mean, float* rstd, int M, int H, float* y32) {
+    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else hipLaunchKernelGGL((ln_fwd_kernel<16, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
 }
 
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
-                         int M, int H, hipStream_t s) {
+                         int M, int H, hipStream_t s, float* y32) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "layernorm: hidden must be a multiple of 4 and <= 4096");
     const int nv = (H + 255) / 256;
     dim3 g((M + 3) / 4);
-    DISPATCH_DTYPE(y_dtype, TO, ln_fwd_dispatch<TO>(nv, g, s, x, w, b, (TO*)y, mean, rstd, M, H));
+    DISPATCH_DTYPE(y_dtype, TO, ln_fwd_dispatch<TO>(nv, g, s, x, w, b, (TO*)y, mean, rstd, M, H, y32));
     return check_launch("layernorm_fwd");
 }
 
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
         const int j = k * 64 + lane;
         float val = -INFINITY;
         if (j < Tp) {
-            const bool ok = (j == i) || (ctx_allowed(i, j, cf, cb) && tmask[b * Tp + j] != 0);
+            const bool ok = (j == i) || (ctx_allowed(i, j, cf, cb) && (!tmask || tmask[b * Tp + j] != 0));
             if (ok) val = sr[j];
         }
         v[k] = val;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int32_t* tmask, int B, int nh, int Tp,
                        int ldS, int ldP, int ctx_fwd, int ctx_bwd, float drop_p, uint32_t seed, uint32_t site,
                        hipStream_t s) {
-    NBCI_REQUIRE(ldP <= 1024 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 1024 tokens");
+    NBCI_REQUIRE(ldP <= 2048 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 2048 tokens");
     const int rows = B * nh * Tp;
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -386,8 +387,11 @@ int softmax_fwd_launch(const float* S, void* P, void* Pd, int p_dtype, const int
         if (ldP <= 256)
             hipLaunchKernelGGL((softmax_fwd_kernel<4, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
                                ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, drop_key(seed, site));
-        else
+        else if (ldP <= 1024)
             hipLaunchKernelGGL((softmax_fwd_kernel<16, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
+                               ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, drop_key(seed, site));
+        else
+            hipLaunchKernelGGL((softmax_fwd_kernel<32, TP>), g, dim3(256), 0, s, S, (TP*)P, (TP*)Pd, tmask, rows, nh, Tp,
                                ldS, ldP, ctx_fwd, ctx_bwd, thr, dscale, drop_key(seed, site));
     });
     return check_launch("softmax_fwd");
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 
 int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, int B, int nh, int Tp, int ldS, int ldP,
                        float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
-    NBCI_REQUIRE(ldP <= 1024 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 1024 tokens");
+    NBCI_REQUIRE(ldP <= 2048 && Tp <= ldP, NBCI_ESHAPE, "softmax: at most 2048 tokens");
     const int rows = B * nh * Tp;
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -436,8 +440,11 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
         if (ldP <= 256)
             hipLaunchKernelGGL((softmax_bwd_kernel<4, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
                                ldP, thr, dscale, drop_key(seed, site));
-        else
+        else if (ldP <= 1024)
             hipLaunchKernelGGL((softmax_bwd_kernel<16, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
+                               ldP, thr, dscale, drop_key(seed, site));
+        else
+            hipLaunchKernelGGL((softmax_bwd_kernel<32, TP>), g, dim3(256), 0, s, dPd, (const TP*)P, (TP*)dS, rows, Tp, ldS,
                                ldP, thr, dscale, drop_key(seed, site));
     });
     return check_launch("softmax_bwd");

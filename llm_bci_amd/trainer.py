@@ -17,14 +17,16 @@ from .ndt1 import NDT1, _ptr, _stream
 from .schedule import LinearWarmup, OneCycle, StepDecay
 
 from .bci import BCI  # noqa: E402
+from .itransformer import iTransformer  # noqa: E402
 
-NAME2MODEL = {"NDT1": NDT1, "BCI": BCI}
+NAME2MODEL = {"NDT1": NDT1, "BCI": BCI, "iTransformer": iTransformer}
 
 
 def register_into(reference_trainer_module):
     """Registry swap: make the reference's Trainer build the HIP NDT1 for model_class 'NDT1'."""
     reference_trainer_module.NAME2MODEL["NDT1"] = NDT1
     reference_trainer_module.NAME2MODEL["BCI"] = BCI
+    reference_trainer_module.NAME2MODEL["iTransformer"] = iTransformer
 
 
 class NativeTrainer:
@@ -77,6 +79,11 @@ class NativeTrainer:
         e = err.sum(0).double()
         return e[0] / e[1]
 
+    def _n_examples(self, loss_vec):
+        """NDT1-CTC: one example per sample (ndt1.py:584); iTransformer mlm: the number of masked bins (itransformer.py:347)."""
+        n = getattr(self.model, "last_n_examples", None)
+        return loss_vec.numel() if n is None else n.sum().double()
+
     def train_step(self, batch, seed=None):
         """One micro-batch: forward, backward (+ overlapped all-reduce), and — on the steps the
         reference synchronises on (trainer.py:335) — AdamW + scheduler + zero_grad."""
@@ -91,8 +98,8 @@ class NativeTrainer:
                 self.reducer.segment_done(self.grads, seg)
         # bookkeeping while the last buckets are in flight
         self.stats[0] += loss_vec.sum().double()
-        self.stats[1] += loss_vec.numel()
-        if self.compute_per and batch.get("targets") is not None:
+        self.stats[1] += self._n_examples(loss_vec)
+        if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
             self.stats[2] += self._per(batch)
             self.stats[3] += 1
         if sync:
@@ -134,8 +141,8 @@ class NativeTrainer:
         for batch in batches:
             loss_vec, _ = m._run_forward(batch, want_grad=False)
             acc[0] += loss_vec.sum().double()
-            acc[1] += loss_vec.numel()
-            if self.compute_per and batch.get("targets") is not None:
+            acc[1] += self._n_examples(loss_vec)
+            if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
                 acc[2] += self._per(batch)
                 acc[3] += 1
         m.train(was_training)

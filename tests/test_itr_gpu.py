@@ -1,0 +1,239 @@
+"""GPU: the iTransformer SSL (mlm) HIP path through the C-ABI against (a) fixtures generated from the reference
+(tests/golden/g_itr_*.npz; fp32 path, deterministic mask replayed), (b) the numpy oracle with identical dropout / masker
+draws (train mode), (c) itself in bf16; and the device Masker against the oracle bit for bit."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import itransformer as OI
+from oracle import optim as OO
+from test_oracle_itr_golden import itr_batch, itr_cfg, load, masked_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dev(batch):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in batch.items()}
+
+
+def _model(fx_or_over, dtype="fp32", **kw):
+    from llm_bci_amd.itransformer import iTransformer
+    if isinstance(fx_or_over, dict):
+        over, kwargs = fx_or_over, dict(log_input=True, loss="poisson_nll")
+    else:
+        over, kwargs = json.loads(str(fx_or_over["config_json"])), json.loads(str(fx_or_over["kwargs_json"]))
+    kwargs.update(kw)
+    torch.manual_seed(1)
+    return iTransformer(over, method_name="mlm", compute_dtype=dtype, **kwargs)
+
+
+def _grads_of(m, batch, seed=None):
+    m.train()
+    loss, preds = m._run_forward(batch, want_grad=True, seed=seed)
+    g = torch.zeros_like(m._flat)
+    m._run_backward(g)
+    torch.cuda.synchronize()
+    return loss, preds, {n: g[o:o + k].view(s).cpu().numpy() for (n, o, k, s, _sg) in m._layout}
+
+
+# ----------------------------------------------------------------------------------------------- masker
+@pytest.mark.parametrize("mode,extra", [("temporal", {}), ("neuron", {}), ("random", {}), ("co-smooth", {"channels": [1, 5, 7]}),
+                                        ("temporal", {"expand_prob": 1.0, "max_timespan": 3}),
+                                        ("random", {"zero_ratio": 0.5, "random_ratio": 0.5}),
+                                        ("region", {"regions": ["CA1", "PO"]})])
+def test_masker_matches_oracle_bit_exact(mode, extra):
+    from llm_bci_amd.itransformer import SITE_MASKER, iTransformer
+    g = np.random.default_rng(3)
+    B, T, N = 5, 12, 37
+    spikes = g.poisson(2.0, (B, T, N)).astype(np.float32)
+    mc = dict(active=True, force_active=True, mode=mode, ratio=0.3, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1)
+    mc.update(extra)
+    over = {"encoder": {"embedder": {"max_n_bins": T, "dropout": 0.0}, "hidden_size": 32, "n_heads": 2, "n_layers": 1, "dropout": 0.0,
+                        "max_n_channels": 64, "embed_region": False}, "masker": {"main": mc}}
+    m = _model(over).to(DEV)
+    m.train()
+    regions = np.array([["CA1", "DG", "PO", "VIS"][i % 4] for i in range(B * N)]).reshape(B, N)
+    probs = np.isin(regions, ["CA1", "PO"]).astype(np.float32)
+    for seed in (7, 123456789):
+        sp = torch.from_numpy(spikes).to(DEV)
+        masked, mask, _keep = m._apply_maskers(sp, regions, seed)
+        torch.cuda.synchronize()
+        ref_out, ref_mask = OI.masker(mc, spikes, True, seed, SITE_MASKER, probs=probs)
+        assert np.array_equal(mask.cpu().numpy(), ref_mask)
+        np.testing.assert_allclose(masked.cpu().numpy(), ref_out, rtol=1e-6, atol=0)
+        assert np.array_equal(sp.cpu().numpy(), spikes)      # the caller's tensor is left alone
+        assert 0 < ref_mask.mean() < 1
+    m.eval()
+    mc2 = dict(mc, force_active=False)
+    m.masker_cfg = [("main", mc2)]
+    masked, mask, _ = m._apply_maskers(torch.from_numpy(spikes).to(DEV), regions, 1)
+    assert mask.sum().item() == 0 and np.array_equal(masked.cpu().numpy(), spikes)   # masker.py:50-51
+
+
+def test_masker_two_maskers_accumulate():
+    from llm_bci_amd.itransformer import SITE_MASKER
+    g = np.random.default_rng(4)
+    spikes = g.poisson(2.0, (3, 12, 10)).astype(np.float32)
+    a = dict(active=True, force_active=True, mode="neuron", ratio=0.3, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1)
+    b = dict(a, mode="temporal", ratio=0.25)
+    over = {"encoder": {"embedder": {"max_n_bins": 12, "dropout": 0.0}, "hidden_size": 32, "n_heads": 2, "n_layers": 1, "dropout": 0.0,
+                        "max_n_channels": 16, "embed_region": False}, "masker": {"main": a, "second": b}}
+    m = _model(over).to(DEV)
+    m.train()
+    masked, mask, _ = m._apply_maskers(torch.from_numpy(spikes).to(DEV), None, 99)
+    o1, m1 = OI.masker(a, spikes, True, 99, SITE_MASKER)
+    o2, m2 = OI.masker(b, o1, True, 99, SITE_MASKER + 8)
+    assert np.array_equal(mask.cpu().numpy(), m1 | m2)
+    np.testing.assert_allclose(masked.cpu().numpy(), o2)
+
+
+# ----------------------------------------------------------------------------------------------- golden parity (fp32 path)
+@pytest.mark.parametrize("name", ["g_itr_tiny", "g_itr_tiny_ss", "g_itr_tiny_rate", "g_itr_tiny_mse"])
+def test_fp32_matches_reference_golden_tiny(name):
+    from llm_bci_amd.trainer import NativeTrainer
+    fx = load(name)
+    m = _model(fx).to(DEV)
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.cpu().numpy(), fx["w0:" + k]), k      # reference-order init is bit-equal
+    batch = _dev(itr_batch(fx))
+    m.eval()
+    m.mask_override = torch.from_numpy(fx["eval_raw_mask"])
+    with torch.no_grad():
+        out = m(**batch)
+    np.testing.assert_allclose(out.preds.cpu().numpy(), fx["eval_preds"], atol=1e-3)   # north_star tolerance (fp32 path)
+    assert np.array_equal(out.mask.cpu().numpy(), fx["eval_mask"])
+    assert int(out.n_examples) == int(fx["eval_n_examples"])
+    np.testing.assert_allclose(float(out.loss), float(fx["eval_loss"]), rtol=1e-4)
+    assert np.array_equal(out.targets.cpu().numpy(), fx["in_spikes"])
+    # gradients of the first train step (stochastic ops off, the reference's mask replayed)
+    m.mask_override = torch.from_numpy(fx["raw_mask_step0"])
+    loss, _, g = _grads_of(m, batch)
+    np.testing.assert_allclose(float(loss.sum()), float(fx["loss_step0"]), rtol=1e-4)
+    for k in g:
+        ref = fx["grad:" + k]
+        np.testing.assert_allclose(g[k], ref, atol=2e-5 + 1e-3 * np.abs(ref).max(), err_msg=k)
+    # two AdamW + OneCycle steps of the native trainer vs torch.optim on the reference model
+    m2 = _model(fx).to(DEV)
+    tr = NativeTrainer(m2, lr=1e-4, wd=0.01, eps=1e-8, scheduler="cosine", total_steps=100, warmup_pct=0.15, div_factor=25, compute_per=False)
+    for s in range(2):
+        m2.mask_override = torch.from_numpy(fx[f"raw_mask_step{s}"])
+        loss, _ = tr.train_step(batch)
+        np.testing.assert_allclose(float(loss.sum()), float(fx[f"loss_step{s}"]), rtol=2e-4)
+        assert int(m2.last_n_examples) == int(fx[f"n_examples_step{s}"])
+    torch.cuda.synchronize()
+    for k, v in m2.state_dict().items():
+        d = np.abs(v.cpu().numpy() - fx["w2:" + k])
+        assert (d > 3e-5).mean() <= 0.05 and d.max() <= 5e-4, (k, d.max())
+    st = tr.read_stats()
+    assert st["n_examples"] == int(fx["n_examples_step0"]) + int(fx["n_examples_step1"])
+
+
+def test_fp32_matches_reference_golden_c3_and_bf16_close():
+    fx = load("g_itr_c3")
+    batch = _dev(itr_batch(fx))
+    m = _model(fx).to(DEV)
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.cpu().numpy().reshape(-1)[fx["w0idx:" + k]], fx["w0val:" + k]), k
+    m.eval()
+    m.mask_override = torch.from_numpy(fx["eval_raw_mask"])
+    with torch.no_grad():
+        out = m(**batch)
+    p32 = out.preds.cpu().numpy()
+    np.testing.assert_allclose(p32[:, ::3, ::5], fx["eval_preds"], atol=1e-3)
+    np.testing.assert_allclose(float(out.loss), float(fx["eval_loss"]), rtol=2e-4)
+    assert int(out.n_examples) == int(fx["eval_n_examples"])
+    m.mask_override = torch.from_numpy(fx["raw_mask_step0"])
+    loss, _, g = _grads_of(m, batch)
+    np.testing.assert_allclose(float(loss.sum()), float(fx["loss_step0"]), rtol=2e-4)
+    for k in g:
+        ref = fx["gval:" + k]
+        got = g[k].reshape(-1)[fx["gidx:" + k]]
+        np.testing.assert_allclose(got, ref, atol=2e-5 + 2e-3 * max(np.abs(ref).max(), fx["gsum:" + k][1] / g[k].size), err_msg=k)
+    # bf16 operands (f32 accumulate) stay close to the fp32 path
+    mb = _model(fx, dtype="bf16").to(DEV)
+    mb.eval()
+    mb.mask_override = torch.from_numpy(fx["eval_raw_mask"])
+    with torch.no_grad():
+        ob = mb(**batch)
+    assert np.abs(ob.preds.cpu().numpy() - p32).max() < 0.08
+    np.testing.assert_allclose(float(ob.loss), float(out.loss), rtol=2e-2)
+    mb.mask_override = torch.from_numpy(fx["raw_mask_step0"])
+    _, _, gb = _grads_of(mb, batch)
+    for k in g:
+        num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
+        assert num / den < 0.06, (k, num / den)
+
+
+# ----------------------------------------------------------------------------------------------- train mode vs oracle
+@pytest.mark.parametrize("dtype,N,lens", [("fp32", 10, [12, 9, 7]), ("fp32", 70, [12, 12, 5, 3]), ("bf16", 70, [12, 12, 5, 3])])
+def test_train_mode_dropout_and_maskers_match_oracle(dtype, N, lens):
+    """recipe-style step: masker on (device RNG), dropout 0.2 / 0.4 on; the oracle mirrors every draw."""
+    from llm_bci_amd.itransformer import SITE_MASKER
+    T, B = 12, len(lens)
+    mc = dict(active=True, force_active=True, mode="neuron", ratio=0.3, zero_ratio=0.8, random_ratio=0.5, expand_prob=0.0, max_timespan=1)
+    over = {"encoder": {"embedder": {"max_n_bins": T, "dropout": 0.2}, "hidden_size": 32, "n_heads": 2, "n_layers": 2, "dropout": 0.4,
+                        "max_n_channels": 96, "embed_region": False}, "masker": {"main": mc}}
+    m = _model(over, dtype=dtype).to(DEV)
+    p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    g = np.random.default_rng(5)
+    spikes = g.poisson(0.7, (B, T, N)).astype(np.float32)
+    smask = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):
+        spikes[b, :T - L] = 0; smask[b, T - L:] = 1
+    ss = np.stack([g.permutation(96)[:N] for _ in range(B)]).astype(np.int64)
+    batch = dict(spikes=spikes, spikes_mask=smask, spikes_spacestamp=ss)
+    cfg = OI.make_config(max_n_bins=T, hidden=32, n_heads=2, n_layers=2, max_n_channels=96, embed_dropout=0.2, dropout=0.4)
+    seed = 4242
+    loss, preds, gh = _grads_of(m, _dev(batch), seed=seed)
+    masked, mask = OI.masker(mc, spikes, True, seed, SITE_MASKER)
+    out, cache = OI.forward(cfg, p, batch, masked, mask, train=True, seed=seed)
+    go = OI.backward(cache)
+    assert int(m.last_n_examples) == int(out["n_examples"]) and int(out["n_examples"]) > 0
+    assert np.array_equal(m.last_mask.cpu().numpy(), out["mask"])
+    tol = 1e-3 if dtype == "fp32" else 0.12
+    np.testing.assert_allclose(preds.cpu().numpy(), out["preds"], atol=tol)
+    np.testing.assert_allclose(float(loss.sum()), float(out["loss"]), rtol=1e-4 if dtype == "fp32" else 3e-2)
+    for k in go:
+        if dtype == "fp32":
+            np.testing.assert_allclose(gh[k], go[k], atol=2e-5 + 1e-3 * np.abs(go[k]).max(), err_msg=k)
+        else:
+            assert np.abs(gh[k] - go[k]).sum() / (np.abs(go[k]).sum() + 1e-6) < 0.08, k
+
+
+def test_autograd_bridge_and_checkpoint_roundtrip(tmp_path):
+    fx = load("g_itr_tiny")
+    m = _model(fx).to(DEV)
+    batch = _dev(itr_batch(fx))
+    m.train()
+    m.mask_override = torch.from_numpy(fx["raw_mask_step0"])
+    out = m(**batch)
+    out.loss.backward()
+    for k, p in m.named_parameters():
+        ref = fx["grad:" + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=2e-5 + 1e-3 * np.abs(ref).max(), err_msg=k)
+    m.save_checkpoint(str(tmp_path))
+    over = json.loads(str(fx["config_json"]))
+    over["encoder"]["from_pt"] = str(tmp_path); over["decoder"] = {"from_pt": str(tmp_path)}
+    torch.manual_seed(5)
+    from llm_bci_amd.itransformer import iTransformer
+    m2 = iTransformer(over, method_name="mlm", loss="poisson_nll", log_input=True, compute_dtype="fp32").to(DEV)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    ref_keys = {k[3:] for k in fx.files if k.startswith("w0:")}
+    assert set(m.state_dict().keys()) == ref_keys
+
+
+def test_unsupported_configs_fail_loudly():
+    from llm_bci_amd.itransformer import iTransformer
+    with pytest.raises(Exception, match="not implemented"):
+        iTransformer({"encoder": {"embed_region": False}}, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, loss="x")
+    with pytest.raises(Exception, match="mlp"):
+        iTransformer({"encoder": {"embed_region": False, "embedder": {"mode": "transformer"}}}, method_name="mlm", loss="poisson_nll", log_input=True)
+    m = _model({"encoder": {"embedder": {"max_n_bins": 12}, "hidden_size": 32, "n_heads": 2, "n_layers": 1, "max_n_channels": 16,
+                            "embed_region": False}})
+    with pytest.raises(Exception):   # CPU tensors: no fallback
+        m(torch.zeros(1, 12, 4), torch.ones(1, 12, dtype=torch.int64), torch.zeros(1, 12, dtype=torch.int64))
