@@ -99,3 +99,19 @@ def itransformer_defaults():
 def itransformer_config(config):
     base = "configs/itransformer.yaml" if os.path.exists("configs/itransformer.yaml") else itransformer_defaults()
     return update_config(base, config if config is not None else {})
+
+
+def patchtst_defaults():
+    """Built-in PatchTST model defaults (values of the reference's configs/patchtst.yaml)."""
+    enc = dict(from_pt=None, num_input_channels=128, context_length=45, patch_length=10, patch_stride=10, num_hidden_layers=4,
+               d_model=256, num_attention_heads=8, share_embedding=True, channel_attention=False, ffn_dim=1024, norm_type="batchnorm",
+               norm_eps=1.0e-5, attention_dropout=0.4, positional_dropout=0.0, path_dropout=0.0, ff_dropout=0.4, bias=True,
+               activation_function="gelu", pre_norm=True, positional_encoding_type="sincos", init_std=0.02, scaling=None,
+               do_mask_input=True, mask_type="random", random_mask_ratio=0.1, channel_consistent_masking=False, mask_value=0)
+    dec = dict(from_pt=None, share_projection=True, pooling_type="mean", head_dropout=0.0, mlp_decoder=False, mlp_activation="gelu")
+    return dict(model_class="PatchTST", encoder=enc, decoder=dec)
+
+
+def patchtst_config(config):
+    base = "configs/patchtst.yaml" if os.path.exists("configs/patchtst.yaml") else patchtst_defaults()
+    return update_config(base, config if config is not None else {})

@@ -236,7 +236,7 @@ def misc_cases():
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
 
-if __name__ == "__main__" and "--bci" not in sys.argv and "--itr" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst")):
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
@@ -450,3 +450,108 @@ if __name__ == "__main__" and "--itr" in sys.argv:
     itr_case("g_itr_c3", {"encoder": {"embedder": {"dropout": 0.0}, "dropout": 0.0, "embed_region": False},
                           "masker": {"main": {"active": True, "regions": None}}}, 4, 64, [100, 100, 80, 61], full=False)
     masker_cases()
+
+
+# ------------------------------------------------------------------------------------------------
+# PatchTST (models/patchtst.py over transformers' PatchTSTModel) — `--ptst`
+# ------------------------------------------------------------------------------------------------
+def ptst_case(name, over, method, B, lens, tgt_lens=None, vocab=11, full=True, steps=2, log_input=True, loss="poisson_nll"):
+    from models.patchtst import PatchTSTForSpikingActivity
+    cfg = update_config("configs/patchtst.yaml", over)
+    torch.manual_seed(1)
+    kw = dict(method_name=method)
+    if method == "ctc":
+        kw.update(vocab_size=vocab, blank_id=0, zero_infinity=True)
+    else:
+        kw.update(log_input=log_input, loss=loss)
+    model = PatchTSTForSpikingActivity(cfg, **kw)
+    ec = model.config.encoder
+    T, C = ec["context_length"], ec["num_input_channels"]
+    g = np.random.default_rng(0)
+    spikes = (g.poisson(0.8, (B, T, C)) if method == "mlm" else g.standard_normal((B, T, C))).astype(np.float32)
+    smask = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):          # right padding (trainer_ctc_ndt1.yaml-style collate)
+        spikes[b, L:] = 0; smask[b, :L] = 1
+    batch = {"spikes": torch.from_numpy(spikes), "spikes_mask": torch.from_numpy(smask), "spikes_lengths": torch.tensor(lens)}
+    if method == "ctc":
+        S = max(tgt_lens)
+        tg = np.zeros((B, S), np.int64)
+        for b, n in enumerate(tgt_lens):
+            tg[b, :n] = g.integers(1, vocab, n)
+        batch["targets"] = torch.from_numpy(tg); batch["targets_lengths"] = torch.tensor(tgt_lens)
+    fx = {"in_" + k: v.numpy() for k, v in batch.items()}
+    inter, masks = {}, []
+    enc = model.encoder
+    hs = [enc.encoder.positional_encoder.register_forward_hook(lambda m, i, o: inter.__setitem__("embed", o.detach()))]
+    for i, lyr in enumerate(enc.encoder.layers):
+        hs.append(lyr.register_forward_hook(lambda m, inp, o, i=i: inter.__setitem__(f"layer{i}", o[0].detach())))
+    if ec["do_mask_input"]:
+        hs.append(enc.masking.register_forward_hook(lambda m, i, o: masks.append(o[1].numpy().copy())))
+    cut = (lambda a: a) if full else (lambda a: a[..., ::7, ::13])
+
+    def record(tag, out):
+        fx[tag + "_loss"] = out.loss.detach().numpy(); fx[tag + "_n_examples"] = out.n_examples.numpy()
+        fx[tag + "_preds"] = out.preds.detach().numpy() if full else out.preds.detach().numpy()[..., ::3, :]
+        if method == "mlm":
+            fx[tag + "_mask"] = out.mask.numpy(); fx[tag + "_raw_mask"] = masks[-1]
+        fx[tag + "_embed"] = cut(inter["embed"].numpy())
+        for i in range(len(enc.encoder.layers)):
+            fx[f"{tag}_layer{i}"] = cut(inter[f"layer{i}"].numpy())
+
+    model.eval()
+    with torch.no_grad():
+        out = model(**{k: v.clone() for k, v in batch.items()})
+    record("eval0", out)
+    if method == "mlm":
+        fx["patch_input"] = out.patch_input.numpy() if full else out.patch_input.numpy()[:, ::3]
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=100, max_lr=1e-3, pct_start=0.0, div_factor=25)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for s in range(steps):
+        out = model(**{k: v.clone() for k, v in batch.items()})
+        out.loss.backward()
+        record(f"step{s}", out)
+        if s == 0:
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                if full:
+                    fx["grad:" + k] = p.grad.numpy().copy()
+                else:
+                    sm = summarise(p.grad)
+                    fx["gsum:" + k] = np.array([sm["sum"], sm["abssum"]]); fx["gidx:" + k], fx["gval:" + k] = sm["idx"], sm["val"]
+        opt.step(); sched.step(); opt.zero_grad()
+    model.eval()
+    with torch.no_grad():
+        out = model(**{k: v.clone() for k, v in batch.items()})
+    record("eval2", out)      # uses the BatchNorm running statistics of the two train steps
+    for k, v in model.state_dict().items():
+        v = v.float() if v.dtype == torch.int64 else v
+        if full:
+            fx["w0:" + k] = sd0[k].float().numpy(); fx["w2:" + k] = v.numpy()
+        else:
+            a, b = summarise(sd0[k].float()), summarise(v)
+            fx["w0sum:" + k] = np.array([a["sum"], a["abssum"]]); fx["w0idx:" + k], fx["w0val:" + k] = a["idx"], a["val"]
+            fx["w2val:" + k] = b["val"]
+    fx["config_json"] = np.array(json.dumps(over)); fx["lens"] = np.array(lens)
+    fx["kwargs_json"] = np.array(json.dumps({k: v for k, v in kw.items()}))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(name, "eval loss", float(fx["eval0_loss"]), "train loss", float(fx["step0_loss"]), "n", int(fx["step0_n_examples"]),
+          "params", sum(p.numel() for p in model.parameters()), list(sd0)[:4], out.preds.shape)
+
+
+def ptst_tiny(**enc_extra):
+    enc = {"num_input_channels": 6, "context_length": 45, "patch_length": 10, "patch_stride": 10, "num_hidden_layers": 2, "d_model": 32,
+           "num_attention_heads": 2, "ffn_dim": 64, "attention_dropout": 0.0, "ff_dropout": 0.0, "do_mask_input": False}
+    enc.update(enc_extra)
+    return {"encoder": enc}
+
+
+if __name__ == "__main__" and "--ptst" in sys.argv:
+    ptst_case("g_ptst_tiny", ptst_tiny(), "ctc", 3, [45, 38, 30], [2, 2, 1])
+    ptst_case("g_ptst_tiny_ov", {**ptst_tiny(patch_stride=5, context_length=48), "decoder": {"mlp_decoder": True}}, "ctc", 3, [48, 40, 29], [4, 3, 2])
+    ptst_case("g_ptst_tiny_mlm", ptst_tiny(do_mask_input=True, random_mask_ratio=0.4), "mlm", 3, [45, 38, 30])
+    ptst_case("g_ptst_tiny_mlm_rate", ptst_tiny(do_mask_input=True, random_mask_ratio=0.4), "mlm", 3, [45, 38, 30], log_input=False)
+    ptst_case("g_ptst_c5", {"encoder": {"num_input_channels": 16, "context_length": 2050, "attention_dropout": 0.0, "ff_dropout": 0.0,
+                                         "do_mask_input": False}}, "ctc", 2, [2050, 1500], [60, 40], vocab=41, full=False)
