@@ -348,6 +348,74 @@ int nbci_itr_forward(nbci_itr_plan plan, const float* params, const void* params
 int nbci_itr_backward(nbci_itr_plan plan, const float* params, const void* params_lp, const nbci_itr_io* io, float* grads,
                       int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * PatchTST model level: PatchTSTForSpikingActivity.forward (models/patchtst.py:214-255) with PredictHead (ctc, :70-94)
+ * or PretrainHead (mlm, :139-154) over the encoder the reference takes from HF transformers (PatchTSTModel,
+ * patchtst.py:8,176): NOP scaler, patchify, random patch masking, shared patch embedding + fixed sincos positions,
+ * pre-norm layers [BatchNorm1d over all (b,c,p) rows -> MHA over the patches of one channel -> residual;
+ * BatchNorm1d -> Linear, GELU, Dropout, Linear -> residual]. share_embedding / share_projection true,
+ * channel_attention false, norm_type batchnorm, pooling mean (the configs/patchtst.yaml settings).
+ *
+ * Besides the flat trainable parameters there is an `aux` f32 buffer the state dict also carries:
+ *   [position_enc (P,D) | per layer: norm1 running_mean, running_var, norm3 running_mean, running_var (D each)]
+ * and an int64 buffer nbt[2L] (num_batches_tracked). Train-mode forwards update the running statistics in place.
+ */
+enum { NBCI_PTST_CTC = 0, NBCI_PTST_MLM = 1 };
+typedef struct nbci_ptst_config { /* configs/patchtst.yaml, flattened */
+    int32_t num_input_channels, context_length, patch_length, patch_stride, num_hidden_layers, d_model, num_attention_heads, ffn_dim;
+    float norm_eps, attention_dropout, positional_dropout, path_dropout, ff_dropout;
+    int32_t act;                       /* NBCI_ACT_GELU */
+    int32_t do_mask_input;
+    float random_mask_ratio;
+    int32_t channel_consistent_masking;
+    float mask_value;
+    int32_t method;                    /* NBCI_PTST_CTC | NBCI_PTST_MLM */
+    int32_t vocab, blank_id, zero_infinity;
+    int32_t mlp_decoder, dec_act;
+    int32_t loss;                      /* NBCI_LOSS_* (mlm) */
+    int32_t dtype;
+} nbci_ptst_config;
+
+typedef struct nbci_ptst_io {
+    int32_t B, S;                       /* batch, padded target length (ctc; 0 otherwise) */
+    const float* spikes;                /* (B,T,C) f32, T = context_length */
+    const int64_t* spikes_mask;         /* (B,T) */
+    const int64_t* spikes_lengths;      /* (B) (ctc) */
+    const int64_t* targets;             /* (B,S) (ctc) */
+    const int64_t* targets_lengths;     /* (B) */
+    const uint8_t* ext_mask;            /* (B,C,P) 0/1: replaces the random patch mask (tests / replay), or NULL */
+    int32_t train, want_grad;
+    uint32_t seed;
+    float grad_scale;
+    float* aux;                         /* see above; running statistics updated when train */
+    int64_t* nbt;
+    float* preds;                       /* out: ctc (B,P,V) log-probs; mlm (B,C,P,patch_length) */
+    float* patch_input;                 /* out (B,C,P,patch_length): the un-masked patches (PatchTSTModelOutput.patch_input) or NULL */
+    uint8_t* mask_out;                  /* out (B,C,P): mlm loss mask (model mask & unpadded patches) or NULL */
+    float* loss;                        /* out: ctc (B) per-sample losses; mlm (1) */
+    int64_t* n_examples;                /* out (1) (mlm: number of masked unpadded patches) */
+    int32_t* argmax;                    /* out (B,P) greedy path (ctc) or NULL */
+    void* hidden_out;                   /* out (B,C,P,D) last_hidden_state in f32, or NULL */
+    void* workspace;
+    int64_t workspace_bytes;
+} nbci_ptst_io;
+
+typedef void* nbci_ptst_plan;
+int nbci_ptst_plan_create(const nbci_ptst_config* cfg, nbci_ptst_plan* out);
+void nbci_ptst_plan_destroy(nbci_ptst_plan plan);
+int64_t nbci_ptst_param_count(nbci_ptst_plan plan);
+int32_t nbci_ptst_num_params(nbci_ptst_plan plan);
+int32_t nbci_ptst_num_segments(nbci_ptst_plan plan);
+int nbci_ptst_param_info(nbci_ptst_plan plan, int32_t index, char* name, int32_t name_cap, int64_t* offset, int64_t* numel,
+                         int32_t* rows, int32_t* cols, int32_t* segment);
+int nbci_ptst_segment_range(nbci_ptst_plan plan, int32_t seg, int64_t* begin, int64_t* end);
+int32_t nbci_ptst_num_patches(nbci_ptst_plan plan);
+int64_t nbci_ptst_aux_floats(nbci_ptst_plan plan);
+int64_t nbci_ptst_workspace_bytes(nbci_ptst_plan plan, int32_t B, int32_t S);
+int nbci_ptst_forward(nbci_ptst_plan plan, const float* params, const void* params_lp, const nbci_ptst_io* io, nbci_stream_t stream);
+int nbci_ptst_backward(nbci_ptst_plan plan, const float* params, const void* params_lp, const nbci_ptst_io* io, float* grads,
+                       int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

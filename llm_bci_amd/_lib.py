@@ -90,7 +90,39 @@ class ItrIO(C.Structure):
                 ("hidden_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
+class PtstConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_input_channels", "context_length", "patch_length", "patch_stride", "num_hidden_layers",
+                                         "d_model", "num_attention_heads", "ffn_dim")] + [
+        (n, C.c_float) for n in ("norm_eps", "attention_dropout", "positional_dropout", "path_dropout", "ff_dropout")] + [
+        ("act", C.c_int32), ("do_mask_input", C.c_int32), ("random_mask_ratio", C.c_float), ("channel_consistent_masking", C.c_int32),
+        ("mask_value", C.c_float), ("method", C.c_int32), ("vocab", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32),
+        ("mlp_decoder", C.c_int32), ("dec_act", C.c_int32), ("loss", C.c_int32), ("dtype", C.c_int32)]
+
+
+class PtstIO(C.Structure):
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("spikes", C.c_void_p), ("spikes_mask", C.c_void_p), ("spikes_lengths", C.c_void_p),
+                ("targets", C.c_void_p), ("targets_lengths", C.c_void_p), ("ext_mask", C.c_void_p),
+                ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
+                ("aux", C.c_void_p), ("nbt", C.c_void_p), ("preds", C.c_void_p), ("patch_input", C.c_void_p), ("mask_out", C.c_void_p),
+                ("loss", C.c_void_p), ("n_examples", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 _SIGNATURES = {
+    "nbci_ptst_plan_create": (C.c_int, [C.POINTER(PtstConfig), C.POINTER(C.c_void_p)]),
+    "nbci_ptst_plan_destroy": (None, [C.c_void_p]),
+    "nbci_ptst_param_count": (C.c_int64, [C.c_void_p]),
+    "nbci_ptst_num_params": (C.c_int32, [C.c_void_p]),
+    "nbci_ptst_num_segments": (C.c_int32, [C.c_void_p]),
+    "nbci_ptst_num_patches": (C.c_int32, [C.c_void_p]),
+    "nbci_ptst_aux_floats": (C.c_int64, [C.c_void_p]),
+    "nbci_ptst_param_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "nbci_ptst_segment_range": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nbci_ptst_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "nbci_ptst_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtstIO), C.c_void_p]),
+    "nbci_ptst_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtstIO), C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_void_p]),
     "nbci_masker": (C.c_int, [C.POINTER(MaskerDesc), C.c_void_p]),
     "nbci_itr_plan_create": (C.c_int, [C.POINTER(ItrConfig), C.POINTER(C.c_void_p)]),
     "nbci_itr_plan_destroy": (None, [C.c_void_p]),

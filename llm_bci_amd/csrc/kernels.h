@@ -101,6 +101,24 @@ int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const 
                         int64_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int N, int use_cls,
                         int kind, float grad_scale, hipStream_t s);
 
+// ---- PatchTST path (ptst_kernels.hip) ----
+int ptst_mask_launch(uint8_t* mask, int B, int C, int P, float ratio, int channel_consistent, uint32_t seed, uint32_t site, hipStream_t s);
+int ptst_patchify_launch(const float* x, float* patch, float* xm, const uint8_t* mask, int B, int T, int C, int P, int pl, int stride,
+                         int start, float mask_value, hipStream_t s);
+int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, float* h, long long M, int P, int pl, int D,
+                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+size_t bn_partial_floats(long long M, int D);
+int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s);
+int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
+                         float* partials, float* sums, long long M, int D, int train, hipStream_t s);
+int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s);
+int ptst_pool_bwd_launch(const float* dpooled, float* dh, int B, int C, int P, int D, hipStream_t s);
+int ptst_lens_launch(const int64_t* lens, int32_t* out, int B, int pl, int stride, hipStream_t s);
+int ptst_mlm_loss_launch(const float* pred, int ldp, const float* target, const uint8_t* mask, const int64_t* smask, float* preds_out,
+                         uint8_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int C, int P, int pl,
+                         int stride, int kind, float grad_scale, hipStream_t s);
+
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
 int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,

@@ -1,0 +1,397 @@
+// ptst_kernels.hip — the non-GEMM kernels only the PatchTST path needs (models/patchtst.py over HF transformers'
+// PatchTSTModel: random patch masking, patchify, shared patch embedding + sincos positions, BatchNorm over all
+// (batch, channel, patch) rows, channel mean-pooling, per-patch mlm loss). All HBM-bound, one pass over their tensors;
+// BatchNorm column statistics are chunk partials combined with Chan's update (no atomics, deterministic, no E[x^2]-mean^2
+// cancellation). See kernels.h for the launch API.
+#include "kernels.h"
+
+namespace nbci {
+
+template <typename T> __device__ __forceinline__ void stq(T* p, long long i, float v);
+template <> __device__ __forceinline__ void stq<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stq<bf16_t>(bf16_t* p, long long i, float v) { p[i] = f2bf(v); }
+template <typename T> __device__ __forceinline__ float ldq(const T* p, long long i);
+template <> __device__ __forceinline__ float ldq<float>(const float* p, long long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldq<bf16_t>(const bf16_t* p, long long i) { return bf2f(p[i]); }
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// random_masking (transformers PatchTST): per (b,c) row the P - len_keep patches with the largest noise are masked.
+// One block per row; rank by counting (ties broken by index, = a stable argsort).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ptst_mask_kernel(unsigned char* __restrict__ mask, int B, int C, int P, int keep,
+                                                        int channel_consistent, uint32_t seed, uint32_t site) {
+    extern __shared__ unsigned noise[];
+    const int row = blockIdx.x, b = row / C;
+    for (int p = threadIdx.x; p < P; p += 256)
+        noise[p] = rng_u32(seed, site, (uint32_t)((channel_consistent ? b : row) * P + p));
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const unsigned v = noise[p];
+        int rank = 0;
+        for (int q = 0; q < P; ++q) rank += (noise[q] < v) || (noise[q] == v && q < p);
+        mask[(long long)row * P + p] = rank >= keep;
+    }
+}
+
+int ptst_mask_launch(uint8_t* mask, int B, int C, int P, float ratio, int channel_consistent, uint32_t seed, uint32_t site,
+                     hipStream_t s) {
+    NBCI_REQUIRE(ratio >= 0.f && ratio < 1.f, NBCI_EINVAL, "Mask ratio has to be between 0 and 1.");
+    NBCI_REQUIRE(P <= 8192, NBCI_ESHAPE, "ptst mask: at most 8192 patches");
+    NBCI_REQUIRE((long long)B * C * P < (1ll << 32), NBCI_ESHAPE, "ptst mask: tensor too large for the RNG counter");
+    const int keep = (int)((double)P * (1.0 - (double)ratio));   // int(sequence_length * (1 - mask_ratio))
+    hipLaunchKernelGGL(ptst_mask_kernel, dim3(B * C), dim3(256), P * sizeof(unsigned), s, mask, B, C, P, keep, channel_consistent, seed, site);
+    return check_launch("ptst_mask");
+}
+
+// ------------------------------------------------------------------------------------------
+// patchify (PatchTSTPatchify): patch[b,c,p,j] = x[b, start + p*stride + j, c]; xm = masked copy (mask_value where masked).
+// 32x32 LDS tile: reads coalesced along channels, writes coalesced along (p,j).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ptst_patchify_kernel(const float* __restrict__ x, float* __restrict__ patch, float* __restrict__ xm,
+                                                            const unsigned char* __restrict__ mask, int T, int C, int P, int pl, int stride,
+                                                            int start, float mask_value) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, e0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int E = P * pl;
+    for (int r = ty; r < 32; r += 8) {
+        const int e = e0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (e < E && c < C) { const int p = e / pl, j = e - p * pl; v = x[((long long)b * T + start + p * stride + j) * C + c]; }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, e = e0 + tx;
+        if (c < C && e < E) {
+            const float v = tile[tx][r];
+            const long long o = ((long long)b * C + c) * E + e;
+            if (patch) patch[o] = v;
+            const bool m = mask && mask[((long long)b * C + c) * P + e / pl];
+            xm[o] = m ? mask_value : v;
+        }
+    }
+}
+
+int ptst_patchify_launch(const float* x, float* patch, float* xm, const uint8_t* mask, int B, int T, int C, int P, int pl, int stride,
+                         int start, float mask_value, hipStream_t s) {
+    hipLaunchKernelGGL(ptst_patchify_kernel, dim3((C + 31) / 32, (P * pl + 31) / 32, B), dim3(256), 0, s, x, patch, xm, mask, T, C, P, pl,
+                       stride, start, mask_value);
+    return check_launch("ptst_patchify");
+}
+
+// ------------------------------------------------------------------------------------------
+// shared patch embedding + positions (+ positional dropout): h[row,:] = xm[row,:] W^T + b + pos[row % P, :]
+// K = patch_length (10): a per-thread dot product, the kernel is bound by the (M, D) f32 write.
+// ------------------------------------------------------------------------------------------
+template <int PLMAX>
+__global__ __launch_bounds__(256) void ptst_embed_kernel(const float* __restrict__ xm, const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ pos, float* __restrict__ h, long long M, int P, int pl, int D,
+                                                         unsigned thr, float dscale, uint32_t key) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = (row, 4 consecutive d)
+    const int dq = D / 4;
+    if (i >= M * dq) return;
+    const long long row = i / dq;
+    const int d = (int)(i % dq) * 4;
+    float xv[PLMAX];
+#pragma unroll
+    for (int j = 0; j < PLMAX; ++j) xv[j] = j < pl ? xm[row * pl + j] : 0.f;
+    const int p = (int)(row % P);
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float acc = bias[d + e];
+        const float* w = W + (long long)(d + e) * pl;
+#pragma unroll
+        for (int j = 0; j < PLMAX; ++j) if (j < pl) acc += xv[j] * w[j];
+        r[e] = acc + pos[(long long)p * D + d + e];
+    }
+    const long long o = row * D + d;
+    if (thr) drop4(key, thr, (unsigned)o, dscale, r);
+    *(float4*)(h + o) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, float* h, long long M, int P, int pl, int D,
+                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(pl <= 32 && D % 4 == 0, NBCI_ESHAPE, "ptst embed: patch_length <= 32 and d_model % 4 == 0");
+    NBCI_REQUIRE(M * D < (1ll << 32), NBCI_ESHAPE, "ptst embed: tensor too large for the dropout counter");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const long long n = M * (D / 4);
+    dim3 g((unsigned)((n + 255) / 256));
+    if (pl <= 16) hipLaunchKernelGGL((ptst_embed_kernel<16>), g, dim3(256), 0, s, xm, W, bias, pos, h, M, P, pl, D, thr, dscale, drop_key(seed, site));
+    else hipLaunchKernelGGL((ptst_embed_kernel<32>), g, dim3(256), 0, s, xm, W, bias, pos, h, M, P, pl, D, thr, dscale, drop_key(seed, site));
+    return check_launch("ptst_embed");
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm1d over rows (nn.BatchNorm1d(D) on (B*C, D, P): statistics over all M = B*C*P rows per feature)
+// ------------------------------------------------------------------------------------------
+constexpr int BN_ROWS = 128;   // rows per chunk
+
+// per (chunk, column): count, mean, M2 — shifted accumulation inside the chunk
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long long M, int D) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= D) return;
+    const long long r0 = (long long)blockIdx.x * BN_ROWS;
+    const long long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+    const float K = x[r0 * D + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = r0; r < r1; ++r) { const float v = x[r * D + c] - K; s1 += v; s2 += v * v; }
+    const float n = (float)(r1 - r0);
+    const float mean = K + s1 / n;
+    const float m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
+    float* o = part + ((long long)blockIdx.x * 2) * D;
+    o[c] = mean; o[D + c] = m2;
+}
+
+// combine the chunk partials (Chan et al.), produce mean / rstd for the normalisation and update the running statistics
+// (momentum 0.1, unbiased variance) in train mode; in eval mode just turn the running statistics into mean / rstd.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunks, long long M, int D, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, int train) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    if (!train) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); return; }
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        const long long r0 = (long long)k * BN_ROWS;
+        const double nb = (double)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
+        const double mb = part[((long long)k * 2) * D + c], m2b = part[((long long)k * 2 + 1) * D + c];
+        const double delta = mb - mu, tot = n + nb;
+        mu += delta * nb / tot;
+        m2 += m2b + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    const double var = m2 / n;
+    mean[c] = (float)mu; rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    run_mean[c] = 0.9f * run_mean[c] + 0.1f * (float)mu;
+    run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(n > 1.0 ? m2 / (n - 1.0) : var);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ w, const float* __restrict__ b, TO* __restrict__ y, long long n4,
+                                                       int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % D);
+    const float4 v = *(const float4*)(x + i * 4);
+    const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c), ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
+    stq<TO>(y, i * 4 + 0, (v.x - mu.x) * rs.x * ww.x + bb.x);
+    stq<TO>(y, i * 4 + 1, (v.y - mu.y) * rs.y * ww.y + bb.y);
+    stq<TO>(y, i * 4 + 2, (v.z - mu.z) * rs.z * ww.z + bb.z);
+    stq<TO>(y, i * 4 + 3, (v.w - mu.w) * rs.w * ww.w + bb.w);
+}
+
+size_t bn_partial_floats(long long M, int D) { return (size_t)((M + BN_ROWS - 1) / BN_ROWS) * 2 * D; }
+
+int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s) {
+    NBCI_REQUIRE(D % 4 == 0, NBCI_ESHAPE, "batchnorm: features must be a multiple of 4");
+    const int nchunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    if (train) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, x, partials, M, D);
+        int rc = check_launch("bn_stats");
+        if (rc != NBCI_OK) return rc;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partials, nchunks, M, D, eps, mean, rstd, run_mean, run_var, train);
+    int rc = check_launch("bn_finalize");
+    if (rc != NBCI_OK) return rc;
+    const long long n4 = M * D / 4;
+    dim3 g((unsigned)((n4 + 255) / 256));
+    if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, n4, D);
+    else hipLaunchKernelGGL((bn_apply_kernel<float>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, n4, D);
+    return check_launch("bn_apply");
+}
+
+// backward pass 1: per (chunk, column) sums of dy and dy * xhat
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ part, long long M, int D) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= D) return;
+    const long long r0 = (long long)blockIdx.x * BN_ROWS;
+    const long long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+    const float mu = mean[c], rs = rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = r0; r < r1; ++r) { const float g = dy[r * D + c]; s1 += g; s2 += g * (x[r * D + c] - mu) * rs; }
+    float* o = part + ((long long)blockIdx.x * 2) * D;
+    o[c] = s1; o[D + c] = s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int D, float* __restrict__ sums,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunks; ++k) { a += part[((long long)k * 2) * D + c]; b += part[((long long)k * 2 + 1) * D + c]; }
+    sums[c] = (float)a; sums[D + c] = (float)b;
+    db[c] += (float)a; dw[c] += (float)b;
+}
+
+// pass 2: dx += w * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M)   (eval mode: dx += dy * w * rstd)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ sums,
+                                                           float* __restrict__ dx, long long n4, int D, float invM, int train) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % D);
+    const float4 g = *(const float4*)(dy + i * 4), v = *(const float4*)(x + i * 4);
+    float4 o = *(const float4*)(dx + i * 4);
+    const float gg[4] = {g.x, g.y, g.z, g.w}, vv[4] = {v.x, v.y, v.z, v.w};
+    float oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float rs = rstd[c + e], ww = w[c + e];
+        if (train) {
+            const float xh = (vv[e] - mean[c + e]) * rs;
+            oo[e] += ww * rs * (gg[e] - sums[c + e] * invM - xh * sums[D + c + e] * invM);
+        } else {
+            oo[e] += gg[e] * ww * rs;
+        }
+    }
+    *(float4*)(dx + i * 4) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+}
+
+int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
+                         float* partials, float* sums, long long M, int D, int train, hipStream_t s) {
+    const int nchunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, dy, x, mean, rstd, partials, M, D);
+    int rc = check_launch("bn_bwd_stats");
+    if (rc != NBCI_OK) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partials, nchunks, D, sums, dw, db);
+    rc = check_launch("bn_bwd_finalize");
+    if (rc != NBCI_OK) return rc;
+    const long long n4 = M * D / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dy, x, mean, rstd, w, sums, dx, n4, D,
+                       1.0f / (float)M, train);
+    return check_launch("bn_bwd_apply");
+}
+
+// ------------------------------------------------------------------------------------------
+// PredictHead pooling (patchtst.py:89): pooled[(b,p), :] = mean_c h[b,c,p,:]; backward broadcasts d/C to every channel
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const float* __restrict__ h, TO* __restrict__ pooled, int B, int C, int P, int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, p, d/4)
+    const int dq = D / 4;
+    if (i >= (long long)B * P * dq) return;
+    const int d = (int)(i % dq) * 4;
+    const long long bp = i / dq;
+    const int p = (int)(bp % P), b = (int)(bp / P);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < C; ++c) {
+        const float4 v = *(const float4*)(h + (((long long)b * C + c) * P + p) * D + d);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float inv = 1.0f / (float)C;
+    const long long o = bp * D + d;
+    stq<TO>(pooled, o + 0, a.x * inv); stq<TO>(pooled, o + 1, a.y * inv); stq<TO>(pooled, o + 2, a.z * inv); stq<TO>(pooled, o + 3, a.w * inv);
+}
+
+__global__ __launch_bounds__(256) void ptst_pool_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dh, int B, int C, int P, int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, c, p, d/4)
+    const int dq = D / 4;
+    if (i >= (long long)B * C * P * dq) return;
+    const int d = (int)(i % dq) * 4;
+    const long long row = i / dq;
+    const int p = (int)(row % P);
+    const int b = (int)(row / ((long long)C * P));
+    const float4 v = *(const float4*)(dpooled + ((long long)b * P + p) * D + d);
+    const float inv = 1.0f / (float)C;
+    *(float4*)(dh + row * D + d) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
+int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s) {
+    const long long n = (long long)B * P * (D / 4);
+    dim3 g((unsigned)((n + 255) / 256));
+    if (dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t>), g, dim3(256), 0, s, h, (bf16_t*)pooled, B, C, P, D);
+    else hipLaunchKernelGGL((ptst_pool_fwd_kernel<float>), g, dim3(256), 0, s, h, (float*)pooled, B, C, P, D);
+    return check_launch("ptst_pool_fwd");
+}
+
+int ptst_pool_bwd_launch(const float* dpooled, float* dh, int B, int C, int P, int D, hipStream_t s) {
+    const long long n = (long long)B * C * P * (D / 4);
+    hipLaunchKernelGGL(ptst_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpooled, dh, B, C, P, D);
+    return check_launch("ptst_pool_bwd");
+}
+
+// patchtst.py:239: lens = trunc(1 + (len - patch_length) / patch_stride)
+__global__ void ptst_lens_kernel(const long long* __restrict__ lens, int* __restrict__ out, int B, int pl, int stride) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < B) out[i] = (int)truncf(1.0f + ((float)lens[i] - (float)pl) / (float)stride);
+}
+
+int ptst_lens_launch(const int64_t* lens, int32_t* out, int B, int pl, int stride, hipStream_t s) {
+    hipLaunchKernelGGL(ptst_lens_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const long long*)lens, out, B, pl, stride);
+    return check_launch("ptst_lens");
+}
+
+// ------------------------------------------------------------------------------------------
+// PretrainHead tail + masked loss (patchtst.py:139-154, 225-231): rows (b,c,p), pl values each.
+// row mask = model mask & (spikes_mask windows starting at bin 0 — the reference's unfold, NOT the patchifier's start).
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void ptst_mlm_loss_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target,
+                                                            const unsigned char* __restrict__ mask, const long long* __restrict__ smask,
+                                                            float* __restrict__ preds_out, unsigned char* __restrict__ mask_out,
+                                                            TO* __restrict__ dpred, float* __restrict__ loss, unsigned long long* __restrict__ nex,
+                                                            long long M, int T, int C, int P, int pl, int stride, int kind, float gscale) {
+    __shared__ float red[4];
+    __shared__ unsigned cnt[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (row, j)
+    float lsum = 0.f;
+    unsigned lcnt = 0;
+    if (i < M * pl) {
+        const long long row = i / pl;
+        const int j = (int)(i - row * pl);
+        const int p = (int)(row % P);
+        const int b = (int)(row / ((long long)C * P));
+        bool valid = true;
+        for (int q = 0; q < pl; ++q) valid = valid && smask[(long long)b * T + p * stride + q] != 0;
+        const bool m = mask[row] && valid;
+        const float raw = pred[row * ldp + j], y = target[i];
+        float pr = raw, el, dl;
+        if (kind == NBCI_LOSS_POISSON_LOG) { const float e = expf(pr); el = e - y * pr; dl = e - y; }
+        else if (kind == NBCI_LOSS_POISSON_RATE) { pr = fmaxf(raw, 0.f); el = pr - y * logf(pr + 1e-8f); dl = raw > 0.f ? 1.f - y / (pr + 1e-8f) : 0.f; }
+        else { const float df = pr - y; el = df * df; dl = 2.f * df; }
+        preds_out[i] = pr;
+        if (j == 0) { mask_out[row] = m; lcnt = m; }
+        if (m) lsum = el;
+        if (dpred) stq<TO>(dpred, row * ldp + j, m ? dl * gscale : 0.f);
+    }
+    lsum = wave_sum(lsum);
+    const float fc = wave_sum((float)lcnt);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lsum; cnt[threadIdx.x >> 6] = (unsigned)fc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(nex, (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));
+    }
+}
+
+int ptst_mlm_loss_launch(const float* pred, int ldp, const float* target, const uint8_t* mask, const int64_t* smask, float* preds_out,
+                         uint8_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int C, int P, int pl,
+                         int stride, int kind, float grad_scale, hipStream_t s) {
+    NBCI_REQUIRE(kind >= NBCI_LOSS_POISSON_LOG && kind <= NBCI_LOSS_MSE, NBCI_EINVAL, "ptst mlm loss: unknown loss kind");
+    const long long M = (long long)B * C * P;
+    NBCI_CHECK_HIP(hipMemsetAsync(loss, 0, 4, s));
+    NBCI_CHECK_HIP(hipMemsetAsync(n_examples, 0, 8, s));
+    if (dpred) NBCI_CHECK_HIP(hipMemsetAsync(dpred, 0, (size_t)M * ldp * (d_dtype == NBCI_BF16 ? 2 : 4), s));
+    dim3 g((unsigned)((M * pl + 255) / 256));
+    if (d_dtype == NBCI_BF16)
+        hipLaunchKernelGGL((ptst_mlm_loss_kernel<bf16_t>), g, dim3(256), 0, s, pred, ldp, target, mask, (const long long*)smask, preds_out, mask_out,
+                           (bf16_t*)dpred, loss, (unsigned long long*)n_examples, M, T, C, P, pl, stride, kind, grad_scale);
+    else
+        hipLaunchKernelGGL((ptst_mlm_loss_kernel<float>), g, dim3(256), 0, s, pred, ldp, target, mask, (const long long*)smask, preds_out, mask_out,
+                           (float*)dpred, loss, (unsigned long long*)n_examples, M, T, C, P, pl, stride, kind, grad_scale);
+    return check_launch("ptst_mlm_loss");
+}
+
+}  // namespace nbci

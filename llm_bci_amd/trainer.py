@@ -18,8 +18,9 @@ from .schedule import LinearWarmup, OneCycle, StepDecay
 
 from .bci import BCI  # noqa: E402
 from .itransformer import iTransformer  # noqa: E402
+from .patchtst import PatchTSTForSpikingActivity  # noqa: E402
 
-NAME2MODEL = {"NDT1": NDT1, "BCI": BCI, "iTransformer": iTransformer}
+NAME2MODEL = {"NDT1": NDT1, "BCI": BCI, "iTransformer": iTransformer, "PatchTST": PatchTSTForSpikingActivity}
 
 
 def register_into(reference_trainer_module):
@@ -27,6 +28,7 @@ def register_into(reference_trainer_module):
     reference_trainer_module.NAME2MODEL["NDT1"] = NDT1
     reference_trainer_module.NAME2MODEL["BCI"] = BCI
     reference_trainer_module.NAME2MODEL["iTransformer"] = iTransformer
+    reference_trainer_module.NAME2MODEL["PatchTST"] = PatchTSTForSpikingActivity
 
 
 class NativeTrainer:
