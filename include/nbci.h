@@ -366,7 +366,7 @@ typedef struct nbci_ptst_config { /* configs/patchtst.yaml, flattened */
     float norm_eps, attention_dropout, positional_dropout, path_dropout, ff_dropout;
     int32_t act;                       /* NBCI_ACT_GELU */
     int32_t do_mask_input;
-    float random_mask_ratio;
+    double random_mask_ratio;          /* double: len_keep = int(P * (1 - ratio)) must round as the reference's Python float does */
     int32_t channel_consistent_masking;
     float mask_value;
     int32_t method;                    /* NBCI_PTST_CTC | NBCI_PTST_MLM */

@@ -102,7 +102,7 @@ int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const 
                         int kind, float grad_scale, hipStream_t s);
 
 // ---- PatchTST path (ptst_kernels.hip) ----
-int ptst_mask_launch(uint8_t* mask, int B, int C, int P, float ratio, int channel_consistent, uint32_t seed, uint32_t site, hipStream_t s);
+int ptst_mask_launch(uint8_t* mask, int B, int C, int P, double ratio, int channel_consistent, uint32_t seed, uint32_t site, hipStream_t s);
 int ptst_patchify_launch(const float* x, float* patch, float* xm, const uint8_t* mask, int B, int T, int C, int P, int pl, int stride,
                          int start, float mask_value, hipStream_t s);
 int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, float* h, long long M, int P, int pl, int D,

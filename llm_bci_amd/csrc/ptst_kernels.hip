@@ -39,12 +39,12 @@ __global__ __launch_bounds__(256) void ptst_mask_kernel(unsigned char* __restric
     }
 }
 
-int ptst_mask_launch(uint8_t* mask, int B, int C, int P, float ratio, int channel_consistent, uint32_t seed, uint32_t site,
+int ptst_mask_launch(uint8_t* mask, int B, int C, int P, double ratio, int channel_consistent, uint32_t seed, uint32_t site,
                      hipStream_t s) {
-    NBCI_REQUIRE(ratio >= 0.f && ratio < 1.f, NBCI_EINVAL, "Mask ratio has to be between 0 and 1.");
+    NBCI_REQUIRE(ratio >= 0.0 && ratio < 1.0, NBCI_EINVAL, "Mask ratio has to be between 0 and 1.");
     NBCI_REQUIRE(P <= 8192, NBCI_ESHAPE, "ptst mask: at most 8192 patches");
     NBCI_REQUIRE((long long)B * C * P < (1ll << 32), NBCI_ESHAPE, "ptst mask: tensor too large for the RNG counter");
-    const int keep = (int)((double)P * (1.0 - (double)ratio));   // int(sequence_length * (1 - mask_ratio))
+    const int keep = (int)((double)P * (1.0 - ratio));   // int(sequence_length * (1 - mask_ratio))
     hipLaunchKernelGGL(ptst_mask_kernel, dim3(B * C), dim3(256), P * sizeof(unsigned), s, mask, B, C, P, keep, channel_consistent, seed, site);
     return check_launch("ptst_mask");
 }
