@@ -459,32 +459,37 @@ constexpr int DC_ROWS = 8;  // rows per block: all 8 row loads of a thread are i
 // consecutive columns of DC_ROWS rows, so the bias-gradient column sums cost one atomic per column per block.
 template <typename TO>
 __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, int M, int N,
-                                                       unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum, RepCfg rc) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= N) return;
-    const int r0 = blockIdx.y * DC_ROWS;
-    float4 q[DC_ROWS];
-#pragma unroll
-    for (int j = 0; j < DC_ROWS; ++j)
-        q[j] = (r0 + j < M) ? *(const float4*)(in + (long long)(r0 + j) * N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                                       unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum, RepCfg rc,
+                                                       int cpt, int gpb) {
+    // cpt = column-threads per row (N / 4, at most 256 per block), gpb = row groups per block (narrow matrices keep all
+    // 256 threads busy); a block walks row groups with a grid stride so the column sums cost one atomic per thread.
+    const int cg = threadIdx.x % cpt, rg = threadIdx.x / cpt;
+    const int c = (blockIdx.x * cpt + cg) * 4;
+    if (c >= N || rg >= gpb) return;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long r0 = ((long long)blockIdx.y * gpb + rg) * DC_ROWS; r0 < M; r0 += (long long)gridDim.y * gpb * DC_ROWS) {
+        float4 q[DC_ROWS];
 #pragma unroll
-    for (int j = 0; j < DC_ROWS; ++j) {
-        if (r0 + j >= M) break;
-        const long long i = (long long)(r0 + j) * N + c;
-        float v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-        if (thr) drop4(key, thr, (unsigned)i, dscale, v);
-        if constexpr (sizeof(TO) == 2) {
-            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            *(bf16x4*)((bf16_t*)out + i) = o;
-        } else {
-            *(float4*)((float*)out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < DC_ROWS; ++j)
+            q[j] = (r0 + j < M) ? *(const float4*)(in + (r0 + j) * N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < DC_ROWS; ++j) {
+            if (r0 + j >= M) break;
+            const long long i = (r0 + j) * N + c;
+            float v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            if (thr) drop4(key, thr, (unsigned)i, dscale, v);
+            if constexpr (sizeof(TO) == 2) {
+                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)((bf16_t*)out + i) = o;
+            } else {
+                *(float4*)((float*)out + i) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
-        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
     if (colsum) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(rep_ptr(colsum, rc, blockIdx.y) + c + e, s[e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(rep_ptr(colsum, rc, blockIdx.y * gpb + rg) + c + e, s[e]);
     }
 }
 
@@ -493,10 +498,12 @@ int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, f
     NBCI_REQUIRE(N % 4 == 0, NBCI_ESHAPE, "dropcast: N must be a multiple of 4");
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    dim3 g((N / 4 + 255) / 256, (M + DC_ROWS - 1) / DC_ROWS);
+    const int cpt = std::min(256, N / 4), gpb = std::max(1, 256 / cpt);
+    const long long groups = ((long long)M + DC_ROWS - 1) / DC_ROWS;
+    dim3 g((N / 4 + cpt - 1) / cpt, (unsigned)std::min<long long>((groups + gpb - 1) / gpb, 4096));
     DISPATCH_DTYPE(out_dtype, TO,
                    hipLaunchKernelGGL((dropcast_kernel<TO>), g, dim3(256), 0, s, in, (TO*)out, M, N, thr, dscale,
-                                      drop_key(seed, site), colsum, rc));
+                                      drop_key(seed, site), colsum, rc, cpt, gpb));
     return check_launch("dropcast");
 }
 

@@ -81,7 +81,17 @@ struct WgradQueue {
     }
     int flush() {
         if (n == 0) return NBCI_OK;
-        const int rc = gemm_grouped_launch_timed(d, n, s);
+        // full-K tiles only pay off when the group fills the chip: with few output tiles and a very long K (narrow
+        // models, huge row counts) split-K launches are the better shape
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += ((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
+        int rc = NBCI_OK;
+        if (tiles >= 192) {
+            rc = gemm_grouped_launch_timed(d, n, s);
+        } else {
+            for (int i = 0; i < n && rc == NBCI_OK; ++i)
+                rc = wgrad(s, dtype, d[i].M, d[i].N, d[i].K, d[i].A, d[i].B, (float*)d[i].C, d[i].ldc);
+        }
         n = 0;
         return rc;
     }

@@ -133,7 +133,7 @@ int ptst_embed_launch(const float* xm, const float* W, const float* bias, const 
 // ------------------------------------------------------------------------------------------
 // BatchNorm1d over rows (nn.BatchNorm1d(D) on (B*C, D, P): statistics over all M = B*C*P rows per feature)
 // ------------------------------------------------------------------------------------------
-constexpr int BN_ROWS = 128;   // rows per chunk
+constexpr int BN_ROWS = 512;   // rows per chunk
 
 // per (chunk, column): count, mean, M2 — shifted accumulation inside the chunk
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long long M, int D) {
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const long long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
     const float K = x[r0 * D + c];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (long long r = r0; r < r1; ++r) { const float v = x[r * D + c] - K; s1 += v; s2 += v * v; }
     const float n = (float)(r1 - r0);
     const float mean = K + s1 / n;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (c >= D) return;
     if (!train) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); return; }
     double n = 0.0, mu = 0.0, m2 = 0.0;
+#pragma unroll 8
     for (int k = 0; k < nchunks; ++k) {
         const long long r0 = (long long)k * BN_ROWS;
         const double nb = (double)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     const long long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
     const float mu = mean[c], rs = rstd[c];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (long long r = r0; r < r1; ++r) { const float g = dy[r * D + c]; s1 += g; s2 += g * (x[r * D + c] - mu) * rs; }
     float* o = part + ((long long)blockIdx.x * 2) * D;
     o[c] = s1; o[D + c] = s2;
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
     double a = 0.0, b = 0.0;
+#pragma unroll 8
     for (int k = 0; k < nchunks; ++k) { a += part[((long long)k * 2) * D + c]; b += part[((long long)k * 2 + 1) * D + c]; }
     sums[c] = (float)a; sums[D + c] = (float)b;
     db[c] += (float)a; dw[c] += (float)b;
