@@ -131,15 +131,16 @@ static void itr_layout(ItrPlan& p) {
 
 // ---- workspace -------------------------------------------------------------------------------
 struct ItrLayerWS {
-    size_t xb, qkv, P, Pd, ad, r1, mean1, rstd1, x1b, g, r2, mean2, rstd2;
+    size_t xb, qkv, P, Pd, ad, lse, r1, mean1, rstd1, x1b, g, r2, mean2, rstd2;
 };
 struct ItrWS {
     size_t xs, h0, t2, mean_e, rstd_e, chtab, mean_c, rstd_c, dchtab, rgtab, mean_r, rstd_r, drgtab, ssidx;
     std::vector<ItrLayerWS> L;
     size_t yA, yB, xlast_b, mean_o, rstd_o, xo, d1, pred, dpred, scores;
-    size_t dY, dR, cA, cA2, dU, dAtt, dqkv, dS, dtok, dH0, rep;
+    size_t dY, dR, cA, cA2, dU, dAtt, dqkv, dS, dtok, dH0, dsum, rep;
     size_t bytes;
     int S, M, M0, ldS, ldP, ldT;
+    bool small_attn;
 };
 
 static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
@@ -166,13 +167,16 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
     w.rgtab = bump(cur, R * H * 4); w.mean_r = bump(cur, R * 4 + 4); w.rstd_r = bump(cur, R * 4 + 4); w.drgtab = bump(cur, R * H * 4);
     w.ssidx = bump(cur, M0 * 8);
     w.L.resize(c.n_layers);
-    const size_t nP = (size_t)B * c.n_heads * S * w.ldP;
+    w.small_attn = sattn_eligible(c.dtype, S, c.hidden, c.n_heads);
+    const size_t nP = w.small_attn ? 0 : (size_t)B * c.n_heads * S * w.ldP;
+    const size_t nstat = sattn_stat_floats(B, c.n_heads, S);
     for (auto& l : w.L) {
         l.xb = bump(cur, M * H * es);
         l.qkv = bump(cur, M * 3 * H * es);
         l.P = bump(cur, nP * es);
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * H * es);
+        l.lse = bump(cur, nstat * 4);
         l.r1 = bump(cur, M * H * 4);
         l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
         l.x1b = bump(cur, M * H * es);
@@ -188,7 +192,8 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
     w.d1 = bump(cur, M * H * es);
     w.pred = bump(cur, M * w.ldT * 4);
     w.dpred = bump(cur, M * w.ldT * es);
-    w.scores = bump(cur, (size_t)B * c.n_heads * S * w.ldS * 4);
+    w.scores = bump(cur, w.small_attn ? 0 : (size_t)B * c.n_heads * S * w.ldS * 4);
+    w.dsum = bump(cur, nstat * 4);
     w.dY = bump(cur, M * H * 4);
     w.dR = bump(cur, M * H * 4);
     w.cA = bump(cur, M * H * es);
@@ -302,6 +307,9 @@ int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, co
             d.bias = params + lo.inb;
             TRY(gemm_launch_timed(d, s));
         }
+        if (w.small_attn) {
+            TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B, nh, S, H, pl, io->seed, 16 + 4 * l, s));
+        } else {
         {   // scores = q k^T / sqrt(hd), batched over (b, head); no mask (itransformer.py:209)
             nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)S * 3 * H, hd),
                                   op(ws + lw.qkv, es, H, 3 * H, 1, 0, 0, (int64_t)S * 3 * H, hd), ws + w.scores, w.ldS, NBCI_F32);
@@ -316,6 +324,7 @@ int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, co
                                   op(ws + lw.qkv, es, 2 * H, 3 * H, 0, 0, 0, (int64_t)S * 3 * H, hd), ws + lw.ad, H, dt);
             d.batch = B * nh; d.zdiv = nh; d.czs1 = (int64_t)S * H; d.czs2 = hd;
             TRY(gemm_launch_timed(d, s));
+        }
         }
         {   // r1 = x + dropout1(out_proj(a))
             nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), ws + lw.r1, H, NBCI_F32);
@@ -451,6 +460,10 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
             const size_t pd = pl > 0.f ? lw.Pd : lw.P;
             const int64_t pz1 = (int64_t)nh * S * w.ldP, pz2 = (int64_t)S * w.ldP;
             const int64_t qz1 = (int64_t)S * 3 * H, az1 = (int64_t)S * H;
+            if (w.small_attn) {
+                TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt, B, nh,
+                                     S, H, pl, io->seed, 16 + 4 * l, s));
+            } else {
             {   // dPd = da v^T (f32, reuses the score buffer)
                 nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + w.dAtt, es, 0, H, 1, 0, 0, az1, hd),
                                       op(ws + lw.qkv, es, 2 * H, 3 * H, 1, 0, 0, qz1, hd), ws + w.scores, w.ldS, NBCI_F32);
@@ -476,6 +489,7 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
                                       op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
                 d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
                 TRY(gemm_launch_timed(d, s));
+            }
             }
             TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.inb), s, rc));
             TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.xb, es, 0, H, 0), grads + lo.inw, H));

@@ -119,6 +119,14 @@ int ptst_mlm_loss_launch(const float* pred, int ldp, const float* target, const 
                          uint8_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int C, int P, int pl,
                          int stride, int kind, float grad_scale, hipStream_t s);
 
+// small-head attention without a score tensor (attn_small.hip): head 16 / 32 / 64, any length, no mask
+bool sattn_eligible(int dtype, int S, int H, int nh);
+size_t sattn_stat_floats(int NS, int nh, int S);
+int sattn_fwd_launch(const void* qkv, void* out, float* L, int dtype, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site,
+                     hipStream_t s);
+int sattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int dtype, int NS, int nh, int S,
+                     int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
 int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,

@@ -113,16 +113,17 @@ static void pt_layout(PtPlan& p) {
 }
 
 struct PtLayerWS {
-    size_t x_in, mean1, rstd1, y1, qkv, P, Pd, ad, x_mid, mean3, rstd3, y3, u, g;
+    size_t x_in, mean1, rstd1, y1, qkv, P, Pd, ad, lse, x_mid, mean3, rstd3, y3, u, g;
 };
 struct PtWS {
     size_t mask, mask2, xm, patch;
     std::vector<PtLayerWS> L;
     size_t x_last, pooled, d1, logits, alpha, dlogits, argmax, tlens, pred, dpred, scores, bnpart, bnsums;
-    size_t dx, dtmp, cA, cA2, dU, dAtt, dqkv, dS, dpool, rep;
+    size_t dx, dtmp, cA, cA2, dU, dAtt, dqkv, dS, dpool, dsum, rep;
     size_t bytes;
     long long M;
     int Mh, ldS, ldP, vpad, ldp;
+    bool small_attn;
 };
 
 static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
@@ -146,7 +147,9 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.xm = bump(cur, M * pl * 4);
     w.patch = bump(cur, M * pl * 4);
     w.L.resize(c.num_hidden_layers);
-    const size_t nP = (size_t)B * C * nh * P * w.ldP;
+    w.small_attn = sattn_eligible(c.dtype, (int)P, (int)D, (int)nh);   // no score / probability tensors on that path
+    const size_t nP = w.small_attn ? 0 : (size_t)B * C * nh * P * w.ldP;
+    const size_t nstat = sattn_stat_floats(B * (int)C, (int)nh, (int)P);
     for (auto& l : w.L) {
         l.x_in = bump(cur, M * D * 4);
         l.mean1 = bump(cur, D * 4); l.rstd1 = bump(cur, D * 4);
@@ -155,6 +158,7 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
         l.P = bump(cur, nP * es);
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * D * es);
+        l.lse = bump(cur, nstat * 4);
         l.x_mid = bump(cur, M * D * 4);
         l.mean3 = bump(cur, D * 4); l.rstd3 = bump(cur, D * 4);
         l.y3 = bump(cur, M * D * es);
@@ -172,7 +176,8 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.tlens = bump(cur, (size_t)B * 4);
     w.pred = bump(cur, M * w.ldp * 4);
     w.dpred = bump(cur, M * w.ldp * es);
-    w.scores = bump(cur, (size_t)B * C * nh * P * w.ldS * 4);
+    w.scores = bump(cur, w.small_attn ? 0 : (size_t)B * C * nh * P * w.ldS * 4);
+    w.dsum = bump(cur, nstat * 4);
     w.bnpart = bump(cur, bn_partial_floats((long long)M, (int)D) * 4);
     w.bnsums = bump(cur, 2 * D * 4);
     w.dx = bump(cur, M * D * 4);
@@ -264,6 +269,9 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
             d.bias = params + lo.qb;
             TRY(gemm_launch_timed(d, s));
         }
+        if (w.small_attn) {
+            TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+        } else {
         {   // scores = q k^T / sqrt(hd), batched over (b, c, head)
             nbci_gemm_desc d = gd(P, P, hd, dt, op(ws + lw.qkv, es, 0, 3 * D, 1, 0, 0, (int64_t)P * 3 * D, hd),
                                   op(ws + lw.qkv, es, D, 3 * D, 1, 0, 0, (int64_t)P * 3 * D, hd), ws + w.scores, w.ldS, NBCI_F32);
@@ -278,6 +286,7 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
                                   op(ws + lw.qkv, es, 2 * D, 3 * D, 0, 0, 0, (int64_t)P * 3 * D, hd), ws + lw.ad, D, dt);
             d.batch = B * C * nh; d.zdiv = nh; d.czs1 = (int64_t)P * D; d.czs2 = hd;
             TRY(gemm_launch_timed(d, s));
+        }
         }
         {   // x_mid = x_in + path_dropout(out_proj(a))
             nbci_gemm_desc d = gd(Mi, D, D, dt, op(ws + lw.ad, es, 0, D, 1), op(W(lo.ow), es, 0, D, 1), x_mid, D, NBCI_F32);
@@ -439,6 +448,10 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             const int64_t pz1 = (int64_t)nh * P * w.ldP, pz2 = (int64_t)P * w.ldP;
             const int64_t qz1 = (int64_t)P * 3 * D, az1 = (int64_t)P * D;
             const int nb = B * C * nh;
+            if (w.small_attn) {
+                TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt,
+                                     B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+            } else {
             {
                 nbci_gemm_desc d = gd(P, P, hd, dt, op(ws + w.dAtt, es, 0, D, 1, 0, 0, az1, hd), op(ws + lw.qkv, es, 2 * D, 3 * D, 1, 0, 0, qz1, hd),
                                       ws + w.scores, w.ldS, NBCI_F32);
@@ -463,6 +476,7 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
                                       (char*)(ws + w.dqkv) + (size_t)D * es, 3 * D, dt);
                 d.batch = nb; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
                 TRY(gemm_launch_timed(d, s));
+            }
             }
             TRY(colsum_launch(ws + w.dqkv, dt, 3 * D, Mi, 3 * D, RG(lo.qb), s, rc));
             TRY(wq.push(3 * D, D, Mi, op(ws + w.dqkv, es, 0, 3 * D, 0), op(ws + lw.y1, es, 0, D, 0), grads + lo.qw, D));
