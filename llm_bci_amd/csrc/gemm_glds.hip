@@ -258,6 +258,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_wa
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
         case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -450,6 +451,13 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
     // small grids (at most one workgroup per CU): nothing else hides the per-tile load latency -> 4-stage pipeline
     static const bool ms_off = [] { const char* e = getenv("NBCI_GEMM_MS"); return e && e[0] == '0'; }();
+    // very small grids (<= half the CUs at 128-row tiles): 64-row tiles double the workgroup count; 5 stages of 24 KB
+    static const bool s64_off = [] { const char* e = getenv("NBCI_GEMM_S64"); return e && e[0] == '0'; }();
+    if (!ms_off && !s64_off && bm == 128 && ak && splitk == 1 && d.K % 64 == 0 && d.K >= 256 && (long)grid.x * grid.y <= 128 && d.M > 64) {
+        k.tiles_m = (d.M + 63) / 64;
+        dim3 g64(k.tiles_m * k.tiles_n, batch);
+        return bk ? launch_ms<true, true, 1, 4, 4, 2, 5>(k, g64, stream) : launch_ms<true, false, 1, 4, 4, 2, 5>(k, g64, stream);
+    }
     if (!ms_off && bm == 128 && splitk == 1 && d.K % 64 == 0 && d.K >= 256 && (long)grid.x * grid.y <= 256) {
         if (ak && bk) return launch_ms<true, true, 2, 2, 4, 4, 4>(k, grid, stream);
         if (ak && !bk) return launch_ms<true, false, 2, 2, 4, 4, 4>(k, grid, stream);
