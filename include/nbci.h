@@ -154,6 +154,23 @@ int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d
                        void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H, int32_t ctx_forward,
                        int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream);
 
+/* Unmasked multi-head attention WITHOUT a score tensor (online softmax), over a packed (NS*S, 3H) q|k|v buffer of NS
+ * sequences of S tokens; out (NS*S, H) merged heads; lse (NS*n_heads*S) f32 row log-sum-exp kept for the backward;
+ * dropout on the probabilities (site). Replaces eager_attention_forward / nn.MultiheadAttention's core under
+ * models/patchtst.py:176 and models/itransformer.py:158-173 (no attention mask on those paths).
+ *   small : head size 16 / 32 / 64, dtype f32 or bf16, one thread per query / key, K/V rows through scalar loads
+ *   flash : head size 32 / 64 / 96 / 128, bf16, one wave per 16 queries / keys on MFMA
+ * The backward writes dqkv (NS*S, 3H); dsum (NS*n_heads*S) f32 is scratch. */
+int nbci_attention_small_fwd(const void* qkv, void* out, float* lse, int32_t dtype, int32_t NS, int32_t n_heads, int32_t S, int32_t H,
+                             float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream);
+int nbci_attention_small_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum, void* dqkv, int32_t dtype,
+                             int32_t NS, int32_t n_heads, int32_t S, int32_t H, float drop_p, uint32_t seed, uint32_t site,
+                             nbci_stream_t stream);
+int nbci_attention_flash_fwd(const void* qkv, void* out, float* lse, int32_t NS, int32_t n_heads, int32_t S, int32_t H, float drop_p,
+                             uint32_t seed, uint32_t site, nbci_stream_t stream);
+int nbci_attention_flash_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum, void* dqkv, int32_t NS,
+                             int32_t n_heads, int32_t S, int32_t H, float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream);
+
 /* BCI coupler splice (models/bci.py:143-166): per example b, out[b] = cat(text[b,:d_b], spikes[b], text[b,d_b:]) for
  * embeddings (B,Lt,H)+(B,Ts,H) -> (B,Lt+Ts,H) in `dtype`, the attention mask (text mask / spike validity) and the
  * targets (-100 over the spike span). int64 masks/targets as the reference collates them. text/targets may be NULL.

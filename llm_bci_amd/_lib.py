@@ -124,6 +124,10 @@ _SIGNATURES = {
     "nbci_ptst_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtstIO), C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p]),
     "nbci_masker": (C.c_int, [C.POINTER(MaskerDesc), C.c_void_p]),
+    "nbci_attention_small_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nbci_attention_small_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nbci_attention_flash_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nbci_attention_flash_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nbci_itr_plan_create": (C.c_int, [C.POINTER(ItrConfig), C.POINTER(C.c_void_p)]),
     "nbci_itr_plan_destroy": (None, [C.c_void_p]),
     "nbci_itr_param_count": (C.c_int64, [C.c_void_p]),

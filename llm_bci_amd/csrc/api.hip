@@ -92,4 +92,23 @@ int nbci_profile_collect(double* out24) {
     return nbci::gemm_profile_collect(out24);
 }
 
+
+int nbci_attention_small_fwd(const void* qkv, void* out, float* lse, int32_t dtype, int32_t NS, int32_t n_heads, int32_t S, int32_t H,
+                             float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream) {
+    return nbci::sattn_fwd_launch(qkv, out, lse, dtype, NS, n_heads, S, H, drop_p, seed, site, (hipStream_t)stream);
+}
+int nbci_attention_small_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum, void* dqkv, int32_t dtype,
+                             int32_t NS, int32_t n_heads, int32_t S, int32_t H, float drop_p, uint32_t seed, uint32_t site,
+                             nbci_stream_t stream) {
+    return nbci::sattn_bwd_launch(qkv, out, d_out, lse, dsum, dqkv, dtype, NS, n_heads, S, H, drop_p, seed, site, (hipStream_t)stream);
+}
+int nbci_attention_flash_fwd(const void* qkv, void* out, float* lse, int32_t NS, int32_t n_heads, int32_t S, int32_t H, float drop_p,
+                             uint32_t seed, uint32_t site, nbci_stream_t stream) {
+    return nbci::fattn_fwd_launch(qkv, out, lse, NS, n_heads, S, H, drop_p, seed, site, (hipStream_t)stream);
+}
+int nbci_attention_flash_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum, void* dqkv, int32_t NS,
+                             int32_t n_heads, int32_t S, int32_t H, float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream) {
+    return nbci::fattn_bwd_launch(qkv, out, d_out, lse, dsum, dqkv, NS, n_heads, S, H, drop_p, seed, site, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,381 @@
+// attn_flash.hip — streaming (online-softmax) unmasked attention on MFMA for long sequences and head sizes 32 / 64 / 96 /
+// 128 in bf16: the iTransformer shape (1501 channel tokens, 8 heads x 96; torch.nn.TransformerEncoderLayer under
+// models/itransformer.py:158-173) and PatchTST's (205 patches, head 32). No score tensor ever reaches HBM; only the row
+// log-sum-exp (and dO.O) are kept for the backward.
+//
+// One WAVE owns 16 queries (fwd, dq) or 16 keys (dk/dv) and walks the other axis in steps of 32; the four waves of a
+// workgroup are independent (no barriers): every LDS image is wave-private and LDS executes a wave's operations in order.
+// Operand plumbing per 32-step (16x16x32 MFMA, swapped operands: lane (i16, g) of the result owns row i16, columns 4g..4g+3):
+//   * "row" fragments (16 rows x 32 k, lane = row i16, 16-byte chunk g) are loaded straight from global memory;
+//   * the operand that must be read TRANSPOSED (V for P.V, K for dS.K, Q / dO for dS^T.Q / Pd^T.dO) is copied into a
+//     32-row x 256-byte image (XOR-swizzled chunks) and fetched with ds_read_b64_tr_b16;
+//   * the probabilities never leave registers: the two 16-column score tiles of a step ARE the second MFMA operand once
+//     the transposed operand's rows are taken in the order pi(g, j) = {4g + j | 16 + 4g + (j - 4)}.
+// Dropout bits = the counter stream of the unfused softmax kernel (index ((unit*S + query)*S + key)): both paths and the
+// oracle draw identical masks.
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace nbci {
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+struct FAArgs {
+    const bf16_t* qkv;   // (NS*S, 3H)
+    bf16_t* out;         // (NS*S, H)
+    float* L;            // (NS*nh, S)
+    float* Dsum;         // (NS*nh, S)
+    const bf16_t* dout;  // (NS*S, H)
+    bf16_t* dqkv;        // (NS*S, 3H)
+    int NS, nh, S, H;
+    float scale;
+    unsigned thr; float dscale; uint32_t key;
+};
+
+constexpr int FA_IMG = 32 * 256;   // bytes of one wave-private image (32 rows x 256 B)
+
+__device__ __forceinline__ int fa_off(int row, int ch) {   // 16-byte chunk `ch` of row `row`
+    return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ bf16x8 fa_tr(const char* img, int r_lo, int r_hi, int c0, int i16) {
+    const int q = i16 >> 2, p = i16 & 3;
+    const int col = c0 + 4 * p;
+    const int ch = col >> 3, within = (col & 7) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + fa_off(r_lo + q, ch) + within));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + fa_off(r_hi + q, ch) + within));
+    union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+    u.p2.a = lo; u.p2.b = hi;
+    return u.v;
+}
+
+__device__ __forceinline__ bf16x8 fa_pack(const f32x4& lo, const f32x4& hi) {
+    bf16x8 o = {f2bf(lo[0]), f2bf(lo[1]), f2bf(lo[2]), f2bf(lo[3]), f2bf(hi[0]), f2bf(hi[1]), f2bf(hi[2]), f2bf(hi[3])};
+    return o;
+}
+
+// copy 32 rows x HD columns (rows r0.., clamped to S-1) of a strided matrix into a wave-private image
+template <int HD>
+__device__ __forceinline__ void fa_stage(char* img, const bf16_t* src, long long ld, int r0, int S, int lane) {
+    constexpr int NCH = HD / 8, PER = NCH / 2;   // chunks per row; per lane (2 lanes share a row)
+    const int row = lane >> 1;
+    int grow = r0 + row;
+    if (grow > S - 1) grow = S - 1;
+    const bf16_t* p = src + (long long)grow * ld;
+    uint4 v[PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) v[c] = *(const uint4*)(p + ((lane & 1) * PER + c) * 8);
+#pragma unroll
+    for (int c = 0; c < PER; ++c) *(uint4*)(img + fa_off(row, (lane & 1) * PER + c)) = v[c];
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.y * 4 + wave;
+    if (16 * qb >= a.S) return;                 // whole wave: no workgroup-level synchronisation anywhere
+    char* img = smem + wave * FA_IMG;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const int query = 16 * qb + i16;
+    const int qrow = query < a.S ? query : a.S - 1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+    f32x4 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    for (int k0 = 0; k0 < a.S; k0 += 32) {
+        f32x4 sc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int krow = k0 + 16 * t + i16;
+            if (krow > a.S - 1) krow = a.S - 1;
+            sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+            }
+        }
+        fa_stage<HD>(img, base + 2 * a.H, ld, k0, a.S, lane);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * t + 4 * g + r;
+                const float s = key < a.S ? sc[t][r] * a.scale : -INFINITY;
+                sc[t][r] = s;
+                cm = fmaxf(cm, s);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mn = fmaxf(m, cm);
+        const float corr = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __expf(sc[t][r] - mn);       // exp(-inf) = 0 for keys past the end
+                ps += p;
+                if (a.thr) {
+                    const int key = k0 + 16 * t + 4 * g + r;
+                    p = drop_keep(a.key, a.thr, rbase + (unsigned)key) ? p * a.dscale : 0.f;
+                }
+                sc[t][r] = p;
+            }
+        l = l * corr + ps;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
+        const bf16x8 pf = fa_pack(sc[0], sc[1]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), pf, o[db], 0, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (query < a.S) {
+        const float inv = 1.0f / l;
+        const long long obase = ((long long)sq * a.S + query) * a.H + h * HD;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            bf16x4 ov = {f2bf(o[db][0] * inv), f2bf(o[db][1] * inv), f2bf(o[db][2] * inv), f2bf(o[db][3] * inv)};
+            *(bf16x4*)(a.out + obase + 16 * db + 4 * g) = ov;
+        }
+        if (g == 0) a.L[(long long)unit * a.S + query] = m + __logf(l);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.y * 4 + wave;
+    if (16 * qb >= a.S) return;
+    char* img = smem + wave * FA_IMG;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const int query = 16 * qb + i16;
+    const int qrow = query < a.S ? query : a.S - 1;
+    bf16x8 qf[KS], df[KS];
+    float D = 0.f;
+    {
+        const bf16_t* dop = a.dout + ((long long)sq * a.S + qrow) * a.H + h * HD;
+        const bf16_t* op = a.out + ((long long)sq * a.S + qrow) * a.H + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+            df[ks] = *(const bf16x8*)(dop + 32 * ks + 8 * g);
+            const bf16x8 of = *(const bf16x8*)(op + 32 * ks + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D += bf2f(df[ks][e]) * bf2f(of[e]);
+        }
+        D += __shfl_xor(D, 16, 64);
+        D += __shfl_xor(D, 32, 64);
+    }
+    const float Li = a.L[(long long)unit * a.S + qrow];
+    f32x4 dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    for (int k0 = 0; k0 < a.S; k0 += 32) {
+        f32x4 sc[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int krow = k0 + 16 * t + i16;
+            if (krow > a.S - 1) krow = a.S - 1;
+            sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
+                const bf16x8 vf = *(const bf16x8*)(base + 2 * a.H + (long long)krow * ld + 32 * ks + 8 * g);
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[ks], dp[t], 0, 0, 0);   // dPd[query][key] = dO . v
+            }
+        }
+        fa_stage<HD>(img, base + a.H, ld, k0, a.S, lane);   // K image for the transposed read
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * t + 4 * g + r;
+                const float p = key < a.S ? __expf(sc[t][r] * a.scale - Li) : 0.f;
+                float d = dp[t][r];
+                if (a.thr) d = drop_keep(a.key, a.thr, rbase + (unsigned)key) ? d * a.dscale : 0.f;
+                sc[t][r] = p * (d - D) * a.scale;   // dS, scaled
+            }
+        const bf16x8 sf = fa_pack(sc[0], sc[1]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dq[db], 0, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    if (query < a.S) {
+        const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            bf16x4 ov = {f2bf(dq[db][0]), f2bf(dq[db][1]), f2bf(dq[db][2]), f2bf(dq[db][3])};
+            *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+        }
+        if (g == 0) a.Dsum[(long long)unit * a.S + query] = D;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.y * 4 + wave;
+    if (16 * kb >= a.S) return;
+    char* imgQ = smem + wave * 2 * FA_IMG;
+    char* imgD = imgQ + FA_IMG;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const bf16_t* dob = a.dout + (long long)sq * a.S * a.H + h * HD;
+    const int key = 16 * kb + i16;
+    const int krow = key < a.S ? key : a.S - 1;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
+        vf[ks] = *(const bf16x8*)(base + 2 * a.H + (long long)krow * ld + 32 * ks + 8 * g);
+    }
+    f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+    const float* Lu = a.L + (long long)unit * a.S;
+    const float* Du = a.Dsum + (long long)unit * a.S;
+    for (int q0 = 0; q0 < a.S; q0 += 32) {
+        f32x4 st[2], dpt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int qrow = q0 + 16 * t + i16;
+            if (qrow > a.S - 1) qrow = a.S - 1;
+            st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qf = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+                const bf16x8 df = *(const bf16x8*)(dob + (long long)qrow * a.H + 32 * ks + 8 * g);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
+                dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
+                *(bf16x8*)(imgQ + fa_off(16 * t + i16, 4 * ks + g)) = qf;
+                *(bf16x8*)(imgD + fa_off(16 * t + i16, 4 * ks + g)) = df;
+            }
+        }
+        f32x4 pd[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 16 * t + 4 * g + r;
+                const int qc = q < a.S ? q : a.S - 1;
+                const float Lq = Lu[qc], Dq = Du[qc];
+                const float p = (q < a.S && key < a.S) ? __expf(st[t][r] * a.scale - Lq) : 0.f;
+                float keep = 1.f;
+                if (a.thr) keep = drop_keep(a.key, a.thr, (unsigned)(((long long)unit * a.S + qc) * a.S) + (unsigned)krow) ? a.dscale : 0.f;
+                pd[t][r] = p * keep;
+                st[t][r] = p * (dpt[t][r] * keep - Dq) * a.scale;   // dS^T, scaled
+            }
+        const bf16x8 pf = fa_pack(pd[0], pd[1]), sf = fa_pack(st[0], st[1]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgD, 4 * g, 16 + 4 * g, 16 * db, i16), pf, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgQ, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dk[db], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (key < a.S) {
+        const long long obase = ((long long)sq * a.S + key) * ld + h * HD;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            bf16x4 kv = {f2bf(dk[db][0]), f2bf(dk[db][1]), f2bf(dk[db][2]), f2bf(dk[db][3])};
+            bf16x4 vv = {f2bf(dv[db][0]), f2bf(dv[db][1]), f2bf(dv[db][2]), f2bf(dv[db][3])};
+            *(bf16x4*)(a.dqkv + obase + a.H + 16 * db + 4 * g) = kv;
+            *(bf16x4*)(a.dqkv + obase + 2 * a.H + 16 * db + 4 * g) = vv;
+        }
+    }
+}
+
+bool fattn_eligible(int dtype, int S, int H, int nh) {
+    static const bool off = [] { const char* e = getenv("NBCI_FLASH_ATTN"); return e && e[0] == '0'; }();
+    if (off || dtype != NBCI_BF16 || nh <= 0 || H % nh) return false;
+    const int hd = H / nh;
+    return (hd == 32 || hd == 64 || hd == 96 || hd == 128) && S >= 1 && H % 8 == 0;
+}
+
+static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site) {
+    NBCI_REQUIRE((long long)NS * nh * S * (long long)S < (1ll << 32), NBCI_ESHAPE, "flash attention: too large for the 32-bit dropout counter");
+    a.NS = NS; a.nh = nh; a.S = S; a.H = H;
+    a.scale = 1.0f / sqrtf((float)(H / nh));
+    a.thr = drop_threshold(drop_p);
+    a.dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    a.key = drop_key(seed, site);
+    return NBCI_OK;
+}
+
+template <int HD>
+static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
+    dim3 g(a.NS * a.nh, (a.S + 63) / 64);
+    if (which == 0) hipLaunchKernelGGL((fattn_fwd_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
+    else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
+    else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD>), g, dim3(256), 8 * FA_IMG, s, a);
+    return check_launch("flash attention");
+}
+
+static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
+    switch (a.H / a.nh) {
+        case 32: return fa_launch<32>(which, a, s);
+        case 64: return fa_launch<64>(which, a, s);
+        case 96: return fa_launch<96>(which, a, s);
+        default: return fa_launch<128>(which, a, s);
+    }
+}
+
+int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh), NBCI_ESHAPE, "flash attention: bf16, head size 32 / 64 / 96 / 128");
+    FAArgs a{};
+    int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
+    if (rc != NBCI_OK) return rc;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.L = L;
+    return fa_dispatch(0, a, s);
+}
+
+int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int NS, int nh, int S, int H,
+                     float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh), NBCI_ESHAPE, "flash attention: bf16, head size 32 / 64 / 96 / 128");
+    FAArgs a{};
+    int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
+    if (rc != NBCI_OK) return rc;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.dout = (const bf16_t*)dout; a.L = (float*)L; a.Dsum = Dsum; a.dqkv = (bf16_t*)dqkv;
+    rc = fa_dispatch(1, a, s);
+    if (rc != NBCI_OK) return rc;
+    return fa_dispatch(2, a, s);
+}
+
+}  // namespace nbci

@@ -82,8 +82,8 @@ constexpr int SA_KC = 8;   // keys per online-softmax group (one rescale of the 
 
 template <int HD, typename T>
 __global__ __launch_bounds__(64) void sattn_fwd_kernel(SAArgs a) {
-    const int unit = blockIdx.y, s = unit / a.nh, h = unit % a.nh;
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int unit = blockIdx.x, s = unit / a.nh, h = unit % a.nh;
+    const int i = blockIdx.y * 64 + threadIdx.x;
     const bool live = i < a.S;
     const int iq = live ? i : a.S - 1;
     const long long row0 = (long long)s * a.S;
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64) void sattn_fwd_kernel(SAArgs a) {
 
 template <int HD, typename T>
 __global__ __launch_bounds__(64) void sattn_bwd_q_kernel(SAArgs a) {
-    const int unit = blockIdx.y, s = unit / a.nh, h = unit % a.nh;
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int unit = blockIdx.x, s = unit / a.nh, h = unit % a.nh;
+    const int i = blockIdx.y * 64 + threadIdx.x;
     const bool live = i < a.S;
     const int iq = live ? i : a.S - 1;
     const long long row0 = (long long)s * a.S;
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(64) void sattn_bwd_q_kernel(SAArgs a) {
 
 template <int HD, typename T>
 __global__ __launch_bounds__(64) void sattn_bwd_kv_kernel(SAArgs a) {
-    const int unit = blockIdx.y, s = unit / a.nh, h = unit % a.nh;
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int unit = blockIdx.x, s = unit / a.nh, h = unit % a.nh;
+    const int j = blockIdx.y * 64 + threadIdx.x;
     const bool live = j < a.S;
     const int jk = live ? j : a.S - 1;
     const long long row0 = (long long)s * a.S;
@@ -218,7 +218,7 @@ size_t sattn_stat_floats(int NS, int nh, int S) { return (size_t)NS * nh * S; }
 
 template <typename T>
 static int sattn_dispatch(int which, int hd, const SAArgs& a, hipStream_t s) {
-    dim3 g((a.S + 63) / 64, a.NS * a.nh);
+    dim3 g(a.NS * a.nh, (a.S + 63) / 64);
 #define SA_LAUNCH(K, HDV) hipLaunchKernelGGL((K<HDV, T>), g, dim3(64), 0, s, a)
 #define SA_HD(K) do { if (hd == 16) SA_LAUNCH(K, 16); else if (hd == 32) SA_LAUNCH(K, 32); else SA_LAUNCH(K, 64); } while (0)
     if (which == 0) SA_HD(sattn_fwd_kernel);

@@ -140,7 +140,7 @@ struct ItrWS {
     size_t dY, dR, cA, cA2, dU, dAtt, dqkv, dS, dtok, dH0, dsum, rep;
     size_t bytes;
     int S, M, M0, ldS, ldP, ldT;
-    bool small_attn;
+    bool small_attn, flash;
 };
 
 static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
@@ -167,7 +167,8 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
     w.rgtab = bump(cur, R * H * 4); w.mean_r = bump(cur, R * 4 + 4); w.rstd_r = bump(cur, R * 4 + 4); w.drgtab = bump(cur, R * H * 4);
     w.ssidx = bump(cur, M0 * 8);
     w.L.resize(c.n_layers);
-    w.small_attn = sattn_eligible(c.dtype, S, c.hidden, c.n_heads);
+    w.flash = fattn_eligible(c.dtype, S, c.hidden, c.n_heads);
+    w.small_attn = w.flash || sattn_eligible(c.dtype, S, c.hidden, c.n_heads);
     const size_t nP = w.small_attn ? 0 : (size_t)B * c.n_heads * S * w.ldP;
     const size_t nstat = sattn_stat_floats(B, c.n_heads, S);
     for (auto& l : w.L) {
@@ -308,7 +309,8 @@ int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, co
             TRY(gemm_launch_timed(d, s));
         }
         if (w.small_attn) {
-            TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B, nh, S, H, pl, io->seed, 16 + 4 * l, s));
+            if (w.flash) TRY(fattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), B, nh, S, H, pl, io->seed, 16 + 4 * l, s));
+            else TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B, nh, S, H, pl, io->seed, 16 + 4 * l, s));
         } else {
         {   // scores = q k^T / sqrt(hd), batched over (b, head); no mask (itransformer.py:209)
             nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)S * 3 * H, hd),
@@ -461,8 +463,12 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
             const int64_t pz1 = (int64_t)nh * S * w.ldP, pz2 = (int64_t)S * w.ldP;
             const int64_t qz1 = (int64_t)S * 3 * H, az1 = (int64_t)S * H;
             if (w.small_attn) {
-                TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt, B, nh,
-                                     S, H, pl, io->seed, 16 + 4 * l, s));
+                if (w.flash)
+                    TRY(fattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, B, nh, S,
+                                         H, pl, io->seed, 16 + 4 * l, s));
+                else
+                    TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt, B, nh,
+                                         S, H, pl, io->seed, 16 + 4 * l, s));
             } else {
             {   // dPd = da v^T (f32, reuses the score buffer)
                 nbci_gemm_desc d = gd(S, S, hd, dt, op(ws + w.dAtt, es, 0, H, 1, 0, 0, az1, hd),

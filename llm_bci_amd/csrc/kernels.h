@@ -127,6 +127,12 @@ int sattn_fwd_launch(const void* qkv, void* out, float* L, int dtype, int NS, in
 int sattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int dtype, int NS, int nh, int S,
                      int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 
+// streaming MFMA attention (attn_flash.hip): bf16, head 32 / 64 / 96 / 128, any length, no mask
+bool fattn_eligible(int dtype, int S, int H, int nh);
+int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int NS, int nh, int S, int H,
+                     float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
 int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,

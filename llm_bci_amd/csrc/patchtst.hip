@@ -123,7 +123,7 @@ struct PtWS {
     size_t bytes;
     long long M;
     int Mh, ldS, ldP, vpad, ldp;
-    bool small_attn;
+    bool small_attn, flash;
 };
 
 static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
@@ -147,7 +147,8 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.xm = bump(cur, M * pl * 4);
     w.patch = bump(cur, M * pl * 4);
     w.L.resize(c.num_hidden_layers);
-    w.small_attn = sattn_eligible(c.dtype, (int)P, (int)D, (int)nh);   // no score / probability tensors on that path
+    w.flash = fattn_eligible(c.dtype, (int)P, (int)D, (int)nh);
+    w.small_attn = w.flash || sattn_eligible(c.dtype, (int)P, (int)D, (int)nh);   // no score / probability tensors on that path
     const size_t nP = w.small_attn ? 0 : (size_t)B * C * nh * P * w.ldP;
     const size_t nstat = sattn_stat_floats(B * (int)C, (int)nh, (int)P);
     for (auto& l : w.L) {
@@ -270,7 +271,8 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
             TRY(gemm_launch_timed(d, s));
         }
         if (w.small_attn) {
-            TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+            if (w.flash) TRY(fattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+            else TRY(sattn_fwd_launch(ws + lw.qkv, ws + lw.ad, (float*)(ws + lw.lse), dt, B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
         } else {
         {   // scores = q k^T / sqrt(hd), batched over (b, c, head)
             nbci_gemm_desc d = gd(P, P, hd, dt, op(ws + lw.qkv, es, 0, 3 * D, 1, 0, 0, (int64_t)P * 3 * D, hd),
@@ -449,8 +451,12 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             const int64_t qz1 = (int64_t)P * 3 * D, az1 = (int64_t)P * D;
             const int nb = B * C * nh;
             if (w.small_attn) {
-                TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt,
-                                     B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+                if (w.flash)
+                    TRY(fattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv,
+                                         B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
+                else
+                    TRY(sattn_bwd_launch(ws + lw.qkv, ws + lw.ad, ws + w.dAtt, (const float*)(ws + lw.lse), (float*)(ws + w.dsum), ws + w.dqkv, dt,
+                                         B * C, nh, P, D, pa, io->seed, 16 + 4 * l, s));
             } else {
             {
                 nbci_gemm_desc d = gd(P, P, hd, dt, op(ws + w.dAtt, es, 0, D, 1, 0, 0, az1, hd), op(ws + lw.qkv, es, 2 * D, 3 * D, 1, 0, 0, qz1, hd),
