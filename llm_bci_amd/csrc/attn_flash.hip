@@ -59,25 +59,97 @@ __device__ __forceinline__ bf16x8 fa_pack(const f32x4& lo, const f32x4& hi) {
     return o;
 }
 
-// copy 32 rows x HD columns (rows r0.., clamped to S-1) of a strided matrix into a wave-private image
-template <int HD>
-__device__ __forceinline__ void fa_stage(char* img, const bf16_t* src, long long ld, int r0, int S, int lane) {
+// keep multipliers (scale or 0) for the 4 consecutive dropout counters idx0 .. idx0+3 (any parity): the counters pair up
+// two to a 32-bit hash (nbci_common.h drop_pair), so 3 hashes cover them instead of 4 element-wise drop_keep calls
+__device__ __forceinline__ void fa_keep4(uint32_t key, uint32_t thr, uint32_t idx0, float scale, float (&k)[4]) {
+    const uint32_t p0 = idx0 >> 1;
+    const uint32_t h0 = mix32(p0 ^ key), h1 = mix32((p0 + 1u) ^ key), h2 = mix32((p0 + 2u) ^ key);
+    const bool odd = (idx0 & 1u) != 0u;
+    const uint32_t hb = odd ? h1 : h0, hd = odd ? h2 : h1;
+    const uint32_t e0 = odd ? (h0 >> 16) : (h0 & 0xFFFFu);
+    const uint32_t e1 = odd ? (hb & 0xFFFFu) : (hb >> 16);
+    const uint32_t e2 = odd ? (h1 >> 16) : (h1 & 0xFFFFu);
+    const uint32_t e3 = odd ? (hd & 0xFFFFu) : (hd >> 16);
+    k[0] = e0 >= thr ? scale : 0.f; k[1] = e1 >= thr ? scale : 0.f; k[2] = e2 >= thr ? scale : 0.f; k[3] = e3 >= thr ? scale : 0.f;
+}
+
+// copy 32 rows x HD columns of a strided matrix into a wave-private image; `p` = this lane's source (row lane>>1 of the
+// step, first chunk of its half); TAIL clamps rows past the end (their probabilities are zero anyway)
+template <int HD, bool TAIL>
+__device__ __forceinline__ void fa_stage(char* img, const bf16_t* p, long long ld, int r0, int S, int lane) {
     constexpr int NCH = HD / 8, PER = NCH / 2;   // chunks per row; per lane (2 lanes share a row)
     const int row = lane >> 1;
-    int grow = r0 + row;
-    if (grow > S - 1) grow = S - 1;
-    const bf16_t* p = src + (long long)grow * ld;
+    if (TAIL) { const int over = r0 + row - (S - 1); if (over > 0) p -= (long long)over * ld; }
     uint4 v[PER];
 #pragma unroll
-    for (int c = 0; c < PER; ++c) v[c] = *(const uint4*)(p + ((lane & 1) * PER + c) * 8);
+    for (int c = 0; c < PER; ++c) v[c] = *(const uint4*)(p + c * 8);
 #pragma unroll
     for (int c = 0; c < PER; ++c) *(uint4*)(img + fa_off(row, (lane & 1) * PER + c)) = v[c];
+}
+
+template <int HD, bool TAIL>
+__device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const bf16_t* kp, const bf16_t* vp, long long ld, int k0,
+                                            const bf16x8 (&qf)[HD / 32], f32x4 (&o)[HD / 16], float& m, float& l, unsigned rbase, int lane) {
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int i16 = lane & 15, g = lane >> 4;
+    f32x4 sc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bf16_t* kr = kp + (long long)(16 * t) * ld;
+        if (TAIL) { const int over = k0 + 16 * t + i16 - (a.S - 1); if (over > 0) kr -= (long long)over * ld; }
+        sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kr + 32 * ks), qf[ks], sc[t], 0, 0, 0);
+    }
+    fa_stage<HD, TAIL>(img, vp, ld, k0, a.S, lane);
+    float cm = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = sc[t][r] * a.scale;
+            if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) s = -INFINITY;
+            sc[t][r] = s;
+            cm = fmaxf(cm, s);
+        }
+    cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+    cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+    // the accumulator is rescaled only when some row's running maximum actually moved (wave-uniform branch): after the
+    // first few steps it rarely does, and the rescale would drag all HD/16 accumulator tiles through the VALU every step
+    if (__builtin_amdgcn_ballot_w64(cm > m) != 0ull) {
+        const float mn = fmaxf(m, cm);
+        const float corr = __expf(m - mn);
+        m = mn;
+        l *= corr;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.thr) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __expf(sc[t][r] - m);       // exp(-inf) = 0 for keys past the end
+            ps += p;
+            sc[t][r] = p * keep[r];
+        }
+    }
+    l += ps;
+    const bf16x8 pf = fa_pack(sc[0], sc[1]);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), pf, o[db], 0, 0, 0);
+    asm volatile("" ::: "memory");
 }
 
 template <int HD>
 __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, NDB = HD / 16;
+    constexpr int KS = HD / 32, NDB = HD / 16, PER = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.y * 4 + wave;
@@ -96,58 +168,12 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-    for (int k0 = 0; k0 < a.S; k0 += 32) {
-        f32x4 sc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int krow = k0 + 16 * t + i16;
-            if (krow > a.S - 1) krow = a.S - 1;
-            sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
-                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[t], 0, 0, 0);
-            }
-        }
-        fa_stage<HD>(img, base + 2 * a.H, ld, k0, a.S, lane);
-        float cm = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * t + 4 * g + r;
-                const float s = key < a.S ? sc[t][r] * a.scale : -INFINITY;
-                sc[t][r] = s;
-                cm = fmaxf(cm, s);
-            }
-        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-        const float mn = fmaxf(m, cm);
-        const float corr = __expf(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __expf(sc[t][r] - mn);       // exp(-inf) = 0 for keys past the end
-                ps += p;
-                if (a.thr) {
-                    const int key = k0 + 16 * t + 4 * g + r;
-                    p = drop_keep(a.key, a.thr, rbase + (unsigned)key) ? p * a.dscale : 0.f;
-                }
-                sc[t][r] = p;
-            }
-        l = l * corr + ps;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
-        const bf16x8 pf = fa_pack(sc[0], sc[1]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), pf, o[db], 0, 0, 0);
-        asm volatile("" ::: "memory");
-    }
+    const bf16_t* kp = base + a.H + (long long)i16 * ld + 8 * g;                          // K row fragment of this lane, step 0
+    const bf16_t* vp = base + 2 * a.H + (long long)(lane >> 1) * ld + (lane & 1) * PER * 8;  // V staging source, step 0
+    const int full = a.S & ~31;
+    int k0 = 0;
+    for (; k0 < full; k0 += 32, kp += 32 * ld, vp += 32 * ld) fa_fwd_step<HD, false>(a, img, kp, vp, ld, k0, qf, o, m, l, rbase, lane);
+    if (k0 < a.S) fa_fwd_step<HD, true>(a, img, kp, vp, ld, k0, qf, o, m, l, rbase, lane);
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (query < a.S) {
@@ -162,10 +188,49 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     }
 }
 
+template <int HD, bool TAIL>
+__device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const bf16_t* kp, const bf16_t* vfp, const bf16_t* ksp, long long ld,
+                                             int k0, const bf16x8 (&qf)[HD / 32], const bf16x8 (&df)[HD / 32], f32x4 (&dq)[HD / 16], float Li,
+                                             float D, unsigned rbase, int lane) {
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int i16 = lane & 15, g = lane >> 4;
+    f32x4 sc[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        long long adj = (long long)(16 * t) * ld;
+        if (TAIL) { const int over = k0 + 16 * t + i16 - (a.S - 1); if (over > 0) adj -= (long long)over * ld; }
+        sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + adj + 32 * ks), qf[ks], sc[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vfp + adj + 32 * ks), df[ks], dp[t], 0, 0, 0);   // dPd = dO . v
+        }
+    }
+    fa_stage<HD, TAIL>(img, ksp, ld, k0, a.S, lane);   // K image for the transposed read
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.thr) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float p = __expf(sc[t][r] * a.scale - Li);
+            if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) p = 0.f;
+            sc[t][r] = p * (dp[t][r] * keep[r] - D) * a.scale;   // dS, scaled
+        }
+    }
+    const bf16x8 sf = fa_pack(sc[0], sc[1]);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dq[db], 0, 0, 0);
+    asm volatile("" ::: "memory");
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, NDB = HD / 16;
+    constexpr int KS = HD / 32, NDB = HD / 16, PER = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.y * 4 + wave;
@@ -197,40 +262,14 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
 #pragma unroll
     for (int db = 0; db < NDB; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-    for (int k0 = 0; k0 < a.S; k0 += 32) {
-        f32x4 sc[2], dp[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int krow = k0 + 16 * t + i16;
-            if (krow > a.S - 1) krow = a.S - 1;
-            sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
-                const bf16x8 vf = *(const bf16x8*)(base + 2 * a.H + (long long)krow * ld + 32 * ks + 8 * g);
-                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[t], 0, 0, 0);
-                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[ks], dp[t], 0, 0, 0);   // dPd[query][key] = dO . v
-            }
-        }
-        fa_stage<HD>(img, base + a.H, ld, k0, a.S, lane);   // K image for the transposed read
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * t + 4 * g + r;
-                const float p = key < a.S ? __expf(sc[t][r] * a.scale - Li) : 0.f;
-                float d = dp[t][r];
-                if (a.thr) d = drop_keep(a.key, a.thr, rbase + (unsigned)key) ? d * a.dscale : 0.f;
-                sc[t][r] = p * (d - D) * a.scale;   // dS, scaled
-            }
-        const bf16x8 sf = fa_pack(sc[0], sc[1]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-            dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dq[db], 0, 0, 0);
-        asm volatile("" ::: "memory");
-    }
+    const bf16_t* kp = base + a.H + (long long)i16 * ld + 8 * g;
+    const bf16_t* vfp = base + 2 * a.H + (long long)i16 * ld + 8 * g;
+    const bf16_t* ksp = base + a.H + (long long)(lane >> 1) * ld + (lane & 1) * PER * 8;
+    const int full = a.S & ~31;
+    int k0 = 0;
+    for (; k0 < full; k0 += 32, kp += 32 * ld, vfp += 32 * ld, ksp += 32 * ld)
+        fa_bwdq_step<HD, false>(a, img, kp, vfp, ksp, ld, k0, qf, df, dq, Li, D, rbase, lane);
+    if (k0 < a.S) fa_bwdq_step<HD, true>(a, img, kp, vfp, ksp, ld, k0, qf, df, dq, Li, D, rbase, lane);
     if (query < a.S) {
         const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
 #pragma unroll
@@ -240,6 +279,65 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
         }
         if (g == 0) a.Dsum[(long long)unit * a.S + query] = D;
     }
+}
+
+template <int HD, bool TAIL>
+__device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const bf16_t* qp, const bf16_t* dp_, long long ld, int q0,
+                                              const bf16x8 (&kf)[HD / 32], const bf16x8 (&vf)[HD / 32], f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16],
+                                              const float* Lu, const float* Du, unsigned ubase, int krow, bool key_ok, int lane) {
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int i16 = lane & 15, g = lane >> 4;
+    f32x4 st[2], dpt[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        long long aq = (long long)(16 * t) * ld, ad = (long long)(16 * t) * a.H;
+        if (TAIL) { const int over = q0 + 16 * t + i16 - (a.S - 1); if (over > 0) { aq -= (long long)over * ld; ad -= (long long)over * a.H; } }
+        st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qf = *(const bf16x8*)(qp + aq + 32 * ks);
+            const bf16x8 df = *(const bf16x8*)(dp_ + ad + 32 * ks);
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
+            dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
+            *(bf16x8*)(imgQ + fa_off(16 * t + i16, 4 * ks + g)) = qf;
+            *(bf16x8*)(imgD + fa_off(16 * t + i16, 4 * ks + g)) = df;
+        }
+    }
+    f32x4 pd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qb4 = q0 + 16 * t + 4 * g;
+        float Lq[4], Dq[4];
+        if (!TAIL) {
+            // (unit * S + q) is 4-aligned only by luck: scalar loads
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Lq[r] = Lu[qb4 + r]; Dq[r] = Du[qb4 + r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int qc = qb4 + r < a.S ? qb4 + r : a.S - 1; Lq[r] = Lu[qc]; Dq[r] = Du[qc]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float p = __expf(st[t][r] * a.scale - Lq[r]);
+            if ((TAIL && qb4 + r >= a.S) || !key_ok) p = 0.f;
+            float keep = 1.f;
+            if (a.thr) {
+                const int qc = (TAIL && qb4 + r >= a.S) ? a.S - 1 : qb4 + r;
+                keep = drop_keep(a.key, a.thr, ubase + (unsigned)qc * (unsigned)a.S + (unsigned)krow) ? a.dscale : 0.f;
+            }
+            pd[t][r] = p * keep;
+            st[t][r] = p * (dpt[t][r] * keep - Dq[r]) * a.scale;   // dS^T, scaled
+        }
+    }
+    const bf16x8 pf = fa_pack(pd[0], pd[1]), sf = fa_pack(st[0], st[1]);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgD, 4 * g, 16 + 4 * g, 16 * db, i16), pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgQ, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dk[db], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
 }
 
 template <int HD>
@@ -269,47 +367,14 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     for (int db = 0; db < NDB; ++db) { dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
     const float* Lu = a.L + (long long)unit * a.S;
     const float* Du = a.Dsum + (long long)unit * a.S;
-    for (int q0 = 0; q0 < a.S; q0 += 32) {
-        f32x4 st[2], dpt[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int qrow = q0 + 16 * t + i16;
-            if (qrow > a.S - 1) qrow = a.S - 1;
-            st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qf = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
-                const bf16x8 df = *(const bf16x8*)(dob + (long long)qrow * a.H + 32 * ks + 8 * g);
-                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
-                dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
-                *(bf16x8*)(imgQ + fa_off(16 * t + i16, 4 * ks + g)) = qf;
-                *(bf16x8*)(imgD + fa_off(16 * t + i16, 4 * ks + g)) = df;
-            }
-        }
-        f32x4 pd[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = q0 + 16 * t + 4 * g + r;
-                const int qc = q < a.S ? q : a.S - 1;
-                const float Lq = Lu[qc], Dq = Du[qc];
-                const float p = (q < a.S && key < a.S) ? __expf(st[t][r] * a.scale - Lq) : 0.f;
-                float keep = 1.f;
-                if (a.thr) keep = drop_keep(a.key, a.thr, (unsigned)(((long long)unit * a.S + qc) * a.S) + (unsigned)krow) ? a.dscale : 0.f;
-                pd[t][r] = p * keep;
-                st[t][r] = p * (dpt[t][r] * keep - Dq) * a.scale;   // dS^T, scaled
-            }
-        const bf16x8 pf = fa_pack(pd[0], pd[1]), sf = fa_pack(st[0], st[1]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgD, 4 * g, 16 + 4 * g, 16 * db, i16), pf, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgQ, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dk[db], 0, 0, 0);
-        }
-        asm volatile("" ::: "memory");
-    }
+    const unsigned ubase = (unsigned)((long long)unit * a.S * a.S);
+    const bf16_t* qp = base + (long long)i16 * ld + 8 * g;
+    const bf16_t* dp_ = dob + (long long)i16 * a.H + 8 * g;
+    const int full = a.S & ~31;
+    int q0 = 0;
+    for (; q0 < full; q0 += 32, qp += 32 * ld, dp_ += 32LL * a.H)
+        fa_bwdkv_step<HD, false>(a, imgQ, imgD, qp, dp_, ld, q0, kf, vf, dk, dv, Lu, Du, ubase, krow, key < a.S, lane);
+    if (q0 < a.S) fa_bwdkv_step<HD, true>(a, imgQ, imgD, qp, dp_, ld, q0, kf, vf, dk, dv, Lu, Du, ubase, krow, key < a.S, lane);
     if (key < a.S) {
         const long long obase = ((long long)sq * a.S + key) * ld + h * HD;
 #pragma unroll
