@@ -73,36 +73,46 @@ __device__ __forceinline__ void fa_keep4(uint32_t key, uint32_t thr, uint32_t id
     k[0] = e0 >= thr ? scale : 0.f; k[1] = e1 >= thr ? scale : 0.f; k[2] = e2 >= thr ? scale : 0.f; k[3] = e3 >= thr ? scale : 0.f;
 }
 
-// copy 32 rows x HD columns of a strided matrix into a wave-private image; `p` = this lane's source (row lane>>1 of the
-// step, first chunk of its half); TAIL clamps rows past the end (their probabilities are zero anyway)
-template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_stage(char* img, const bf16_t* p, long long ld, int r0, int S, int lane) {
-    constexpr int NCH = HD / 8, PER = NCH / 2;   // chunks per row; per lane (2 lanes share a row)
-    const int row = lane >> 1;
-    if (TAIL) { const int over = r0 + row - (S - 1); if (over > 0) p -= (long long)over * ld; }
-    uint4 v[PER];
+// One step's operands: two row-fragment sets (16 rows x 32 k per (t, ks); lane = row i16, 16-byte chunk g) of two strided
+// matrices X and Y, rows r0 .. r0+31 (clamped to S-1: the out-of-range rows only meet zero probabilities). ALL global loads
+// of a step are issued here, one step ahead of their use (register double buffer), so a wave sees no load latency.
+template <int HD> struct FaBuf { bf16x8 x[2][HD / 32], y[2][HD / 32]; };
+
+template <int HD>
+__device__ __forceinline__ void fa_load(FaBuf<HD>& b, const bf16_t* xp, long long ldx, const bf16_t* yp, long long ldy, int r0, int S, int i16) {
 #pragma unroll
-    for (int c = 0; c < PER; ++c) v[c] = *(const uint4*)(p + c * 8);
+    for (int t = 0; t < 2; ++t) {
+        int row = r0 + 16 * t + i16;
+        if (row > S - 1) row = S - 1;
+        const bf16_t* xr = xp + (long long)row * ldx;
+        const bf16_t* yr = yp + (long long)row * ldy;
 #pragma unroll
-    for (int c = 0; c < PER; ++c) *(uint4*)(img + fa_off(row, (lane & 1) * PER + c)) = v[c];
+        for (int ks = 0; ks < HD / 32; ++ks) { b.x[t][ks] = *(const bf16x8*)(xr + 32 * ks); b.y[t][ks] = *(const bf16x8*)(yr + 32 * ks); }
+    }
+}
+
+// the fragments a lane holds are exactly the 16-byte chunks (row 16t + i16, chunk 4ks + g) of the 32-row image
+template <int HD>
+__device__ __forceinline__ void fa_to_image(char* img, const bf16x8 (&f)[2][HD / 32], int i16, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) *(bf16x8*)(img + fa_off(16 * t + i16, 4 * ks + g)) = f[t][ks];
 }
 
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const bf16_t* kp, const bf16_t* vp, long long ld, int k0,
-                                            const bf16x8 (&qf)[HD / 32], f32x4 (&o)[HD / 16], float& m, float& l, unsigned rbase, int lane) {
+__device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[HD / 32],
+                                            f32x4 (&o)[HD / 16], float& m, float& l, unsigned rbase, int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     f32x4 sc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const bf16_t* kr = kp + (long long)(16 * t) * ld;
-        if (TAIL) { const int over = k0 + 16 * t + i16 - (a.S - 1); if (over > 0) kr -= (long long)over * ld; }
         sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kr + 32 * ks), qf[ks], sc[t], 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[ks], sc[t], 0, 0, 0);
     }
-    fa_stage<HD, TAIL>(img, vp, ld, k0, a.S, lane);
+    fa_to_image<HD>(img, b.y, i16, g);   // V rows of this step, for the transposed read below
     float cm = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -146,10 +156,43 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const bf
     asm volatile("" ::: "memory");
 }
 
+// software pipeline over the streamed axis: operands of step s+1 are requested before step s is computed
+#ifndef FA_PREFETCH
+#define FA_PREFETCH 0   // measured: the double buffer costs occupancy (346 VGPRs in dk/dv at head 96) and buys nothing — the kernels are bound by L2 -> register traffic, not latency
+#endif
+#if FA_PREFETCH
+#define FA_PIPELINE(LOAD, STEP)                                                          \
+    {                                                                                    \
+        const int nsteps = (a.S + 31) / 32;                                              \
+        const bool ragged = (a.S & 31) != 0;                                             \
+        FaBuf<HD> bufA, bufB;                                                            \
+        LOAD(bufA, 0);                                                                   \
+        for (int st = 0; st < nsteps; st += 2) {                                         \
+            if (st + 1 < nsteps) LOAD(bufB, 32 * (st + 1));                              \
+            if (ragged && st == nsteps - 1) STEP(true, bufA, 32 * st); else STEP(false, bufA, 32 * st); \
+            if (st + 1 < nsteps) {                                                       \
+                if (st + 2 < nsteps) LOAD(bufA, 32 * (st + 2));                          \
+                if (ragged && st + 1 == nsteps - 1) STEP(true, bufB, 32 * (st + 1)); else STEP(false, bufB, 32 * (st + 1)); \
+            }                                                                            \
+        }                                                                                \
+    }
+#else
+#define FA_PIPELINE(LOAD, STEP)                                                          \
+    {                                                                                    \
+        const int nsteps = (a.S + 31) / 32;                                              \
+        const bool ragged = (a.S & 31) != 0;                                             \
+        for (int st = 0; st < nsteps; ++st) {                                            \
+            FaBuf<HD> bufA;                                                              \
+            LOAD(bufA, 32 * st);                                                         \
+            if (ragged && st == nsteps - 1) STEP(true, bufA, 32 * st); else STEP(false, bufA, 32 * st); \
+        }                                                                                \
+    }
+#endif
+
 template <int HD>
 __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, NDB = HD / 16, PER = HD / 16;
+    constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.y * 4 + wave;
@@ -168,12 +211,13 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-    const bf16_t* kp = base + a.H + (long long)i16 * ld + 8 * g;                          // K row fragment of this lane, step 0
-    const bf16_t* vp = base + 2 * a.H + (long long)(lane >> 1) * ld + (lane & 1) * PER * 8;  // V staging source, step 0
-    const int full = a.S & ~31;
-    int k0 = 0;
-    for (; k0 < full; k0 += 32, kp += 32 * ld, vp += 32 * ld) fa_fwd_step<HD, false>(a, img, kp, vp, ld, k0, qf, o, m, l, rbase, lane);
-    if (k0 < a.S) fa_fwd_step<HD, true>(a, img, kp, vp, ld, k0, qf, o, m, l, rbase, lane);
+    const bf16_t* kp = base + a.H + 8 * g;
+    const bf16_t* vp = base + 2 * a.H + 8 * g;
+#define FWD_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
+#define FWD_STEP(T, B, R0) fa_fwd_step<HD, T>(a, img, B, R0, qf, o, m, l, rbase, lane)
+    FA_PIPELINE(FWD_LOAD, FWD_STEP)
+#undef FWD_LOAD
+#undef FWD_STEP
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (query < a.S) {
@@ -189,25 +233,22 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
 }
 
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const bf16_t* kp, const bf16_t* vfp, const bf16_t* ksp, long long ld,
-                                             int k0, const bf16x8 (&qf)[HD / 32], const bf16x8 (&df)[HD / 32], f32x4 (&dq)[HD / 16], float Li,
-                                             float D, unsigned rbase, int lane) {
+__device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[HD / 32],
+                                             const bf16x8 (&df)[HD / 32], f32x4 (&dq)[HD / 16], float Li, float D, unsigned rbase, int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     f32x4 sc[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        long long adj = (long long)(16 * t) * ld;
-        if (TAIL) { const int over = k0 + 16 * t + i16 - (a.S - 1); if (over > 0) adj -= (long long)over * ld; }
         sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + adj + 32 * ks), qf[ks], sc[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vfp + adj + 32 * ks), df[ks], dp[t], 0, 0, 0);   // dPd = dO . v
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[ks], sc[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], df[ks], dp[t], 0, 0, 0);   // dPd[query][key] = dO . v
         }
     }
-    fa_stage<HD, TAIL>(img, ksp, ld, k0, a.S, lane);   // K image for the transposed read
+    fa_to_image<HD>(img, b.x, i16, g);   // K rows of this step, for the transposed read
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float keep[4] = {1.f, 1.f, 1.f, 1.f};
@@ -230,7 +271,7 @@ __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const b
 template <int HD>
 __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = HD / 32, NDB = HD / 16, PER = HD / 16;
+    constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.y * 4 + wave;
@@ -262,14 +303,13 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
 #pragma unroll
     for (int db = 0; db < NDB; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-    const bf16_t* kp = base + a.H + (long long)i16 * ld + 8 * g;
-    const bf16_t* vfp = base + 2 * a.H + (long long)i16 * ld + 8 * g;
-    const bf16_t* ksp = base + a.H + (long long)(lane >> 1) * ld + (lane & 1) * PER * 8;
-    const int full = a.S & ~31;
-    int k0 = 0;
-    for (; k0 < full; k0 += 32, kp += 32 * ld, vfp += 32 * ld, ksp += 32 * ld)
-        fa_bwdq_step<HD, false>(a, img, kp, vfp, ksp, ld, k0, qf, df, dq, Li, D, rbase, lane);
-    if (k0 < a.S) fa_bwdq_step<HD, true>(a, img, kp, vfp, ksp, ld, k0, qf, df, dq, Li, D, rbase, lane);
+    const bf16_t* kp = base + a.H + 8 * g;
+    const bf16_t* vp = base + 2 * a.H + 8 * g;
+#define BQ_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
+#define BQ_STEP(T, B, R0) fa_bwdq_step<HD, T>(a, img, B, R0, qf, df, dq, Li, D, rbase, lane)
+    FA_PIPELINE(BQ_LOAD, BQ_STEP)
+#undef BQ_LOAD
+#undef BQ_STEP
     if (query < a.S) {
         const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
 #pragma unroll
@@ -282,40 +322,33 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
 }
 
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const bf16_t* qp, const bf16_t* dp_, long long ld, int q0,
-                                              const bf16x8 (&kf)[HD / 32], const bf16x8 (&vf)[HD / 32], f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16],
-                                              const float* Lu, const float* Du, unsigned ubase, int krow, bool key_ok, int lane) {
+__device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[HD / 32],
+                                              const bf16x8 (&vf)[HD / 32], f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16], const float* Lu,
+                                              const float* Du, unsigned ubase, int krow, bool key_ok, int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     f32x4 st[2], dpt[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        long long aq = (long long)(16 * t) * ld, ad = (long long)(16 * t) * a.H;
-        if (TAIL) { const int over = q0 + 16 * t + i16 - (a.S - 1); if (over > 0) { aq -= (long long)over * ld; ad -= (long long)over * a.H; } }
         st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qf = *(const bf16x8*)(qp + aq + 32 * ks);
-            const bf16x8 df = *(const bf16x8*)(dp_ + ad + 32 * ks);
-            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
-            dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
-            *(bf16x8*)(imgQ + fa_off(16 * t + i16, 4 * ks + g)) = qf;
-            *(bf16x8*)(imgD + fa_off(16 * t + i16, 4 * ks + g)) = df;
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
+            dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
         }
     }
+    fa_to_image<HD>(imgQ, b.x, i16, g);
+    fa_to_image<HD>(imgD, b.y, i16, g);
     f32x4 pd[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int qb4 = q0 + 16 * t + 4 * g;
         float Lq[4], Dq[4];
-        if (!TAIL) {
-            // (unit * S + q) is 4-aligned only by luck: scalar loads
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { Lq[r] = Lu[qb4 + r]; Dq[r] = Du[qb4 + r]; }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int qc = qb4 + r < a.S ? qb4 + r : a.S - 1; Lq[r] = Lu[qc]; Dq[r] = Du[qc]; }
+        for (int r = 0; r < 4; ++r) {
+            const int qc = (TAIL && qb4 + r >= a.S) ? a.S - 1 : qb4 + r;
+            Lq[r] = Lu[qc]; Dq[r] = Du[qc];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -368,13 +401,14 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     const float* Lu = a.L + (long long)unit * a.S;
     const float* Du = a.Dsum + (long long)unit * a.S;
     const unsigned ubase = (unsigned)((long long)unit * a.S * a.S);
-    const bf16_t* qp = base + (long long)i16 * ld + 8 * g;
-    const bf16_t* dp_ = dob + (long long)i16 * a.H + 8 * g;
-    const int full = a.S & ~31;
-    int q0 = 0;
-    for (; q0 < full; q0 += 32, qp += 32 * ld, dp_ += 32LL * a.H)
-        fa_bwdkv_step<HD, false>(a, imgQ, imgD, qp, dp_, ld, q0, kf, vf, dk, dv, Lu, Du, ubase, krow, key < a.S, lane);
-    if (q0 < a.S) fa_bwdkv_step<HD, true>(a, imgQ, imgD, qp, dp_, ld, q0, kf, vf, dk, dv, Lu, Du, ubase, krow, key < a.S, lane);
+    const bf16_t* qp = base + 8 * g;
+    const bf16_t* dp_ = dob + 8 * g;
+    const bool key_ok = key < a.S;
+#define BK_LOAD(B, R0) fa_load<HD>(B, qp, ld, dp_, (long long)a.H, R0, a.S, i16)
+#define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, lane)
+    FA_PIPELINE(BK_LOAD, BK_STEP)
+#undef BK_LOAD
+#undef BK_STEP
     if (key < a.S) {
         const long long obase = ((long long)sq * a.S + key) * ld + h * HD;
 #pragma unroll
