@@ -100,59 +100,73 @@ __device__ __forceinline__ void fa_to_image(char* img, const bf16x8 (&f)[2][HD /
         for (int ks = 0; ks < HD / 32; ++ks) *(bf16x8*)(img + fa_off(16 * t + i16, 4 * ks + g)) = f[t][ks];
 }
 
+#ifndef FA_NQ
+#define FA_NQ 2   // 16-row tiles per wave: every streamed K/V (Q/dO) fragment and transposed read is used FA_NQ times
+#endif
+constexpr int NQ = FA_NQ;
+
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[HD / 32],
-                                            f32x4 (&o)[HD / 16], float& m, float& l, unsigned rbase, int lane) {
+__device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
+                                            f32x4 (&o)[NQ][HD / 16], float (&m)[NQ], float (&l)[NQ], const unsigned (&rbase)[NQ], int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
-    f32x4 sc[2];
+    f32x4 sc[NQ][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[ks], sc[t], 0, 0, 0);
-    }
+        for (int t = 0; t < 2; ++t) {
+            sc[qi][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sc[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[qi][ks], sc[qi][t], 0, 0, 0);
+        }
     fa_to_image<HD>(img, b.y, i16, g);   // V rows of this step, for the transposed read below
-    float cm = -INFINITY;
+    bf16x8 pf[NQ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int qi = 0; qi < NQ; ++qi) {
+        float cm = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = sc[t][r] * a.scale;
-            if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) s = -INFINITY;
-            sc[t][r] = s;
-            cm = fmaxf(cm, s);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = sc[qi][t][r] * a.scale;
+                if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) s = -INFINITY;
+                sc[qi][t][r] = s;
+                cm = fmaxf(cm, s);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        // the accumulator is rescaled only when some row's running maximum actually moved (wave-uniform branch): after
+        // the first few steps it rarely does, and the rescale would drag all HD/16 accumulator tiles through the VALU
+        if (__builtin_amdgcn_ballot_w64(cm > m[qi]) != 0ull) {
+            const float mn = fmaxf(m[qi], cm);
+            const float corr = __expf(m[qi] - mn);
+            m[qi] = mn;
+            l[qi] *= corr;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) { o[qi][db][0] *= corr; o[qi][db][1] *= corr; o[qi][db][2] *= corr; o[qi][db][3] *= corr; }
         }
-    cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-    cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-    // the accumulator is rescaled only when some row's running maximum actually moved (wave-uniform branch): after the
-    // first few steps it rarely does, and the rescale would drag all HD/16 accumulator tiles through the VALU every step
-    if (__builtin_amdgcn_ballot_w64(cm > m) != 0ull) {
-        const float mn = fmaxf(m, cm);
-        const float corr = __expf(m - mn);
-        m = mn;
-        l *= corr;
+        float ps = 0.f;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
-    }
-    float ps = 0.f;
+        for (int t = 0; t < 2; ++t) {
+            float keep[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.thr) fa_keep4(a.key, a.thr, rbase[qi] + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float keep[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.thr) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sc[t][r] - m);       // exp(-inf) = 0 for keys past the end
-            ps += p;
-            sc[t][r] = p * keep[r];
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[qi][t][r] - m[qi]);       // exp(-inf) = 0 for keys past the end
+                ps += p;
+                sc[qi][t][r] = p * keep[r];
+            }
         }
+        l[qi] += ps;
+        pf[qi] = fa_pack(sc[qi][0], sc[qi][1]);
     }
-    l += ps;
-    const bf16x8 pf = fa_pack(sc[0], sc[1]);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), pf, o[db], 0, 0, 0);
+    for (int db = 0; db < NDB; ++db) {
+        const bf16x8 vt = fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) o[qi][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[qi], o[qi][db], 0, 0, 0);
+    }
     asm volatile("" ::: "memory");
 }
 
@@ -195,22 +209,28 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.y * 4 + wave;
-    if (16 * qb >= a.S) return;                 // whole wave: no workgroup-level synchronisation anywhere
+    const int qb0 = (blockIdx.y * 4 + wave) * NQ;
+    if (16 * qb0 >= a.S) return;                 // whole wave: no workgroup-level synchronisation anywhere
     char* img = smem + wave * FA_IMG;
     const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
-    const int query = 16 * qb + i16;
-    const int qrow = query < a.S ? query : a.S - 1;
-    bf16x8 qf[KS];
+    bf16x8 qf[NQ][KS];
+    f32x4 o[NQ][NDB];
+    float m[NQ], l[NQ];
+    unsigned rbase[NQ];
+    int query[NQ];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
-    f32x4 o[NDB];
+    for (int qi = 0; qi < NQ; ++qi) {
+        query[qi] = 16 * (qb0 + qi) + i16;
+        const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
-    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+        for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[qi][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[qi] = -INFINITY; l[qi] = 0.f;
+        rbase[qi] = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    }
     const bf16_t* kp = base + a.H + 8 * g;
     const bf16_t* vp = base + 2 * a.H + 8 * g;
 #define FWD_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
@@ -218,53 +238,67 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     FA_PIPELINE(FWD_LOAD, FWD_STEP)
 #undef FWD_LOAD
 #undef FWD_STEP
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (query < a.S) {
-        const float inv = 1.0f / l;
-        const long long obase = ((long long)sq * a.S + query) * a.H + h * HD;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            bf16x4 ov = {f2bf(o[db][0] * inv), f2bf(o[db][1] * inv), f2bf(o[db][2] * inv), f2bf(o[db][3] * inv)};
-            *(bf16x4*)(a.out + obase + 16 * db + 4 * g) = ov;
+    for (int qi = 0; qi < NQ; ++qi) {
+        float lt = l[qi];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        if (query[qi] < a.S) {
+            const float inv = 1.0f / lt;
+            const long long obase = ((long long)sq * a.S + query[qi]) * a.H + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                bf16x4 ov = {f2bf(o[qi][db][0] * inv), f2bf(o[qi][db][1] * inv), f2bf(o[qi][db][2] * inv), f2bf(o[qi][db][3] * inv)};
+                *(bf16x4*)(a.out + obase + 16 * db + 4 * g) = ov;
+            }
+            if (g == 0) a.L[(long long)unit * a.S + query[qi]] = m[qi] + __logf(lt);
         }
-        if (g == 0) a.L[(long long)unit * a.S + query] = m + __logf(l);
     }
 }
 
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[HD / 32],
-                                             const bf16x8 (&df)[HD / 32], f32x4 (&dq)[HD / 16], float Li, float D, unsigned rbase, int lane) {
+__device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
+                                             const bf16x8 (&df)[NQ][HD / 32], f32x4 (&dq)[NQ][HD / 16], const float (&Li)[NQ], const float (&D)[NQ],
+                                             const unsigned (&rbase)[NQ], int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
-    f32x4 sc[2], dp[2];
+    f32x4 sc[NQ][2], dp[NQ][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[ks], sc[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], df[ks], dp[t], 0, 0, 0);   // dPd[query][key] = dO . v
+        for (int t = 0; t < 2; ++t) {
+            sc[qi][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[qi][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                sc[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[qi][ks], sc[qi][t], 0, 0, 0);
+                dp[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], df[qi][ks], dp[qi][t], 0, 0, 0);   // dPd[query][key] = dO . v
+            }
         }
-    }
     fa_to_image<HD>(img, b.x, i16, g);   // K rows of this step, for the transposed read
+    bf16x8 sf[NQ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float keep[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.thr) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
+    for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float p = __expf(sc[t][r] * a.scale - Li);
-            if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) p = 0.f;
-            sc[t][r] = p * (dp[t][r] * keep[r] - D) * a.scale;   // dS, scaled
+        for (int t = 0; t < 2; ++t) {
+            float keep[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.thr) fa_keep4(a.key, a.thr, rbase[qi] + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __expf(sc[qi][t][r] * a.scale - Li[qi]);
+                if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) p = 0.f;
+                sc[qi][t][r] = p * (dp[qi][t][r] * keep[r] - D[qi]) * a.scale;   // dS, scaled
+            }
         }
+        sf[qi] = fa_pack(sc[qi][0], sc[qi][1]);
     }
-    const bf16x8 sf = fa_pack(sc[0], sc[1]);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dq[db], 0, 0, 0);
+    for (int db = 0; db < NDB; ++db) {
+        const bf16x8 kt = fa_tr(img, 4 * g, 16 + 4 * g, 16 * db, i16);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) dq[qi][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, sf[qi], dq[qi][db], 0, 0, 0);
+    }
     asm volatile("" ::: "memory");
 }
 
@@ -274,35 +308,40 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.y * 4 + wave;
-    if (16 * qb >= a.S) return;
+    const int qb0 = (blockIdx.y * 4 + wave) * NQ;
+    if (16 * qb0 >= a.S) return;
     char* img = smem + wave * FA_IMG;
     const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
-    const int query = 16 * qb + i16;
-    const int qrow = query < a.S ? query : a.S - 1;
-    bf16x8 qf[KS], df[KS];
-    float D = 0.f;
-    {
+    bf16x8 qf[NQ][KS], df[NQ][KS];
+    f32x4 dq[NQ][NDB];
+    float D[NQ], Li[NQ];
+    unsigned rbase[NQ];
+    int query[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        query[qi] = 16 * (qb0 + qi) + i16;
+        const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
         const bf16_t* dop = a.dout + ((long long)sq * a.S + qrow) * a.H + h * HD;
         const bf16_t* op = a.out + ((long long)sq * a.S + qrow) * a.H + h * HD;
+        float d = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
-            df[ks] = *(const bf16x8*)(dop + 32 * ks + 8 * g);
+            qf[qi][ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+            df[qi][ks] = *(const bf16x8*)(dop + 32 * ks + 8 * g);
             const bf16x8 of = *(const bf16x8*)(op + 32 * ks + 8 * g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) D += bf2f(df[ks][e]) * bf2f(of[e]);
+            for (int e = 0; e < 8; ++e) d += bf2f(df[qi][ks][e]) * bf2f(of[e]);
         }
-        D += __shfl_xor(D, 16, 64);
-        D += __shfl_xor(D, 32, 64);
-    }
-    const float Li = a.L[(long long)unit * a.S + qrow];
-    f32x4 dq[NDB];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        D[qi] = d;
+        Li[qi] = a.L[(long long)unit * a.S + qrow];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+        for (int db = 0; db < NDB; ++db) dq[qi][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        rbase[qi] = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    }
     const bf16_t* kp = base + a.H + 8 * g;
     const bf16_t* vp = base + 2 * a.H + 8 * g;
 #define BQ_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
@@ -310,65 +349,81 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     FA_PIPELINE(BQ_LOAD, BQ_STEP)
 #undef BQ_LOAD
 #undef BQ_STEP
-    if (query < a.S) {
-        const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            bf16x4 ov = {f2bf(dq[db][0]), f2bf(dq[db][1]), f2bf(dq[db][2]), f2bf(dq[db][3])};
-            *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+    for (int qi = 0; qi < NQ; ++qi)
+        if (query[qi] < a.S) {
+            const long long obase = ((long long)sq * a.S + query[qi]) * ld + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                bf16x4 ov = {f2bf(dq[qi][db][0]), f2bf(dq[qi][db][1]), f2bf(dq[qi][db][2]), f2bf(dq[qi][db][3])};
+                *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+            }
+            if (g == 0) a.Dsum[(long long)unit * a.S + query[qi]] = D[qi];
         }
-        if (g == 0) a.Dsum[(long long)unit * a.S + query] = D;
-    }
 }
 
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[HD / 32],
-                                              const bf16x8 (&vf)[HD / 32], f32x4 (&dk)[HD / 16], f32x4 (&dv)[HD / 16], const float* Lu,
-                                              const float* Du, unsigned ubase, int krow, bool key_ok, int lane) {
+__device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[NQ][HD / 32],
+                                              const bf16x8 (&vf)[NQ][HD / 32], f32x4 (&dk)[NQ][HD / 16], f32x4 (&dv)[NQ][HD / 16], const float* Lu,
+                                              const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
-    f32x4 st[2], dpt[2];
+    f32x4 st[NQ][2], dpt[NQ][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dpt[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ki = 0; ki < NQ; ++ki)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], kf[ks], st[t], 0, 0, 0);    // S^T[key][query]
-            dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], vf[ks], dpt[t], 0, 0, 0);  // dPd^T[key][query]
+        for (int t = 0; t < 2; ++t) {
+            st[ki][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dpt[ki][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                st[ki][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], kf[ki][ks], st[ki][t], 0, 0, 0);    // S^T[key][query]
+                dpt[ki][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], vf[ki][ks], dpt[ki][t], 0, 0, 0);  // dPd^T[key][query]
+            }
         }
-    }
     fa_to_image<HD>(imgQ, b.x, i16, g);
     fa_to_image<HD>(imgD, b.y, i16, g);
-    f32x4 pd[2];
+    float Lq[2][4], Dq[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int qb4 = q0 + 16 * t + 4 * g;
-        float Lq[4], Dq[4];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int qc = (TAIL && qb4 + r >= a.S) ? a.S - 1 : qb4 + r;
-            Lq[r] = Lu[qc]; Dq[r] = Du[qc];
+            const int q = q0 + 16 * t + 4 * g + r;
+            const int qc = (TAIL && q >= a.S) ? a.S - 1 : q;
+            Lq[t][r] = Lu[qc]; Dq[t][r] = Du[qc];
         }
+    bf16x8 pf[NQ], sf[NQ];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float p = __expf(st[t][r] * a.scale - Lq[r]);
-            if ((TAIL && qb4 + r >= a.S) || !key_ok) p = 0.f;
-            float keep = 1.f;
-            if (a.thr) {
-                const int qc = (TAIL && qb4 + r >= a.S) ? a.S - 1 : qb4 + r;
-                keep = drop_keep(a.key, a.thr, ubase + (unsigned)qc * (unsigned)a.S + (unsigned)krow) ? a.dscale : 0.f;
+    for (int ki = 0; ki < NQ; ++ki) {
+        f32x4 pd[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 16 * t + 4 * g + r;
+                float p = __expf(st[ki][t][r] * a.scale - Lq[t][r]);
+                if ((TAIL && q >= a.S) || !key_ok[ki]) p = 0.f;
+                float keep = 1.f;
+                if (a.thr) {
+                    const int qc = (TAIL && q >= a.S) ? a.S - 1 : q;
+                    keep = drop_keep(a.key, a.thr, ubase + (unsigned)qc * (unsigned)a.S + (unsigned)krow[ki]) ? a.dscale : 0.f;
+                }
+                pd[t][r] = p * keep;
+                st[ki][t][r] = p * (dpt[ki][t][r] * keep - Dq[t][r]) * a.scale;   // dS^T, scaled
             }
-            pd[t][r] = p * keep;
-            st[t][r] = p * (dpt[t][r] * keep - Dq[r]) * a.scale;   // dS^T, scaled
-        }
+        pf[ki] = fa_pack(pd[0], pd[1]);
+        sf[ki] = fa_pack(st[ki][0], st[ki][1]);
     }
-    const bf16x8 pf = fa_pack(pd[0], pd[1]), sf = fa_pack(st[0], st[1]);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgD, 4 * g, 16 + 4 * g, 16 * db, i16), pf, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr(imgQ, 4 * g, 16 + 4 * g, 16 * db, i16), sf, dk[db], 0, 0, 0);
+        const bf16x8 dt = fa_tr(imgD, 4 * g, 16 + 4 * g, 16 * db, i16);
+        const bf16x8 qt = fa_tr(imgQ, 4 * g, 16 + 4 * g, 16 * db, i16);
+#pragma unroll
+        for (int ki = 0; ki < NQ; ++ki) {
+            dv[ki][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt, pf[ki], dv[ki][db], 0, 0, 0);
+            dk[ki][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf[ki], dk[ki][db], 0, 0, 0);
+        }
     }
     asm volatile("" ::: "memory");
 }
@@ -379,46 +434,53 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int kb = blockIdx.y * 4 + wave;
-    if (16 * kb >= a.S) return;
+    const int kb0 = (blockIdx.y * 4 + wave) * NQ;
+    if (16 * kb0 >= a.S) return;
     char* imgQ = smem + wave * 2 * FA_IMG;
     char* imgD = imgQ + FA_IMG;
     const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
     const bf16_t* dob = a.dout + (long long)sq * a.S * a.H + h * HD;
-    const int key = 16 * kb + i16;
-    const int krow = key < a.S ? key : a.S - 1;
-    bf16x8 kf[KS], vf[KS];
+    bf16x8 kf[NQ][KS], vf[NQ][KS];
+    f32x4 dk[NQ][NDB], dv[NQ][NDB];
+    int key[NQ], krow[NQ];
+    bool key_ok[NQ];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *(const bf16x8*)(base + a.H + (long long)krow * ld + 32 * ks + 8 * g);
-        vf[ks] = *(const bf16x8*)(base + 2 * a.H + (long long)krow * ld + 32 * ks + 8 * g);
+    for (int ki = 0; ki < NQ; ++ki) {
+        key[ki] = 16 * (kb0 + ki) + i16;
+        key_ok[ki] = key[ki] < a.S;
+        krow[ki] = key_ok[ki] ? key[ki] : a.S - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ki][ks] = *(const bf16x8*)(base + a.H + (long long)krow[ki] * ld + 32 * ks + 8 * g);
+            vf[ki][ks] = *(const bf16x8*)(base + 2 * a.H + (long long)krow[ki] * ld + 32 * ks + 8 * g);
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { dk[ki][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ki][db] = dk[ki][db]; }
     }
-    f32x4 dk[NDB], dv[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) { dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
     const float* Lu = a.L + (long long)unit * a.S;
     const float* Du = a.Dsum + (long long)unit * a.S;
     const unsigned ubase = (unsigned)((long long)unit * a.S * a.S);
     const bf16_t* qp = base + 8 * g;
     const bf16_t* dp_ = dob + 8 * g;
-    const bool key_ok = key < a.S;
 #define BK_LOAD(B, R0) fa_load<HD>(B, qp, ld, dp_, (long long)a.H, R0, a.S, i16)
 #define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, lane)
     FA_PIPELINE(BK_LOAD, BK_STEP)
 #undef BK_LOAD
 #undef BK_STEP
-    if (key < a.S) {
-        const long long obase = ((long long)sq * a.S + key) * ld + h * HD;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            bf16x4 kv = {f2bf(dk[db][0]), f2bf(dk[db][1]), f2bf(dk[db][2]), f2bf(dk[db][3])};
-            bf16x4 vv = {f2bf(dv[db][0]), f2bf(dv[db][1]), f2bf(dv[db][2]), f2bf(dv[db][3])};
-            *(bf16x4*)(a.dqkv + obase + a.H + 16 * db + 4 * g) = kv;
-            *(bf16x4*)(a.dqkv + obase + 2 * a.H + 16 * db + 4 * g) = vv;
+    for (int ki = 0; ki < NQ; ++ki)
+        if (key_ok[ki]) {
+            const long long obase = ((long long)sq * a.S + key[ki]) * ld + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                bf16x4 kv = {f2bf(dk[ki][db][0]), f2bf(dk[ki][db][1]), f2bf(dk[ki][db][2]), f2bf(dk[ki][db][3])};
+                bf16x4 vv = {f2bf(dv[ki][db][0]), f2bf(dv[ki][db][1]), f2bf(dv[ki][db][2]), f2bf(dv[ki][db][3])};
+                *(bf16x4*)(a.dqkv + obase + a.H + 16 * db + 4 * g) = kv;
+                *(bf16x4*)(a.dqkv + obase + 2 * a.H + 16 * db + 4 * g) = vv;
+            }
         }
-    }
 }
 
 bool fattn_eligible(int dtype, int S, int H, int nh) {
@@ -440,7 +502,7 @@ static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32
 
 template <int HD>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
-    dim3 g(a.NS * a.nh, (a.S + 63) / 64);
+    dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
     if (which == 0) hipLaunchKernelGGL((fattn_fwd_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
     else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
     else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD>), g, dim3(256), 8 * FA_IMG, s, a);
