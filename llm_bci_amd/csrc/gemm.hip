@@ -187,6 +187,7 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     if (d.bias) cvec = cvec && (((uintptr_t)d.bias) % 16 == 0);
     if (d.residual) cvec = cvec && (d.ldr % 4 == 0) && (((uintptr_t)d.residual) % 16 == 0);
     k.cvec = cvec ? 1 : 0;
+    { static const int dbg = [] { const char* e = getenv("NBCI_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
     return NBCI_OK;
 }
 

@@ -71,6 +71,7 @@ struct GemmK {
     int gate_bf16;
     int c2_grad;   // C2 receives act'(pre-activation) instead of the pre-activation
     int cvec;  // vector C/residual accesses legal
+    int dbg;   // NBCI_GEMM_DBG ablation bits (measurement only): 1 = epilogue computes but does not store, 2 = no K loop
 };
 
 __device__ __forceinline__ long long row_offset(const OperandK& o, int r) {
@@ -215,6 +216,113 @@ __device__ __forceinline__ void compute_tile(const char* sA, const char* sB, f32
     }
 }
 
+// One lane's share of the fused epilogue: v[0..3] = alpha * accumulator of C[m][n .. n+3] (m < M, n < N checked by
+// the caller). Applies bias / activation / gate / dropout / residual in the order the model needs, stores C (and C2),
+// and adds the stored values into csum[0..3] when column sums are requested.
+__device__ __forceinline__ void epi_apply(const GemmK& d, float (&v)[4], int m, int n, long long coff, float (&csum)[4]) {
+    const long long cidx = coff + (long long)m * d.ldc + n;
+    const bool full = (n + 3 < d.N) && d.cvec;
+    if (d.bias) {
+        if (full) {
+            const float4 b4 = *(const float4*)(d.bias + n);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.bias[n + e];
+        }
+    }
+    float dact[4] = {1.f, 1.f, 1.f, 1.f};
+    bool act_done = false;
+    if (d.C2 && d.c2_grad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(d.act, v[e], y, dact[e]); v[e] = y; }
+        act_done = true;
+    }
+    if (d.C2) {
+        const float* src = d.c2_grad ? dact : v;
+        if (d.c_bf16) {
+            bf16_t* c2 = (bf16_t*)d.C2 + cidx;
+            if (full) { bf16x4 o = {f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3])}; *(bf16x4*)c2 = o; }
+            else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(src[e]); }
+        } else {
+            float* c2 = (float*)d.C2 + cidx;
+            if (full) *(float4*)c2 = make_float4(src[0], src[1], src[2], src[3]);
+            else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = src[e]; }
+        }
+    }
+    if (d.residual && d.residual_first) {
+        const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+        const float* r = d.residual + rr * d.ldr + n;
+        if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+        else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+    }
+    if (d.act != ACT_NONE && !act_done) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
+    }
+    if (d.gate && full && d.gate_bf16 && d.gate_act < 0 && (d.ldg & 3) == 0) {   // the train step's case: one 8-byte load
+        const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (long long)m * d.ldg + n);
+        v[0] *= bf2f(g4[0]); v[1] *= bf2f(g4[1]); v[2] *= bf2f(g4[2]); v[3] *= bf2f(g4[3]);
+    } else if (d.gate) {
+        const long long gi = (long long)m * d.ldg + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e < d.N) {
+                const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
+                v[e] *= (d.gate_act < 0) ? gv : act_bwd(d.gate_act, gv);   // gate_act < 0: gate already holds act'
+            }
+        }
+    }
+    if (d.drop_thr) {
+        // dropout stream index = element offset inside C (so a head-batched GEMM that writes
+        // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
+        const unsigned idx = (unsigned)cidx;
+        if ((idx & 1u) == 0u) {
+            drop4(d.drop_key, d.drop_thr, idx, d.drop_scale, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_keep(d.drop_key, d.drop_thr, idx + e) ? v[e] * d.drop_scale : 0.f;
+        }
+    }
+    if (d.residual && !d.residual_first) {
+        const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+        const float* r = d.residual + rr * d.ldr + n;
+        if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+        else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
+    }
+    if (d.colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += v[e];
+    }
+    if (d.c_bf16) {
+        bf16_t* c = (bf16_t*)d.C + cidx;
+        if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
+        else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
+    } else {
+        float* c = (float*)d.C + cidx;
+        if (d.beta != 0.f) {
+            if (full) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
+            else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
+        }
+        if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+_Pragma("unroll")
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
+    }
+}
+
 // ---- epilogue shared by both kernels. The wave owns rows [mw, mw + 16*MI) x cols [nw, nw + 16*NI);
 // lane owns m = mw + 16*mi + (lane&15), n = nw + 16*ni + 4*(lane>>4) + 0..3.
 template <int MI, int NI>
@@ -248,6 +356,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
         return;
     }
     }
+    if (d.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
+        float t = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (t == 1.2345e-30f) ((float*)d.C)[0] = t;
+        return;
+    }
     float csum[NI][4];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -263,104 +380,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
             if (n >= d.N) continue;
             float v[4] = {acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha,
                           acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha};
-            const long long cidx = coff + (long long)m * d.ldc + n;
-            const bool full = (n + 3 < d.N) && d.cvec;
-            if (d.bias) {
-                if (full) {
-                    const float4 b4 = *(const float4*)(d.bias + n);
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.bias[n + e];
-                }
-            }
-            float dact[4] = {1.f, 1.f, 1.f, 1.f};
-            bool act_done = false;
-            if (d.C2 && d.c2_grad) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(d.act, v[e], y, dact[e]); v[e] = y; }
-                act_done = true;
-            }
-            if (d.C2) {
-                const float* src = d.c2_grad ? dact : v;
-                if (d.c_bf16) {
-                    bf16_t* c2 = (bf16_t*)d.C2 + cidx;
-                    if (full) { bf16x4 o = {f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3])}; *(bf16x4*)c2 = o; }
-                    else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(src[e]); }
-                } else {
-                    float* c2 = (float*)d.C2 + cidx;
-                    if (full) *(float4*)c2 = make_float4(src[0], src[1], src[2], src[3]);
-                    else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = src[e]; }
-                }
-            }
-            if (d.residual && d.residual_first) {
-                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
-                const float* r = d.residual + rr * d.ldr + n;
-                if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
-            }
-            if (d.act != ACT_NONE && !act_done) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
-            }
-            if (d.gate) {
-                const long long gi = (long long)m * d.ldg + n;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e < d.N) {
-                        const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
-                        v[e] *= (d.gate_act < 0) ? gv : act_bwd(d.gate_act, gv);   // gate_act < 0: gate already holds act'
-                    }
-                }
-            }
-            if (d.drop_thr) {
-                // dropout stream index = element offset inside C (so a head-batched GEMM that writes
-                // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
-                const unsigned idx = (unsigned)cidx;
-                if ((idx & 1u) == 0u) {
-                    drop4(d.drop_key, d.drop_thr, idx, d.drop_scale, v);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = drop_keep(d.drop_key, d.drop_thr, idx + e) ? v[e] * d.drop_scale : 0.f;
-                }
-            }
-            if (d.residual && !d.residual_first) {
-                const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
-                const float* r = d.residual + rr * d.ldr + n;
-                if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
-            }
-            if (d.colsum) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) csum[ni][e] += v[e];
-            }
-            if (d.c_bf16) {
-                bf16_t* c = (bf16_t*)d.C + cidx;
-                if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
-                else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
-            } else {
-                float* c = (float*)d.C + cidx;
-                if (d.beta != 0.f) {
-                    if (full) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
-                    else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
-                }
-                if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-_Pragma("unroll")
-                    for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
-            }
+            epi_apply(d, v, m, n, coff, csum[ni]);
         }
     }
     if (d.colsum) {
@@ -378,5 +398,59 @@ _Pragma("unroll")
             }
     }
 }
+
+// ---- row-contiguous epilogue for the direct-to-LDS kernels (no split-K). In the accumulator layout a wave store
+// covers 16 rows x 64 B (f32) or 32 B (bf16): partial cache lines, assembled in L2 from several instructions of
+// several waves while the K loop of the co-resident workgroup streams through the same L2. Here the accumulators
+// go through the (dead) staging LDS once, as an f32 tile [BM][128 + 4]; afterwards a wave instruction covers whole
+// rows: lane owns n = 4 * (t & 31) .. + 3 of row t / 32 (+ nthreads / 32 per pass): 512 B (f32) / 256 B (bf16)
+// contiguous per row for C, C2, the residual and the gate. The per-element work is epi_apply(), unchanged.
+constexpr int EPI_LD = 132;   // floats per LDS row: 16 B of padding spreads the 16 rows of a fragment over all banks
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[MI][NI], int mw_l, int nw_l, int m0, int n0, int bm,
+                                                   long long coff, int t, int nthreads, char* smem) {
+    const int lane = t & 63, i16 = lane & 15, g = lane >> 4;
+    float* tile = (float*)smem;
+    if (d.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
+        float s = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) s += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (s == 1.2345e-30f) ((float*)d.C)[0] = s;
+        return;
+    }
+    __syncthreads();   // every wave has left the K loop: the staging buffers are dead
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            *(float4*)(tile + (mw_l + mi * 16 + i16) * EPI_LD + nw_l + ni * 16 + 4 * g) =
+                make_float4(acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha, acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha);
+    __syncthreads();
+    const int c4 = 4 * (t & 31), n = n0 + c4;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < d.N) {
+        const int rstep = nthreads >> 5;
+        for (int r = t >> 5; r < bm; r += rstep) {
+            const int m = m0 + r;
+            if (m >= d.M) break;
+            const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
+            float v[4] = {a.x, a.y, a.z, a.w};
+            epi_apply(d, v, m, n, coff, csum);
+        }
+    }
+    if (d.colsum) {   // bias gradient: the two half-waves hold the same columns; one atomic per column per wave
+        const int cbase = (int)(coff % d.ldc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = csum[e];
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 32 && n + e < d.N)
+                atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(m0 >> 4) + (unsigned)(t >> 6) + (unsigned)(coff / d.ldc)) + cbase + n + e, s);
+        }
+    }
+}
+
 
 }  // namespace nbci

@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = d.splitk > 1 ? zsplit : block_y;
-    const int ktiles = (d.K + 63) / 64;
+    const int ktiles = (d.dbg & 2) ? 0 : (d.K + 63) / 64;
     int kt_begin = 0, kt_end = ktiles;
     OperandK A = d.A, B = d.B;
     long long coff = 0;
@@ -209,7 +209,13 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
             __syncthreads();
         }
     }
-    gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
+    if constexpr (MI == 4 && NI == 4) {
+        if (d.splitk > 1) {   // split-K partials: LDS-transposed atomics
+            gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
+            return;
+        }
+    }
+    gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, GEMM_THREADS, smem);
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
@@ -336,8 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
         cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
         nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
     }
-    __syncthreads();   // (the split-K epilogue reuses LDS; harmless otherwise)
-    gemm_epilogue<MI, NI>(d, acc, m0 + wm * MI * 16, n0 + wn * NI * 16, coff, lane, w, smem);
+    gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, NW * 64, smem);
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
@@ -353,6 +358,157 @@ static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>), grid, dim3(WM * WN * 64), lds, s, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms launch: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+// ---- K-group variant: 288 x 128 tile, 8 waves = 2 K-groups x (2 x 2) waves of 144 x 64 -------------------
+// What bounds the kernels above is LDS READ bandwidth, not MFMA: a wave tile of wm x wn re-reads (wm + wn) * 64 k
+// * 2 B of LDS per K tile, and the 144 x 32 wave tiles of the 144-row kernel need 88 KB per workgroup per K tile
+// = 704 cycles at 128 B/clk against 576 MFMA cycles (measured: the loop with the global loads removed runs at
+// exactly that rate). Squarer wave tiles are the fix: 144 x 64 needs 26 KB per 1152 MFMA cycles. To keep two
+// waves on every SIMD (so that one wave's fragment reads hide under the other's MFMAs) without halving the
+// wave tile again, the two waves of a SIMD split K instead: group g takes k-step g (32 of the 64 k) of every K
+// tile into its own full set of 144 x 64 accumulators, and the two sets are added once, through LDS, before the
+// epilogue (each group then finishes half of the rows). M = 9152 tokens x N = 1024 is 32 x 8 = 256 such tiles:
+// one per CU, a single round. Three LDS stages (156 KB), two K tiles in flight under a counted vmcnt.
+template <bool BKM, int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_glds_kg_kernel(GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8, MI = 9, NI = 4;
+    constexpr int BM = 288;
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 16384;
+    constexpr int NPA = A_BYTES / 1024, NPB = 16;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kg = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
+    const int nwg = d.tiles_m * d.tiles_n;
+    int wg;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int tm, tn;
+    {
+        const int per_group = 4 * d.tiles_n;   // an XCD's 32 resident tiles = 4 A panels x 8 B panels
+        const int grp = wg / per_group, in_grp = wg % per_group;
+        const int first_m = grp * 4;
+        const int gsize = min(4, d.tiles_m - first_m);
+        tm = first_m + in_grp % gsize;
+        tn = in_grp / gsize;
+    }
+    const int m0 = tm * BM, n0 = tn * 128;
+    OperandK A = d.A, B = d.B;
+    const int z = blockIdx.y;
+    const int z1 = z / d.zdiv, z2 = z % d.zdiv;
+    A.ptr = (const bf16_t*)A.ptr + z1 * d.azs1 + z2 * d.azs2;
+    B.ptr = (const bf16_t*)B.ptr + z1 * d.bzs1 + z2 * d.bzs2;
+    const long long coff = z1 * d.czs1 + z2 * d.czs2;
+    const int nt = d.K / 64;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    GldsOperand<true, NPA, NW> ga;
+    GldsOperand<BKM, NPB, NW> gb;
+    glds_setup<true, NPA, NW>(ga, A, m0, d.M, w, lane);
+    glds_setup<BKM, NPB, NW>(gb, B, n0, d.N, w, lane);
+    const int lw = (NPA - w + NW - 1) / NW + (NPB - w + NW - 1) / NW;   // LDS-DMA instructions this wave issues per tile
+
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nt) {
+            glds_stage<true, NPA, NW>(ga, A, smem + p * STAGE, p, w);
+            glds_stage<BKM, NPB, NW>(gb, B, smem + p * STAGE + A_BYTES, p, w);
+        }
+    const int i16 = lane & 15, g = lane >> 4;
+    const int ar0 = wm * 144, bc0 = wn * 64;
+    int cur = 0, nxt = NSTAGE - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        const int ahead = min(NSTAGE - 2, nt - 1 - kt);
+        wait_vmcnt(lw * ahead);
+        __builtin_amdgcn_s_barrier();   // tile kt is visible to every wave; stage `nxt` (tile kt - 1) is no longer read
+        asm volatile("" ::: "memory");
+        if (kt + NSTAGE - 1 < nt) {
+            char* nx = smem + nxt * STAGE;
+            glds_stage<true, NPA, NW>(ga, A, nx, kt + NSTAGE - 1, w);
+            glds_stage<BKM, NPB, NW>(gb, B, nx + A_BYTES, kt + NSTAGE - 1, w);
+        }
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + A_BYTES;
+        bf16x8 bf[NI], af[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = read_frag_bf16<BKM>(sB, bc0 + ni * 16, kg, i16, g);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = read_frag_bf16<true>(sA, ar0 + mi * 16, kg, i16, g);
+        __builtin_amdgcn_sched_barrier(0);   // all 13 fragment reads first; the MFMAs start as the fragments arrive (counted lgkmcnt)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+    }
+    __syncthreads();   // every wave is done with the stages (and no LDS-DMA is in flight): LDS becomes the exchange buffer
+    // K-group 0 keeps row blocks 0..4 and receives the partner's partial sums for them; group 1 keeps 5..8.
+    // One block = 64 lanes x 16 B, contiguous: conflict-free, and the partner (same wave tile, other k half) has the
+    // matching accumulator element in the same lane.
+    {
+        constexpr int KEEP0 = 5;
+        float4* xb = (float4*)smem + (size_t)(w & 3) * (MI * NI * 64);   // 36 KB per wave pair
+        if (kg == 0) {
+#pragma unroll
+            for (int mi = KEEP0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    xb[(mi * NI + ni) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < KEEP0; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    xb[(mi * NI + ni) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int mi = 0; mi < KEEP0; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float4 o = xb[(mi * NI + ni) * 64 + lane];
+                    acc[mi][ni][0] += o.x; acc[mi][ni][1] += o.y; acc[mi][ni][2] += o.z; acc[mi][ni][3] += o.w;
+                }
+            gemm_epilogue<KEEP0, NI>(d, reinterpret_cast<f32x4 (&)[KEEP0][NI]>(acc[0]), m0 + ar0, n0 + bc0, coff, lane, w, smem);
+        } else {
+#pragma unroll
+            for (int mi = KEEP0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float4 o = xb[(mi * NI + ni) * 64 + lane];
+                    acc[mi][ni][0] += o.x; acc[mi][ni][1] += o.y; acc[mi][ni][2] += o.z; acc[mi][ni][3] += o.w;
+                }
+            gemm_epilogue<MI - KEEP0, NI>(d, reinterpret_cast<f32x4 (&)[MI - KEEP0][NI]>(acc[KEEP0]), m0 + ar0 + 16 * KEEP0, n0 + bc0, coff,
+                                          lane, w, smem);
+        }
+    }
+}
+
+template <bool BKM>
+static int launch_kg(const GemmK& k, dim3 grid, hipStream_t s) {
+    constexpr int lds = 3 * (288 * 128 + 16384);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kg_kernel<BKM, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_kg: LDS attribute: ") + hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kg_kernel<BKM, 3>), grid, dim3(512), lds, s, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_kg launch: ") + hipGetErrorString(e));
     return NBCI_OK;
 }
 
@@ -373,7 +529,8 @@ bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k) {
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
 static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
-    constexpr int lds = 2 * (WM * MI * 16 * 128 + 16384);
+    constexpr int stage2 = 2 * (WM * MI * 16 * 128 + 16384), epi = WM * MI * 16 * EPI_LD * 4;   // K-loop stages / epilogue tile
+    constexpr int lds = stage2 > epi ? stage2 : epi;
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI>,
@@ -416,7 +573,16 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
     }
     for (int i = n; i < GEMM_GROUP_MAX; ++i) grp.start[i + 1] = grp.start[n];
     dim3 grid(grp.start[n]);
-    constexpr int lds = 65536;
+    constexpr int lds = 128 * EPI_LD * 4;   // the epilogue tile (67.6 KB) is a little larger than the two K-loop stages
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e3 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e4 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(NBCI_EHIP, "gemm group: LDS attribute");
+        attr_set = true;
+    }
     if (ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, grp);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<false, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
@@ -431,6 +597,17 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int splitk = k.splitk;
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.
+    // K-group 288 x 128 kernel (one workgroup per CU): token-major GEMMs whose 288-row tiles fill most of a round
+    static const int kg_mode = [] { const char* e = getenv("NBCI_GEMM_KG"); return e ? atoi(e) : 0; }();
+    if (kg_mode && d.A.kmajor && d.K % 64 == 0 && d.K >= 192 && splitk == 1 && d.M >= 288 && d.colsum == nullptr) {
+        const long tiles = (long)((d.M + 287) / 288) * k.tiles_n * batch;
+        const long rounds = (tiles + 255) / 256;
+        if (tiles >= 192 && tiles * 10 >= rounds * 256 * 7) {   // >= 70 % of the CU-rounds it occupies do work
+            k.tiles_m = (d.M + 287) / 288;
+            dim3 g(k.tiles_m * k.tiles_n, batch);
+            return d.B.kmajor ? launch_kg<true>(k, g, stream) : launch_kg<false>(k, g, stream);
+        }
+    }
     int bm = 128;
     if (d.A.kmajor && d.K % 64 == 0 && splitk == 1) {
         // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel
