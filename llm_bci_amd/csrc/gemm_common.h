@@ -71,7 +71,7 @@ struct GemmK {
     int gate_bf16;
     int c2_grad;   // C2 receives act'(pre-activation) instead of the pre-activation
     int cvec;  // vector C/residual accesses legal
-    int dbg;   // NBCI_GEMM_DBG ablation bits (measurement only): 1 = epilogue computes but does not store, 2 = no K loop
+    int dbg;   // NBCI_GEMM_DBG ablation bits (measurement only): 1 = epilogue computes but does not store, 2 = no K loop (both outside the K loop: a flag tested inside it slows the loop itself)
 };
 
 __device__ __forceinline__ long long row_offset(const OperandK& o, int r) {

@@ -1,0 +1,107 @@
+// gemm_glds.h — direct-to-LDS staging helpers shared by gemm_glds.hip and gemm_wgrad.hip (layout notes: gemm_glds.hip).
+#pragma once
+#include "gemm_common.h"
+
+namespace nbci {
+
+typedef __attribute__((address_space(1))) void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+template <bool KMAJOR, int NPIECES, int NW = 4>
+struct GldsOperand {
+    static constexpr int PER_WAVE = (NPIECES + NW - 1) / NW;
+    const bf16_t* base;        // operand base (batch offset applied)
+    long long off[PER_WAVE];   // per-piece element offset of this lane's chunk at k-tile 0
+    long long step;            // element step per K tile (kmajor: 64; else 64 * ld), 0 if recomputed
+    int col[PER_WAVE];         // (!KMAJOR, rpb view) column of the chunk
+    int krow[PER_WAVE];        // (!KMAJOR) local k row of this lane in the piece
+};
+
+// per-lane source offsets for the pieces this wave stages
+template <bool KMAJOR, int NPIECES, int NW = 4>
+__device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, int row0, int R, int w, int lane) {
+    g.base = (const bf16_t*)o.ptr;
+#pragma unroll
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
+        const int p = w + NW * i;
+        if constexpr (KMAJOR) {
+            const int rl = 8 * p + (lane >> 3);
+            int row = row0 + rl;
+            if (row > R - 1) row = R - 1;                       // clamp: garbage rows are never stored
+            const int c = (lane & 7) ^ ((rl >> 1) & 7);
+            g.off[i] = row_offset(o, row) + c * 8;
+            g.col[i] = 0; g.krow[i] = 0;
+        } else {
+            const int kl = 4 * p + (lane >> 4);
+            const int c = ((((lane & 15) >> 1) ^ rm_swz(kl)) << 1) | (lane & 1);
+            int col = row0 + c * 8;
+            if (col + 8 > ((R + 7) & ~7)) col = 0;              // chunk entirely past the padded extent
+            g.col[i] = col; g.krow[i] = kl;
+            g.off[i] = (long long)kl * o.ld + col;              // plain (non-view) addressing
+        }
+    }
+    g.step = KMAJOR ? 64 : 64 * o.ld;
+}
+
+template <bool KMAJOR, int NPIECES, int NW = 4>
+__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
+#pragma unroll
+    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
+        const int p = w + NW * i;
+        if (p < NPIECES) {
+            const bf16_t* src;
+            if (!KMAJOR && o.rpb > 0) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
+            else src = g.base + g.off[i] + (long long)kt * g.step;
+            __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <bool AK, bool BKM, int MI, int NI>
+__device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    // all fragment reads of BOTH k-steps are issued before the first MFMA: the second step's ds_reads
+    // stay in flight under the first step's MFMAs (lgkmcnt retires in order, hipcc waits per use)
+    bf16x8 af[2][MI], bf[2][NI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int sb = 0; sb < NI; ++sb) bf[ks][sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
+#pragma unroll
+        for (int sb = 0; sb < MI; ++sb) af[ks][sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
+    }
+    // hipcc otherwise sinks each pair of ds_reads next to its 4 MFMAs with an lgkmcnt(0) in front (to save
+    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs;
+    // the compiler's counted lgkmcnt waits let the MFMAs start as the fragments arrive, in order.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#if defined(NBCI_ABLATE) && NBCI_ABLATE == 1
+                asm volatile("" :: "v"(bf[ks][ni]), "v"(af[ks][mi]));
+#else
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
+#endif
+            }
+    }
+}
+
+}  // namespace nbci

@@ -17,94 +17,9 @@
 // need a second, 12 %-full round.
 #include <cstdlib>
 
-#include "gemm_common.h"
+#include "gemm_glds.h"
 
 namespace nbci {
-
-typedef __attribute__((address_space(1))) void gvoid;
-typedef __attribute__((address_space(3))) void lvoid;
-
-template <bool KMAJOR, int NPIECES, int NW = 4>
-struct GldsOperand {
-    static constexpr int PER_WAVE = (NPIECES + NW - 1) / NW;
-    const bf16_t* base;        // operand base (batch offset applied)
-    long long off[PER_WAVE];   // per-piece element offset of this lane's chunk at k-tile 0
-    long long step;            // element step per K tile (kmajor: 64; else 64 * ld), 0 if recomputed
-    int col[PER_WAVE];         // (!KMAJOR, rpb view) column of the chunk
-    int krow[PER_WAVE];        // (!KMAJOR) local k row of this lane in the piece
-};
-
-// per-lane source offsets for the pieces this wave stages
-template <bool KMAJOR, int NPIECES, int NW = 4>
-__device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, int row0, int R, int w, int lane) {
-    g.base = (const bf16_t*)o.ptr;
-#pragma unroll
-    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
-        const int p = w + NW * i;
-        if constexpr (KMAJOR) {
-            const int rl = 8 * p + (lane >> 3);
-            int row = row0 + rl;
-            if (row > R - 1) row = R - 1;                       // clamp: garbage rows are never stored
-            const int c = (lane & 7) ^ ((rl >> 1) & 7);
-            g.off[i] = row_offset(o, row) + c * 8;
-            g.col[i] = 0; g.krow[i] = 0;
-        } else {
-            const int kl = 4 * p + (lane >> 4);
-            const int c = ((((lane & 15) >> 1) ^ rm_swz(kl)) << 1) | (lane & 1);
-            int col = row0 + c * 8;
-            if (col + 8 > ((R + 7) & ~7)) col = 0;              // chunk entirely past the padded extent
-            g.col[i] = col; g.krow[i] = kl;
-            g.off[i] = (long long)kl * o.ld + col;              // plain (non-view) addressing
-        }
-    }
-    g.step = KMAJOR ? 64 : 64 * o.ld;
-}
-
-template <bool KMAJOR, int NPIECES, int NW = 4>
-__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
-#pragma unroll
-    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
-        const int p = w + NW * i;
-        if (p < NPIECES) {
-            const bf16_t* src;
-            if (!KMAJOR && o.rpb > 0) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
-            else src = g.base + g.off[i] + (long long)kt * g.step;
-            __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
-        }
-    }
-}
-
-template <bool AK, bool BKM, int MI, int NI>
-__device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
-    const int i16 = lane & 15, g = lane >> 4;
-    // all fragment reads of BOTH k-steps are issued before the first MFMA: the second step's ds_reads
-    // stay in flight under the first step's MFMAs (lgkmcnt retires in order, hipcc waits per use)
-    bf16x8 af[2][MI], bf[2][NI];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int sb = 0; sb < NI; ++sb) bf[ks][sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
-#pragma unroll
-        for (int sb = 0; sb < MI; ++sb) af[ks][sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
-    }
-    // hipcc otherwise sinks each pair of ds_reads next to its 4 MFMAs with an lgkmcnt(0) in front (to save
-    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs;
-    // the compiler's counted lgkmcnt waits let the MFMAs start as the fragments arrive, in order.
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-#if defined(NBCI_ABLATE) && NBCI_ABLATE == 1
-                asm volatile("" :: "v"(bf[ks][ni]), "v"(af[ks][mi]));
-#else
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
-#endif
-            }
-    }
-}
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
 __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x, const int block_y, char* smem) {
@@ -255,21 +170,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_group_kernel(GemmGroup
 //   <.., 2,2,4,4, 4>: 128 x 128 tile, 4 waves, 4 stages (128 KB LDS): small grids (<= 1 workgroup per CU)
 //   <.., 2,4,9,2, 3>: 288 x 128 tile, 8 waves, 3 stages (156 KB LDS): opt-in (NBCI_GEMM3=1), measured no
 //                     faster than the 2-stage 144-row kernel on the full-chip shapes
-__device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_waitcnt needs an immediate
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,157 +261,6 @@ static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
     return NBCI_OK;
 }
 
-// ---- K-group variant: 288 x 128 tile, 8 waves = 2 K-groups x (2 x 2) waves of 144 x 64 -------------------
-// What bounds the kernels above is LDS READ bandwidth, not MFMA: a wave tile of wm x wn re-reads (wm + wn) * 64 k
-// * 2 B of LDS per K tile, and the 144 x 32 wave tiles of the 144-row kernel need 88 KB per workgroup per K tile
-// = 704 cycles at 128 B/clk against 576 MFMA cycles (measured: the loop with the global loads removed runs at
-// exactly that rate). Squarer wave tiles are the fix: 144 x 64 needs 26 KB per 1152 MFMA cycles. To keep two
-// waves on every SIMD (so that one wave's fragment reads hide under the other's MFMAs) without halving the
-// wave tile again, the two waves of a SIMD split K instead: group g takes k-step g (32 of the 64 k) of every K
-// tile into its own full set of 144 x 64 accumulators, and the two sets are added once, through LDS, before the
-// epilogue (each group then finishes half of the rows). M = 9152 tokens x N = 1024 is 32 x 8 = 256 such tiles:
-// one per CU, a single round. Three LDS stages (156 KB), two K tiles in flight under a counted vmcnt.
-template <bool BKM, int NSTAGE>
-__global__ __launch_bounds__(512) void gemm_glds_kg_kernel(GemmK d) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NW = 8, MI = 9, NI = 4;
-    constexpr int BM = 288;
-    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 16384;
-    constexpr int NPA = A_BYTES / 1024, NPB = 16;
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int kg = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
-    const int nwg = d.tiles_m * d.tiles_n;
-    int wg;
-    {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    int tm, tn;
-    {
-        const int per_group = 4 * d.tiles_n;   // an XCD's 32 resident tiles = 4 A panels x 8 B panels
-        const int grp = wg / per_group, in_grp = wg % per_group;
-        const int first_m = grp * 4;
-        const int gsize = min(4, d.tiles_m - first_m);
-        tm = first_m + in_grp % gsize;
-        tn = in_grp / gsize;
-    }
-    const int m0 = tm * BM, n0 = tn * 128;
-    OperandK A = d.A, B = d.B;
-    const int z = blockIdx.y;
-    const int z1 = z / d.zdiv, z2 = z % d.zdiv;
-    A.ptr = (const bf16_t*)A.ptr + z1 * d.azs1 + z2 * d.azs2;
-    B.ptr = (const bf16_t*)B.ptr + z1 * d.bzs1 + z2 * d.bzs2;
-    const long long coff = z1 * d.czs1 + z2 * d.czs2;
-    const int nt = d.K / 64;
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    GldsOperand<true, NPA, NW> ga;
-    GldsOperand<BKM, NPB, NW> gb;
-    glds_setup<true, NPA, NW>(ga, A, m0, d.M, w, lane);
-    glds_setup<BKM, NPB, NW>(gb, B, n0, d.N, w, lane);
-    const int lw = (NPA - w + NW - 1) / NW + (NPB - w + NW - 1) / NW;   // LDS-DMA instructions this wave issues per tile
-
-#pragma unroll
-    for (int p = 0; p < NSTAGE - 1; ++p)
-        if (p < nt) {
-            glds_stage<true, NPA, NW>(ga, A, smem + p * STAGE, p, w);
-            glds_stage<BKM, NPB, NW>(gb, B, smem + p * STAGE + A_BYTES, p, w);
-        }
-    const int i16 = lane & 15, g = lane >> 4;
-    const int ar0 = wm * 144, bc0 = wn * 64;
-    int cur = 0, nxt = NSTAGE - 1;
-    for (int kt = 0; kt < nt; ++kt) {
-        const int ahead = min(NSTAGE - 2, nt - 1 - kt);
-        wait_vmcnt(lw * ahead);
-        __builtin_amdgcn_s_barrier();   // tile kt is visible to every wave; stage `nxt` (tile kt - 1) is no longer read
-        asm volatile("" ::: "memory");
-        if (kt + NSTAGE - 1 < nt) {
-            char* nx = smem + nxt * STAGE;
-            glds_stage<true, NPA, NW>(ga, A, nx, kt + NSTAGE - 1, w);
-            glds_stage<BKM, NPB, NW>(gb, B, nx + A_BYTES, kt + NSTAGE - 1, w);
-        }
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + A_BYTES;
-        bf16x8 bf[NI], af[MI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[ni] = read_frag_bf16<BKM>(sB, bc0 + ni * 16, kg, i16, g);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = read_frag_bf16<true>(sA, ar0 + mi * 16, kg, i16, g);
-        __builtin_amdgcn_sched_barrier(0);   // all 13 fragment reads first; the MFMAs start as the fragments arrive (counted lgkmcnt)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
-        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
-    }
-    __syncthreads();   // every wave is done with the stages (and no LDS-DMA is in flight): LDS becomes the exchange buffer
-    // K-group 0 keeps row blocks 0..4 and receives the partner's partial sums for them; group 1 keeps 5..8.
-    // One block = 64 lanes x 16 B, contiguous: conflict-free, and the partner (same wave tile, other k half) has the
-    // matching accumulator element in the same lane.
-    {
-        constexpr int KEEP0 = 5;
-        float4* xb = (float4*)smem + (size_t)(w & 3) * (MI * NI * 64);   // 36 KB per wave pair
-        if (kg == 0) {
-#pragma unroll
-            for (int mi = KEEP0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    xb[(mi * NI + ni) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < KEEP0; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    xb[(mi * NI + ni) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int mi = 0; mi < KEEP0; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const float4 o = xb[(mi * NI + ni) * 64 + lane];
-                    acc[mi][ni][0] += o.x; acc[mi][ni][1] += o.y; acc[mi][ni][2] += o.z; acc[mi][ni][3] += o.w;
-                }
-            gemm_epilogue<KEEP0, NI>(d, reinterpret_cast<f32x4 (&)[KEEP0][NI]>(acc[0]), m0 + ar0, n0 + bc0, coff, lane, w, smem);
-        } else {
-#pragma unroll
-            for (int mi = KEEP0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const float4 o = xb[(mi * NI + ni) * 64 + lane];
-                    acc[mi][ni][0] += o.x; acc[mi][ni][1] += o.y; acc[mi][ni][2] += o.z; acc[mi][ni][3] += o.w;
-                }
-            gemm_epilogue<MI - KEEP0, NI>(d, reinterpret_cast<f32x4 (&)[MI - KEEP0][NI]>(acc[KEEP0]), m0 + ar0 + 16 * KEEP0, n0 + bc0, coff,
-                                          lane, w, smem);
-        }
-    }
-}
-
-template <bool BKM>
-static int launch_kg(const GemmK& k, dim3 grid, hipStream_t s) {
-    constexpr int lds = 3 * (288 * 128 + 16384);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kg_kernel<BKM, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_kg: LDS attribute: ") + hipGetErrorString(e));
-        attr = true;
-    }
-    hipLaunchKernelGGL((gemm_glds_kg_kernel<BKM, 3>), grid, dim3(512), lds, s, k);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_kg launch: ") + hipGetErrorString(e));
-    return NBCI_OK;
-}
-
 // ---- host --------------------------------------------------------------------------------------
 static bool glds_operand_ok(const nbci_operand& o, int R) {
     if (((uintptr_t)o.ptr) % 16) return false;
@@ -597,17 +346,6 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int splitk = k.splitk;
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.
-    // K-group 288 x 128 kernel (one workgroup per CU): token-major GEMMs whose 288-row tiles fill most of a round
-    static const int kg_mode = [] { const char* e = getenv("NBCI_GEMM_KG"); return e ? atoi(e) : 0; }();
-    if (kg_mode && d.A.kmajor && d.K % 64 == 0 && d.K >= 192 && splitk == 1 && d.M >= 288 && d.colsum == nullptr) {
-        const long tiles = (long)((d.M + 287) / 288) * k.tiles_n * batch;
-        const long rounds = (tiles + 255) / 256;
-        if (tiles >= 192 && tiles * 10 >= rounds * 256 * 7) {   // >= 70 % of the CU-rounds it occupies do work
-            k.tiles_m = (d.M + 287) / 288;
-            dim3 g(k.tiles_m * k.tiles_n, batch);
-            return d.B.kmajor ? launch_kg<true>(k, g, stream) : launch_kg<false>(k, g, stream);
-        }
-    }
     int bm = 128;
     if (d.A.kmajor && d.K % 64 == 0 && splitk == 1) {
         // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel

@@ -43,7 +43,6 @@ struct Plan {
         return -1;
     }
     std::vector<std::pair<int64_t, int>> cmap;  // (flat offset of a 1-D param, compact offset)
-    mutable SideStream side;                     // weight gradients run here, beside the backward chain (plan_common.h)
 };
 
 static int64_t add_param(Plan& p, int64_t& cur, const std::string& name, int rows, int cols, int seg) {
@@ -373,10 +372,6 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     float* rep = (float*)(ws + w.rep);
     const RepCfg rc{p.compact_total, NREP};
     auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };  // replica-0 slot of a 1-D param's grad
-    // bf16 train step: weight gradients go to a second stream (not while per-launch timing is on: the roofline pass
-    // measures every GEMM alone)
-    SideStream* side = (dt == NBCI_BF16 && !gemm_profile_on() && p.side.ensure()) ? &p.side : nullptr;
-    auto ntiles = [](int m, int n) { return ((m + 127) / 128) * ((n + 127) / 128); };
     // The f32 gradient stream dx is consumed by GEMMs in the operand dtype: the LayerNorm backward that
     // finalises dx also writes that (dropout-masked) copy into ws.dA and sums its columns (bias grad).
     const bool need_cast = !(dt == NBCI_F32 && p_lay == 0.f && p_emb == 0.f);
@@ -409,8 +404,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
             const LayerOff& lo = p.L[l];
-            WgradQueue wq; wq.dtype = dt; wq.s = s; wq.side = side;
-            wq.layer_tiles = ntiles(H, I) + ntiles(I, H) + ntiles(H, H) + ntiles(3 * H, H);
+            WgradQueue wq; wq.dtype = dt; wq.s = s;
             // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
             const void* dm;  // d(down output) in the GEMM operand dtype (written by the previous LayerNorm backward)
             if (!need_cast) {
@@ -427,7 +421,6 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(wq.push(I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
-            TRY(wq.flush_async(0));   // down / up weight gradients run beside the rest of this layer's chain
             {
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
                 TRY(gemm_launch_timed(d, s));
@@ -493,17 +486,14 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
                 TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
             TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
-            if (side) TRY(wq.flush_async(1));   // out / qkv weight gradients: beside the qkv data gradient + LayerNorm backward
-            else TRY(wq.flush());               // all four operand pairs exist now; the LayerNorm backward below overwrites dA
+            TRY(wq.flush());   // all four operand pairs exist now; the LayerNorm backward below overwrites dA
             {
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
                                       NBCI_F32);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(wq.join(0));   // the LayerNorm backward overwrites dA, an operand of the down-projection weight gradient
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
                                      (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1)));
-            TRY(wq.join(1));   // this segment's gradients are complete when the call returns; dA2 / dqkv may be rewritten
         } else {
             // ---- embedder backward (ndt1.py:160-203)
             const int KS = c.stack_size * D;
@@ -515,15 +505,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 dx0 = ws + w.dA;
             }
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
-            WgradQueue wq; wq.dtype = dt; wq.s = s; wq.side = side; wq.layer_tiles = ntiles(H, KS);
-            if (side) {   // the stack-projection weight gradient runs beside the window data gradient + col2im
-                TRY(wq.push(H, KS, M, op(dx0, es, 0, H, 0), op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D),
-                            grads + p.stkw, KS));
-                TRY(wq.flush_async(0));
-            } else {
-                TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
-                          op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
-            }
+            TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
+                      op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
             {   // dwin = dx0 W_s  (M, S*D)
                 nbci_gemm_desc d = gd(M, KS, H, dt, op(dx0, es, 0, H, 1), op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
                 TRY(gemm_launch_timed(d, s));
@@ -533,7 +516,6 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, RG(p.embb), s, rc));
             TRY(wgrad(s, dt, D, c.n_channels, B * T, op(ws + w.dpre, es, 0, D, 0), op(ws + w.xs, es, 0, c.n_channels, 0),
                       grads + p.embw, c.n_channels));
-            TRY(wq.join(0));
         }
         TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
@@ -599,7 +581,6 @@ void nbci_ndt1_plan_destroy(nbci_ndt1_plan plan) {
     if (!p) return;
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_flat_of) (void)hipFree(p->d_flat_of);
-    p->side.destroy();
     delete p;
 }
 

@@ -2,7 +2,6 @@
 // flat-parameter bookkeeping, workspace carving, GEMM descriptor helpers, weight-gradient queue.
 #pragma once
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,48 +65,13 @@ static inline int wgrad(hipStream_t s, int dtype, int M, int N, int K, nbci_oper
     return gemm_launch_timed(d, s);
 }
 
-// Second HIP stream for work that is off the critical path of the backward chain (the weight gradients:
-// nothing downstream reads them until the optimizer). The chain's GEMMs leave the chip partly idle in
-// their ramp-up, tail and HBM-bound epilogues, and a LayerNorm / attention backward leaves MFMA idle
-// altogether; a weight-gradient launch queued on a lower-priority stream fills those holes. Ordering is
-// by events only (fork: operands exist; done: the chain may overwrite them / the caller may read grads).
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-    bool tried = false;
-    bool ensure() {   // lazily, on the device that is current at the first backward
-        if (tried) return s != nullptr;
-        tried = true;
-        const char* e = getenv("NBCI_OVERLAP");   // opt-in: measured SLOWER on the NDT1 step
-        if (!(e && e[0] == '1')) return false;
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) { s = nullptr; (void)hipGetLastError(); return false; }
-        for (int i = 0; i < 2; ++i)
-            if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) { destroy(); (void)hipGetLastError(); return false; }
-        return true;
-    }
-    void destroy() {
-        for (int i = 0; i < 2; ++i) {
-            if (fork[i]) (void)hipEventDestroy(fork[i]);
-            if (done[i]) (void)hipEventDestroy(done[i]);
-            fork[i] = done[i] = nullptr;
-        }
-        if (s) (void)hipStreamDestroy(s);
-        s = nullptr;
-    }
-};
-
-// A layer's weight gradients are queued and issued as grouped launches (full-K tiles, beta = 1, no
-// split-K atomics) once their operands exist; in f32 mode they run one by one as before.
+// A layer's weight gradients are queued and issued as ONE grouped launch (full-K tiles, beta = 1, no
+// split-K atomics) once all their operands exist; in f32 mode they run one by one as before.
 struct WgradQueue {
     nbci_gemm_desc d[6];
     int n = 0;
     int dtype;
     hipStream_t s;
-    SideStream* side = nullptr;   // when set, flush_async() issues on side->s
-    int layer_tiles = 0;          // output tiles of ALL of the layer's weight gradients (decides grouped vs split-K)
     int push(int M, int N, int K, nbci_operand A, nbci_operand B, float* dW, int64_t ldw) {
         if (dtype != NBCI_BF16 || n >= 6) return wgrad(s, dtype, M, N, K, A, B, dW, ldw);
         d[n] = gd(M, N, K, dtype, A, B, dW, ldw, NBCI_F32);
@@ -115,42 +79,21 @@ struct WgradQueue {
         ++n;
         return NBCI_OK;
     }
-    int issue(hipStream_t st, int tiles_for_choice) {
+    int flush() {
         if (n == 0) return NBCI_OK;
         // full-K tiles only pay off when the group fills the chip: with few output tiles and a very long K (narrow
         // models, huge row counts) split-K launches are the better shape
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += ((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
         int rc = NBCI_OK;
-        if (tiles_for_choice >= 192) {
-            rc = gemm_grouped_launch_timed(d, n, st);
+        if (tiles >= 192) {
+            rc = gemm_grouped_launch_timed(d, n, s);
         } else {
             for (int i = 0; i < n && rc == NBCI_OK; ++i)
-                rc = wgrad(st, dtype, d[i].M, d[i].N, d[i].K, d[i].A, d[i].B, (float*)d[i].C, d[i].ldc);
+                rc = wgrad(s, dtype, d[i].M, d[i].N, d[i].K, d[i].A, d[i].B, (float*)d[i].C, d[i].ldc);
         }
         n = 0;
         return rc;
-    }
-    int flush() {
-        int tiles = 0;
-        for (int i = 0; i < n; ++i) tiles += ((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
-        return issue(s, tiles);
-    }
-    // Issue what is queued on the side stream (slot = 0 / 1 selects the event pair); without a side stream
-    // the entries stay queued for a later flush().
-    int flush_async(int slot) {
-        if (!side || n == 0) return NBCI_OK;
-        if (hipEventRecord(side->fork[slot], s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork[slot], 0) != hipSuccess)
-            return fail(NBCI_EHIP, "wgrad side stream: fork");
-        const int rc = issue(side->s, layer_tiles);
-        if (rc != NBCI_OK) return rc;
-        if (hipEventRecord(side->done[slot], side->s) != hipSuccess) return fail(NBCI_EHIP, "wgrad side stream: done");
-        return NBCI_OK;
-    }
-    // the chain waits until the side-stream launches of `slot` have finished (before overwriting their operands /
-    // before handing the gradients to the caller)
-    int join(int slot) {
-        if (!side) return NBCI_OK;
-        if (hipStreamWaitEvent(s, side->done[slot], 0) != hipSuccess) return fail(NBCI_EHIP, "wgrad side stream: join");
-        return NBCI_OK;
     }
 };
 
