@@ -144,15 +144,17 @@ int nbci_softmax_bwd(const float* dPd, const void* P, void* dS, int32_t p_dtype,
 
 /* Fused attention (bf16, head size 128, T' <= 160): F.scaled_dot_product_attention(q,k,v,attn_mask,dropout_p)
  * of ndt1.py:289 on a packed (B*T', 3H) qkv buffer, mask of ndt1.py:435-437 built on the fly, output already in the
- * merged (B*T', H) layout with the attention-output dropout of ndt1.py:292 applied. Backward: d_out = d loss / d(Pd v)
- * (B*T', H) -> dqkv (B*T', 3H); dS_ws / Pd_ws: bf16 scratch (B, heads, T', ldP), ldP = round_up(T', 8);
+ * merged (B*T', H) layout with the attention-output dropout of ndt1.py:292 applied; lse: f32 (B, heads, T') row
+ * log-sum-exp of the scaled masked scores, kept for the backward (may be NULL when no backward follows).
+ * Backward: out / lse = what the forward wrote; d_out = d loss / d(Pd v) (B*T', H), i.e. with the output dropout's
+ * backward already applied -> dqkv (B*T', 3H); dS_ws / Pd_ws: bf16 scratch (B, heads, T', ldP), ldP = round_up(T', 8);
  * bias_grad: optional f32 (3H) += column sums of dqkv. */
-int nbci_attention_fwd(const void* qkv, const int32_t* token_mask, void* out, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
-                       int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob,
+int nbci_attention_fwd(const void* qkv, const int32_t* token_mask, void* out, float* lse, int32_t B, int32_t n_heads, int32_t Tp,
+                       int32_t H, int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob,
                        uint32_t site_out, nbci_stream_t stream);
-int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d_out, void* dS_ws, void* Pd_ws, int32_t ldP,
-                       void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H, int32_t ctx_forward,
-                       int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream);
+int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* out, const float* lse, const void* d_out, void* dS_ws,
+                       void* Pd_ws, int32_t ldP, void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
+                       int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream);
 
 /* Unmasked multi-head attention WITHOUT a score tensor (online softmax), over a packed (NS*S, 3H) q|k|v buffer of NS
  * sequences of S tokens; out (NS*S, H) merged heads; lse (NS*n_heads*S) f32 row log-sum-exp kept for the backward;

@@ -170,9 +170,9 @@ _SIGNATURES = {
                            C.c_float, C.c_void_p]),
     "nbci_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "nbci_gemm_grouped": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
-    "nbci_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_float, C.c_uint32, C.c_uint32,
+    "nbci_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_float, C.c_uint32, C.c_uint32,
                                                                                                C.c_uint32, C.c_void_p]),
-    "nbci_attention_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +
+    "nbci_attention_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +
                            [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nbci_coupler_splice_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]),
     "nbci_coupler_splice_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),

@@ -64,17 +64,17 @@ int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_str
     return nbci::cast_launch(in, out, out_dtype, n, (hipStream_t)stream);
 }
 
-int nbci_attention_fwd(const void* qkv, const int32_t* token_mask, void* out, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
+int nbci_attention_fwd(const void* qkv, const int32_t* token_mask, void* out, float* lse, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
                        int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, uint32_t site_out,
                        nbci_stream_t stream) {
-    return nbci::attn_fwd_launch(qkv, token_mask, out, B, n_heads, Tp, H, ctx_forward, ctx_backward, drop_p, seed, site_prob, site_out,
+    return nbci::attn_fwd_launch(qkv, token_mask, out, lse, B, n_heads, Tp, H, ctx_forward, ctx_backward, drop_p, seed, site_prob, site_out,
                                  (hipStream_t)stream);
 }
-int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* d_out, void* dS_ws, void* Pd_ws, int32_t ldP, void* dqkv,
-                       float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H, int32_t ctx_forward, int32_t ctx_backward,
-                       float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream) {
-    return nbci::attn_bwd_launch(qkv, token_mask, d_out, dS_ws, Pd_ws, ldP, dqkv, bias_grad, B, n_heads, Tp, H, ctx_forward, ctx_backward,
-                                 drop_p, seed, site_prob, (hipStream_t)stream, nbci::RepCfg{0, 1});
+int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* out, const float* lse, const void* d_out, void* dS_ws,
+                       void* Pd_ws, int32_t ldP, void* dqkv, float* bias_grad, int32_t B, int32_t n_heads, int32_t Tp, int32_t H,
+                       int32_t ctx_forward, int32_t ctx_backward, float drop_p, uint32_t seed, uint32_t site_prob, nbci_stream_t stream) {
+    return nbci::attn_bwd_launch(qkv, token_mask, out, lse, d_out, dS_ws, Pd_ws, ldP, dqkv, bias_grad, B, n_heads, Tp, H, ctx_forward,
+                                 ctx_backward, drop_p, seed, site_prob, (hipStream_t)stream, nbci::RepCfg{0, 1});
 }
 int nbci_coupler_splice_fwd(const void* text, const void* spikes, void* out, int32_t dtype, const int64_t* text_mask,
                             const int64_t* spikes_valid, int64_t* mask_out, const int64_t* targets, int64_t* targets_out,

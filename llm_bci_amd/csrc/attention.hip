@@ -9,9 +9,10 @@
 // (<= 160 keys) stays in registers, so softmax needs only two cross-lane steps and P never
 // leaves registers: the QK^T accumulator IS the B operand of the PV product once the k-order
 // permutation pi(g, j) = {4g+j | 16+4g+(j-4)} is applied to the V operand's row addresses.
-//   fwd     : S = q k^T, masked softmax, dropout, O = Pd v   -> a (pre-dropout) / ad (merged layout)
-//   bwd_dq  : recomputes P; dP = (da v^T) * keep; dS = P (dP - rowsum(dP P)) / sqrt(d);
-//             dq = dS k -> dqkv; stores dS and Pd (bf16) for the second kernel
+//   fwd     : S = q k^T, masked softmax, dropout, O = Pd v   -> ad (merged layout) + row log-sum-exp (f32)
+//   bwd_dq  : 32 keys at a time: P = exp(S - lse); dP = (da v^T) * keep; dS = P (dP - delta) / sqrt(d) with
+//             delta = rowsum(dP P) = da . O taken from the stored forward output (no full score row in registers:
+//             nine waves fit, one per 16-query block); dq = dS k -> dqkv; stores dS and Pd (bf16) for the second kernel
 //   bwd_dkv : dk = dS^T q, dv = Pd^T da  (contraction over queries: both operands tr-read)
 // Larger T', other head sizes and the f32 parity path use the batched-GEMM + softmax kernels.
 #include <cstring>
@@ -73,7 +74,8 @@ struct AttnArgs {
     float scale;
     unsigned p_thr; float p_scale; uint32_t p_key;   // attention-prob dropout
     unsigned o_thr; float o_scale; uint32_t o_key;   // attention-output dropout (forward only)
-    bf16_t* ad;            // fwd out (B*Tp, H): dropout(merge_heads(Pd v))
+    bf16_t* ad;            // fwd out / bwd in (B*Tp, H): dropout(merge_heads(Pd v))
+    float* lse;            // fwd out / bwd in (B, nh, Tp): log-sum-exp of the scaled, masked score row
     const bf16_t* da;      // bwd in  (B*Tp, H): d loss / d (Pd v)
     bf16_t* dS;            // bwd scratch (B, nh, Tp, ldP)
     bf16_t* Pd;            // bwd scratch (B, nh, Tp, ldP)
@@ -96,7 +98,7 @@ __device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4
 }
 
 // masked softmax of the register-resident row; returns normalised probabilities in place
-__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, int b, int query, int g) {
+__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, int b, int query, int g, float* lse_out) {
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < AT_NB; ++kb)
@@ -122,6 +124,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (lse_out && g == 0) *lse_out = mx + __logf(sum);   // (the diagonal is always attendable: sum > 0)
 #pragma unroll
     for (int kb = 0; kb < AT_NB; ++kb)
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
         f32x4 acc[AT_NB];
         score_block(sK, qf, acc, i16, g);
-        softmax_rows(acc, a, b, qrow, g);
+        softmax_rows(acc, a, b, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
         if (a.p_thr) {
             const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
 #pragma unroll
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
     }
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = smem + AT_TPAD * 256;
@@ -206,64 +209,71 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
     __syncthreads();
     const int nqb = (a.Tp + 15) / 16;
-    for (int qb = wave; qb < nqb; qb += AT_THREADS / 64) {
+    const float inv_o_scale = 1.0f / a.o_scale;
+    for (int qb = wave; qb < nqb; qb += (int)(blockDim.x >> 6)) {
         const int query = 16 * qb + i16;
         const int qrow = query < a.Tp ? query : a.Tp - 1;
-        f32x4 p[AT_NB], dp[AT_NB];
-        {
-            bf16x8 qf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
-            score_block(sK, qf, p, i16, g);
-        }
-        softmax_rows(p, a, b, qrow, g);
-        {
-            bf16x8 df[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                df[ks] = *(const bf16x8*)(a.da + ((long long)b * a.Tp + qrow) * a.H + h * AT_HD + 32 * ks + 8 * g);
-            score_block(sV, df, dp, i16, g);      // dPd[query][key] = da . v^T
-        }
-        const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
-        const long long srow = ((long long)blockIdx.x * a.Tp + query) * a.ldP;
+        bf16x8 qf[4], df[4];
         float delta = 0.f;
+        {
+            const long long arow = ((long long)b * a.Tp + qrow) * a.H + h * AT_HD;
 #pragma unroll
-        for (int kb = 0; kb < AT_NB; ++kb) {
-            float pdv[4];
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+                df[ks] = *(const bf16x8*)(a.da + arow + 32 * ks + 8 * g);
+                const bf16x8 of = *(const bf16x8*)(a.ad + arow + 32 * ks + 8 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * kb + 4 * g + r;
-                float keep = (key < a.Tp) ? 1.f : 0.f;
-                if (a.p_thr && key < a.Tp) keep = drop_keep(a.p_key, a.p_thr, rbase + key) ? a.p_scale : 0.f;
-                dp[kb][r] *= keep;                         // dP = dPd * keep
-                pdv[r] = p[kb][r] * keep;                  // Pd
-                delta += dp[kb][r] * p[kb][r];
-            }
-            const int key0 = 16 * kb + 4 * g;
-            if (query < a.Tp && key0 < a.ldP) {
-                bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
-                *(bf16x4*)(a.Pd + srow + key0) = pv;
+                for (int e = 0; e < 8; ++e) delta += bf2f(df[ks][e]) * bf2f(of[e]);
             }
         }
+        // delta = rowsum(dP P) = da . O ; the stored output is dropout(O) and da is zero wherever it was dropped
         delta += __shfl_xor(delta, 16, 64);
         delta += __shfl_xor(delta, 32, 64);
-#pragma unroll
-        for (int kb = 0; kb < AT_NB; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dp[kb][r] = p[kb][r] * (dp[kb][r] - delta) * a.scale;   // dS (scaled), in place
-            const int key0 = 16 * kb + 4 * g;
-            if (query < a.Tp && key0 < a.ldP) {
-                bf16x4 sv = {f2bf(dp[kb][0]), f2bf(dp[kb][1]), f2bf(dp[kb][2]), f2bf(dp[kb][3])};
-                *(bf16x4*)(a.dS + srow + key0) = sv;
-            }
-        }
-        // dq[query][d] = sum_key dS[query][key] k[key][d]   (k image read transposed)
+        delta *= inv_o_scale;
+        const float lse = a.lse[(long long)blockIdx.x * a.Tp + qrow];
+        const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
+        const long long srow = ((long long)blockIdx.x * a.Tp + query) * a.ldP;
         f32x4 o[8];
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < AT_NB / 2; ++s) {
-            const bf16x8 sf = pack8(dp[2 * s], dp[2 * s + 1]);
+            f32x4 sc[2], dp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kb = 2 * s + j;
+                sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, 16 * kb + i16, ks, g), qf[ks], sc[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, 16 * kb + i16, ks, g), df[ks], dp[j], 0, 0, 0);   // dPd = da . v^T
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kb = 2 * s + j;
+                float pdv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kb + 4 * g + r;
+                    const bool ok = key < a.Tp && ((key == qrow) || (ctx_ok(qrow, key, a.cf, a.cb) && a.tmask[b * a.Tp + key] != 0));
+                    const float p = ok ? __expf(sc[j][r] * a.scale - lse) : 0.f;
+                    float keep = (key < a.Tp) ? 1.f : 0.f;
+                    if (a.p_thr && key < a.Tp) keep = drop_keep(a.p_key, a.p_thr, rbase + key) ? a.p_scale : 0.f;
+                    pdv[r] = p * keep;                                        // Pd
+                    dp[j][r] = p * (dp[j][r] * keep - delta) * a.scale;       // dS (scaled), in place
+                }
+                const int key0 = 16 * kb + 4 * g;
+                if (query < a.Tp && key0 < a.ldP) {
+                    bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
+                    *(bf16x4*)(a.Pd + srow + key0) = pv;
+                    bf16x4 sv = {f2bf(dp[j][0]), f2bf(dp[j][1]), f2bf(dp[j][2]), f2bf(dp[j][3])};
+                    *(bf16x4*)(a.dS + srow + key0) = sv;
+                }
+            }
+            // dq[query][d] += sum over these 32 keys of dS[query][key] k[key][d]   (k image read transposed)
+            const bf16x8 sf = pack8(dp[0], dp[1]);
 #pragma unroll
             for (int db = 0; db < 8; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, i16), sf,
@@ -385,7 +395,7 @@ static AttnArgs base_args(const void* qkv, const int32_t* tmask, int B, int nh, 
     return a;
 }
 
-int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
+int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
                     uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
     static bool once = false;
@@ -393,7 +403,7 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int 
     if (!once) { int r = set_lds((const void*)attn_fwd_kernel, lds); if (r) return r; once = true; }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
-    a.ad = (bf16_t*)ad;
+    a.ad = (bf16_t*)ad; a.lse = lse;
     const int nblk = (Tp + 15) / 16;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
     hipError_t e = hipGetLastError();
@@ -401,8 +411,8 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int 
     return NBCI_OK;
 }
 
-int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void* dS, void* Pd, int ldP, void* dqkv,
-                    float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
+int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const float* lse, const void* da, void* dS, void* Pd, int ldP,
+                    void* dqkv, float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
                     hipStream_t s, RepCfg rc) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
     NBCI_REQUIRE(ldP % 8 == 0 && ldP >= Tp && ldP <= AT_TPAD, NBCI_ESHAPE, "fused attention: bad ldP");
@@ -414,9 +424,11 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void*
         once = true;
     }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
+    NBCI_REQUIRE(ad && lse, NBCI_EINVAL, "fused attention backward: needs the forward output and its log-sum-exp");
+    a.ad = (bf16_t*)ad; a.lse = (float*)lse; a.o_scale = a.p_scale;
     a.da = (const bf16_t*)da; a.dS = (bf16_t*)dS; a.Pd = (bf16_t*)Pd; a.ldP = ldP; a.dqkv = (bf16_t*)dqkv; a.bias_grad = bias_grad; a.rc = rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(AT_THREADS), lds1, s, a);
     const int nblk = (Tp + 15) / 16;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds1, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(64 * (nblk < 2 ? 2 : nblk)), lds2, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_bwd: ") + hipGetErrorString(e));

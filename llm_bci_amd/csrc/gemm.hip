@@ -105,7 +105,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
         cur ^= 1;
     }
 
-    gemm_epilogue<4, 4>(d, acc, m0 + wm * 64, n0 + wn * 64, coff, lane, w, smem);
+    if (d.splitk > 1) {
+        gemm_epilogue<4, 4>(d, acc, m0 + wm * 64, n0 + wn * 64, coff, lane, w, smem);
+        return;
+    }
+    gemm_epilogue_tile<4, 4>(d, acc, wm * 64, wn * 64, m0, n0, GEMM_BM, coff, t, GEMM_THREADS, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -124,7 +128,17 @@ static bool operand_vec_ok(const nbci_operand& o, int E, size_t esz) {
 template <typename T, bool AK, bool BKM>
 static int launch_inst(const GemmK& k, dim3 grid, hipStream_t stream) {
     // split-K transposes the 4 x 16 KB accumulator tiles through LDS in its epilogue
-    const int lds = (k.splitk > 1 && 4 * GemmTile<T>::REGION < 65536) ? 65536 : 4 * GemmTile<T>::REGION;
+    // split-K transposes the 4 x 16 KB accumulator tiles through LDS in its epilogue; otherwise the row-contiguous
+    // epilogue needs a 128 x 132 f32 tile (67.6 KB: above the 64 KB default limit -> attribute)
+    constexpr int epi = GEMM_BM * EPI_LD * 4;
+    const int lds = k.splitk > 1 ? (4 * GemmTile<T>::REGION < 65536 ? 65536 : 4 * GemmTile<T>::REGION)
+                                 : (4 * GemmTile<T>::REGION < epi ? epi : 4 * GemmTile<T>::REGION);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AK, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, epi);
+        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm: LDS attribute: ") + hipGetErrorString(e));
+        attr_set = true;
+    }
     hipLaunchKernelGGL((gemm_kernel<T, AK, BKM>), grid, dim3(GEMM_THREADS), lds, stream, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm launch: ") + hipGetErrorString(e));

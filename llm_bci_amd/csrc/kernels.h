@@ -136,10 +136,10 @@ int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
 
 // fused attention (attention.hip): bf16, head 128, T' <= 160
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh);
-int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
+int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
                     uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s);
-int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* da, void* dS, void* Pd, int ldP, void* dqkv,
-                    float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
-                    hipStream_t s, RepCfg rc = RepCfg{0, 1});
+int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const float* lse, const void* da, void* dS, void* Pd, int ldP,
+                    void* dqkv, float* bias_grad, int B, int nh, int Tp, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_p,
+                    hipStream_t s, RepCfg rc);
 
 }  // namespace nbci

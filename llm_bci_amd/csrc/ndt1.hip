@@ -121,7 +121,7 @@ static void build_layout(Plan& p) {
 
 // ---- workspace carve -----------------------------------------------------------------------
 struct LayerWS {
-    size_t x_in, mean1, rstd1, h1, qkv, P, Pd, ad, x_mid, mean2, rstd2, h2, u, g;
+    size_t x_in, mean1, rstd1, h1, qkv, P, Pd, ad, lse, x_mid, mean2, rstd2, h2, u, g;
 };
 struct WS {
     size_t xs, y, tmask, tts, tlens;
@@ -160,6 +160,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
         l.P = bump(cur, nP * es);
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * H * es);
+        l.lse = bump(cur, (size_t)B * c.n_heads * Tp * 4);
         l.x_mid = bump(cur, M * H * 4);
         l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
         l.h2 = bump(cur, M * H * es);
@@ -279,7 +280,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         if (c.use_rope)
             TRY(rope_launch(ws + lw.qkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 0, s));
         if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
-            TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, B, nh, Tp, H, c.context_forward,
+            TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H, c.context_forward,
                                 c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
         } else {
             {   // scores = q k^T / sqrt(hd), batched over (b, head)
@@ -447,7 +448,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
             const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
-                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
+                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
                                     nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
             } else {

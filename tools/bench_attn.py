@@ -21,6 +21,7 @@ dS = torch.zeros(B * nh * Tp * ldP, device=dev, dtype=torch.bfloat16)
 Pd = torch.zeros_like(dS)
 dqkv = torch.zeros_like(qkv)
 bg = torch.zeros(3 * H, device=dev)
+lse = torch.zeros(B * nh * Tp, device=dev)
 l = lib()
 
 
@@ -38,7 +39,7 @@ def timeit(fn, n=20):
 
 
 for p in (0.0, 0.4):
-    f = lambda: check(l.nbci_attention_fwd(vp(qkv), vp(tm), vp(out), B, nh, Tp, H, -2, -2, p, 1, 16, 17, st()), "fwd")
-    b1 = lambda: check(l.nbci_attention_bwd(vp(qkv), vp(tm), vp(da), vp(dS), vp(Pd), ldP, vp(dqkv), vp(bg), B, nh, Tp, H, -2, -2, p, 1, 16, st()), "bwd")
-    b0 = lambda: check(l.nbci_attention_bwd(vp(qkv), vp(tm), vp(da), vp(dS), vp(Pd), ldP, vp(dqkv), None, B, nh, Tp, H, -2, -2, p, 1, 16, st()), "bwd")
+    f = lambda: check(l.nbci_attention_fwd(vp(qkv), vp(tm), vp(out), vp(lse), B, nh, Tp, H, -2, -2, p, 1, 16, 17, st()), "fwd")
+    b1 = lambda: check(l.nbci_attention_bwd(vp(qkv), vp(tm), vp(out), vp(lse), vp(da), vp(dS), vp(Pd), ldP, vp(dqkv), vp(bg), B, nh, Tp, H, -2, -2, p, 1, 16, st()), "bwd")
+    b0 = lambda: check(l.nbci_attention_bwd(vp(qkv), vp(tm), vp(out), vp(lse), vp(da), vp(dS), vp(Pd), ldP, vp(dqkv), None, B, nh, Tp, H, -2, -2, p, 1, 16, st()), "bwd")
     print(f"p={p}: fwd {timeit(f):.1f} us   bwd(bias) {timeit(b1):.1f} us   bwd(no bias) {timeit(b0):.1f} us", flush=True)
