@@ -72,6 +72,39 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_wa
     }
 }
 
+// Transposed fragment reads of a row-major-in-k tile, issued as INLINE ASM. Through the builtin
+// (__builtin_amdgcn_ds_read_tr16_b64) hipcc 7.2 cannot tell that the read does not alias an LDS-DMA still in
+// flight, and puts `s_waitcnt vmcnt(0)` in front of the first transposed read of every K tile: the prefetch of
+// the next tile(s) is drained before the current tile is computed, load and compute run back to back, and deeper
+// pipelines buy nothing (measured: weight-gradient GEMMs at one load round trip, ~1.25 us, per K tile whatever
+// the stage count). The compiler neither waits for nor counts an asm read, so the caller issues
+// `s_waitcnt lgkmcnt(0)` + sched_barrier before the first use (ordering against the LDS-DMA is the K loop's own
+// vmcnt + barrier, as for the plain reads).
+template <int OFF>
+__device__ __forceinline__ s16x4 ds_read_tr_asm(unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+// byte address (k-step 0, low half) of the fragment of 16 columns starting at r0 (see read_frag_bf16<false>):
+// k row = 32 ks + 8 g + q (+ 4 for the high half) -> the k-step adds 8192 B, the high half 1024 B; the granule
+// swizzle rm_swz(k row) = (q & 3) | ((g & 1) << 2) does not depend on either
+__device__ __forceinline__ unsigned tr_frag_base(const char* s, int r0, int i16, int g) {
+    const int q = i16 >> 2, p = i16 & 3;
+    const int swz = (q & 3) | ((g & 1) << 2);
+    return lds_addr(s) + (8 * g + q) * 256 + ((((r0 >> 4) ^ swz) << 5) | (p << 3));
+}
+template <int KS>
+__device__ __forceinline__ bf16x8 read_frag_tr_asm(unsigned base) {
+    union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+    u.p2.a = ds_read_tr_asm<8192 * KS>(base);
+    u.p2.b = ds_read_tr_asm<8192 * KS + 1024>(base);
+    return u.v;
+}
+
 template <bool AK, bool BKM, int MI, int NI>
 __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
     const int i16 = lane & 15, g = lane >> 4;
@@ -79,28 +112,39 @@ __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f
     // stay in flight under the first step's MFMAs (lgkmcnt retires in order, hipcc waits per use)
     bf16x8 af[2][MI], bf[2][NI];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int sb = 0; sb < NI; ++sb) bf[ks][sb] = read_frag_bf16<BKM>(sB, bc0 + sb * 16, ks, i16, g);
-#pragma unroll
-        for (int sb = 0; sb < MI; ++sb) af[ks][sb] = read_frag_bf16<AK>(sA, ar0 + sb * 16, ks, i16, g);
+    for (int sb = 0; sb < NI; ++sb) {
+        if constexpr (BKM) {
+            bf[0][sb] = read_frag_bf16<true>(sB, bc0 + sb * 16, 0, i16, g);
+            bf[1][sb] = read_frag_bf16<true>(sB, bc0 + sb * 16, 1, i16, g);
+        } else {
+            const unsigned base = tr_frag_base(sB, bc0 + sb * 16, i16, g);
+            bf[0][sb] = read_frag_tr_asm<0>(base);
+            bf[1][sb] = read_frag_tr_asm<1>(base);
+        }
     }
+#pragma unroll
+    for (int sb = 0; sb < MI; ++sb) {
+        if constexpr (AK) {
+            af[0][sb] = read_frag_bf16<true>(sA, ar0 + sb * 16, 0, i16, g);
+            af[1][sb] = read_frag_bf16<true>(sA, ar0 + sb * 16, 1, i16, g);
+        } else {
+            const unsigned base = tr_frag_base(sA, ar0 + sb * 16, i16, g);
+            af[0][sb] = read_frag_tr_asm<0>(base);
+            af[1][sb] = read_frag_tr_asm<1>(base);
+        }
+    }
+    if constexpr (!AK || !BKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm reads are invisible to hipcc's counters
     // hipcc otherwise sinks each pair of ds_reads next to its 4 MFMAs with an lgkmcnt(0) in front (to save
-    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs;
-    // the compiler's counted lgkmcnt waits let the MFMAs start as the fragments arrive, in order.
+    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs
+    // (and the MFMAs behind the explicit wait above).
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-#if defined(NBCI_ABLATE) && NBCI_ABLATE == 1
-                asm volatile("" :: "v"(bf[ks][ni]), "v"(af[ks][mi]));
-#else
+            for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
-#endif
-            }
     }
 }
 

@@ -213,7 +213,8 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
     return check_launch("layernorm_fwd");
 }
 
-constexpr int LNB_ROWS = 8;  // rows per block: 2 per wave, both rows' loads in flight together
+constexpr int LNB_ITERS = 2;             // passes per block (the column partial sums stay in registers across them)
+constexpr int LNB_ROWS = 8 * LNB_ITERS;  // rows per block: 2 per wave and pass, both rows' loads in flight together
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float4 gw[NV], gb[NV], gc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; gc[k] = gw[k]; }
-    const int ra = blockIdx.x * LNB_ROWS + wv * 2;
+#pragma unroll 1
+  for (int it = 0; it < LNB_ITERS; ++it) {
+    const int ra = blockIdx.x * LNB_ROWS + it * 8 + wv * 2;
     float4 xv[2][NV], dv[2][NV], od[2][NV];
     float mu[2], rs[2];
 #pragma unroll
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
+  }
     // cross-wave reduce through LDS, then thread t owns columns t, t+256, ...: one CONTIGUOUS 256-B
     // atomic wave-instruction per 64 columns (float atomics run at full rate only in that shape)
 #pragma unroll
