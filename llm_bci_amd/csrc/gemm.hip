@@ -114,6 +114,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmK d) {
 
 // ---- host side ---------------------------------------------------------------------------
 bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k);
+bool glds_view(const nbci_gemm_desc& d);
 int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
 int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream);
 static bool operand_vec_ok(const nbci_operand& o, int E, size_t esz) {
@@ -226,7 +227,7 @@ int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream) 
     for (int i = 0; i < n && ok; ++i) {
         int rc = build_gemmk(descs[i], ks[i]);
         if (rc != NBCI_OK) return rc;
-        ok = descs[i].in_dtype == NBCI_BF16 && ks[i].splitk == 1 && descs[i].batch <= 1 && glds_eligible(descs[i], ks[i]) &&
+        ok = descs[i].in_dtype == NBCI_BF16 && ks[i].splitk == 1 && descs[i].batch <= 1 && glds_eligible(descs[i], ks[i]) && !glds_view(descs[i]) &&
              (descs[i].A.kmajor != 0) == (descs[0].A.kmajor != 0) && (descs[i].B.kmajor != 0) == (descs[0].B.kmajor != 0);
     }
     if (ok) return gemm_group_launch(descs, ks, n, stream);

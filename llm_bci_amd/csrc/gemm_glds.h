@@ -43,16 +43,23 @@ __device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES, NW>& g, 
     g.step = KMAJOR ? 64 : 64 * o.ld;
 }
 
-template <bool KMAJOR, int NPIECES, int NW = 4>
+// Issue this wave's LDS-DMA pieces of K tile `kt`. VIEW = the operand is row-major-in-k AND an overlapping-window
+// view (k rows are not equidistant across groups: one division per piece per tile); every other case is
+// base + offset + kt * step with NO branch in the K loop — the per-piece "is it a view" / "does this wave own the
+// piece" tests used to cost ~60 scalar + vector instructions and half a dozen branches per piece per K tile.
+template <bool KMAJOR, int NPIECES, int NW = 4, bool VIEW = false>
 __device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
+    constexpr int PW = GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE;
 #pragma unroll
-    for (int i = 0; i < GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE; ++i) {
+    for (int i = 0; i < PW; ++i) {
         const int p = w + NW * i;
-        if (p < NPIECES) {
-            const bf16_t* src;
-            if (!KMAJOR && o.rpb > 0) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
-            else src = g.base + g.off[i] + (long long)kt * g.step;
+        const bf16_t* src;
+        if constexpr (VIEW && !KMAJOR) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
+        else src = g.base + g.off[i] + (long long)kt * g.step;
+        if constexpr (NPIECES % NW == 0) {
             __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
+        } else {
+            if (i < PW - 1 || p < NPIECES) __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
         }
     }
 }

@@ -21,7 +21,7 @@
 
 namespace nbci {
 
-template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x, const int block_y, char* smem) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     static_assert(BN == 128, "B tile is always 128 wide");
@@ -92,8 +92,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
 
     int cur = 0;
     if (kt_begin < kt_full_end) {
-        glds_stage<AK, NPA>(ga, A, smem, kt_begin, w);
-        glds_stage<BKM, NPB>(gb, B, smem + A_BYTES, kt_begin, w);
+        glds_stage<AK, NPA, 4, VIEW>(ga, A, smem, kt_begin, w);
+        glds_stage<BKM, NPB, 4, VIEW>(gb, B, smem + A_BYTES, kt_begin, w);
     }
     __syncthreads();  // drains the LDS-DMA (hipcc emits vmcnt(0) ahead of the barrier)
     for (int kt = kt_begin; kt < kt_full_end; ++kt) {
@@ -103,8 +103,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
         if (kt + 1 < kt_full_end) {
 #endif
             char* nx = smem + (cur ^ 1) * STAGE;
-            glds_stage<AK, NPA>(ga, A, nx, kt + 1, w);
-            glds_stage<BKM, NPB>(gb, B, nx + A_BYTES, kt + 1, w);
+            glds_stage<AK, NPA, 4, VIEW>(ga, A, nx, kt + 1, w);
+            glds_stage<BKM, NPB, 4, VIEW>(gb, B, nx + A_BYTES, kt + 1, w);
         }
         const char* sA = smem + cur * STAGE;
         compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
@@ -133,10 +133,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, GEMM_THREADS, smem);
 }
 
-template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_kernel(GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_glds_body<AK, BKM, WM, WN, MI, NI>(d, blockIdx.x, blockIdx.y, smem);
+    gemm_glds_body<AK, BKM, WM, WN, MI, NI, VIEW>(d, blockIdx.x, blockIdx.y, smem);
 }
 
 // Several independent GEMMs of one layout in ONE launch (block ranges by prefix sums). Used for the
@@ -270,24 +270,28 @@ static bool glds_operand_ok(const nbci_operand& o, int R) {
     return true;
 }
 
+// a row-major-in-k operand that is an overlapping-window view: its k rows need a division per K tile (VIEW kernels)
+bool glds_view(const nbci_gemm_desc& d) { return (!d.A.kmajor && d.A.rpb > 0) || (!d.B.kmajor && d.B.rpb > 0); }
+
 bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k) {
     (void)k;
     if (d.in_dtype != NBCI_BF16 || d.K < 64) return false;
+    if (glds_view(d) && (d.A.kmajor || d.B.kmajor)) return false;   // the view loop exists for the weight-gradient layout only
     return glds_operand_ok(d.A, d.M) && glds_operand_ok(d.B, d.N);
 }
 
-template <bool AK, bool BKM, int WM, int WN, int MI, int NI>
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
     constexpr int stage2 = 2 * (WM * MI * 16 * 128 + 16384), epi = WM * MI * 16 * EPI_LD * 4;   // K-loop stages / epilogue tile
     constexpr int lds = stage2 > epi ? stage2 : epi;
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI, VIEW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds: LDS attribute: ") + hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<AK, BKM, WM, WN, MI, NI>), grid, dim3(GEMM_THREADS), lds, s, k);
+    hipLaunchKernelGGL((gemm_glds_kernel<AK, BKM, WM, WN, MI, NI, VIEW>), grid, dim3(GEMM_THREADS), lds, s, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds launch: ") + hipGetErrorString(e));
     return NBCI_OK;
@@ -315,7 +319,7 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
     for (int i = 0; i < n; ++i) {
         NBCI_REQUIRE((descs[i].A.kmajor != 0) == ak && (descs[i].B.kmajor != 0) == bk, NBCI_EINVAL, "gemm group: mixed layouts");
         NBCI_REQUIRE(ks[i].splitk == 1 && (descs[i].batch <= 1), NBCI_EINVAL, "gemm group: no split-K / batch");
-        NBCI_REQUIRE(glds_eligible(descs[i], ks[i]), NBCI_EALIGN, "gemm group: operand not eligible for the direct-to-LDS path");
+        NBCI_REQUIRE(glds_eligible(descs[i], ks[i]) && !glds_view(descs[i]), NBCI_EALIGN, "gemm group: operand not eligible for the direct-to-LDS path");
         grp.sub[i] = ks[i];
         grp.sub[i].tiles_m = (descs[i].M + 127) / 128;
         grp.start[i + 1] = grp.start[i] + grp.sub[i].tiles_m * grp.sub[i].tiles_n;
@@ -364,6 +368,7 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     k.tiles_m = (d.M + bm - 1) / bm;
     dim3 grid(k.tiles_m * k.tiles_n * (splitk > 1 ? splitk : 1), splitk > 1 ? 1 : batch);
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
+    if (glds_view(d)) return launch_glds<false, false, 2, 2, 4, 4, true>(k, grid, stream);   // (eligibility: both row-major-in-k)
     // small grids (at most one workgroup per CU): nothing else hides the per-tile load latency -> 4-stage pipeline
     static const bool ms_off = [] { const char* e = getenv("NBCI_GEMM_MS"); return e && e[0] == '0'; }();
     // very small grids (<= half the CUs at 128-row tiles): 64-row tiles double the workgroup count; 5 stages of 24 KB
