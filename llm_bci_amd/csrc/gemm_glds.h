@@ -112,47 +112,70 @@ __device__ __forceinline__ bf16x8 read_frag_tr_asm(unsigned base) {
     return u.v;
 }
 
+// k-major tile [rows][64 k], 128-B rows, 16-B chunk ^= (row >> 1) & 7 (read_frag_bf16<true>): the fragment of rows
+// r0 + 16 sb .. + 15 at k-step ks sits at  (base0 ^ 64 ks) + 2048 sb  (the swizzle term does not depend on sb)
+__device__ __forceinline__ unsigned km_frag_base(const char* s, int r0, int i16, int g) {
+    return lds_addr(s) + (r0 + i16) * 128 + ((g ^ ((i16 >> 1) & 7)) << 4);
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 ds_read_b128_asm(unsigned addr) {
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N, int SB = 0>
+__device__ __forceinline__ void km_read_frags(bf16x8 (&f)[N], unsigned base_ks) {
+    if constexpr (SB < N) {
+        f[SB] = ds_read_b128_asm<2048 * SB>(base_ks);
+        km_read_frags<N, SB + 1>(f, base_ks);
+    }
+}
+template <int KS, int N>
+__device__ __forceinline__ void tr_read_frags(bf16x8 (&f)[N], const unsigned (&base_sb)[N]) {
+#pragma unroll
+    for (int sb = 0; sb < N; ++sb) f[sb] = read_frag_tr_asm<KS>(base_sb[sb]);
+}
+
+// One K tile (64 k) of MFMAs for a wave tile of MI x NI 16 x 16 blocks. ALL fragment reads are inline asm, in
+// k-step order, and the waits are explicit: hipcc waits lgkmcnt(0) before the first MFMA whatever the order
+// (scalar loads share the counter), i.e. for both k-steps' fragments. Here the first k-step's MFMAs start once
+// ITS fragments have landed — a counted lgkmcnt: LDS reads return in order, and scalar loads that may also be
+// outstanding only make a counted wait conservative — while the second k-step's reads are still in flight.
 template <bool AK, bool BKM, int MI, int NI>
 __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
     const int i16 = lane & 15, g = lane >> 4;
-    // all fragment reads of BOTH k-steps are issued before the first MFMA: the second step's ds_reads
-    // stay in flight under the first step's MFMAs (lgkmcnt retires in order, hipcc waits per use)
     bf16x8 af[2][MI], bf[2][NI];
+    unsigned ka[2] = {0u, 0u}, kb[2] = {0u, 0u}, ta[MI], tb[NI];
+    if constexpr (AK) { ka[0] = km_frag_base(sA, ar0, i16, g); ka[1] = ka[0] ^ 64u; }
+    else {
 #pragma unroll
-    for (int sb = 0; sb < NI; ++sb) {
-        if constexpr (BKM) {
-            bf[0][sb] = read_frag_bf16<true>(sB, bc0 + sb * 16, 0, i16, g);
-            bf[1][sb] = read_frag_bf16<true>(sB, bc0 + sb * 16, 1, i16, g);
-        } else {
-            const unsigned base = tr_frag_base(sB, bc0 + sb * 16, i16, g);
-            bf[0][sb] = read_frag_tr_asm<0>(base);
-            bf[1][sb] = read_frag_tr_asm<1>(base);
-        }
+        for (int sb = 0; sb < MI; ++sb) ta[sb] = tr_frag_base(sA, ar0 + sb * 16, i16, g);
     }
+    if constexpr (BKM) { kb[0] = km_frag_base(sB, bc0, i16, g); kb[1] = kb[0] ^ 64u; }
+    else {
 #pragma unroll
-    for (int sb = 0; sb < MI; ++sb) {
-        if constexpr (AK) {
-            af[0][sb] = read_frag_bf16<true>(sA, ar0 + sb * 16, 0, i16, g);
-            af[1][sb] = read_frag_bf16<true>(sA, ar0 + sb * 16, 1, i16, g);
-        } else {
-            const unsigned base = tr_frag_base(sA, ar0 + sb * 16, i16, g);
-            af[0][sb] = read_frag_tr_asm<0>(base);
-            af[1][sb] = read_frag_tr_asm<1>(base);
-        }
+        for (int sb = 0; sb < NI; ++sb) tb[sb] = tr_frag_base(sB, bc0 + sb * 16, i16, g);
     }
-    if constexpr (!AK || !BKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm reads are invisible to hipcc's counters
-    // hipcc otherwise sinks each pair of ds_reads next to its 4 MFMAs with an lgkmcnt(0) in front (to save
-    // VGPRs): the LDS latency is then paid 18 times per tile. The fence keeps all reads ahead of the MFMAs
-    // (and the MFMAs behind the explicit wait above).
+    if constexpr (BKM) km_read_frags<NI>(bf[0], kb[0]); else tr_read_frags<0, NI>(bf[0], tb);
+    if constexpr (AK) km_read_frags<MI>(af[0], ka[0]); else tr_read_frags<0, MI>(af[0], ta);
+    if constexpr (BKM) km_read_frags<NI>(bf[1], kb[1]); else tr_read_frags<1, NI>(bf[1], tb);
+    if constexpr (AK) km_read_frags<MI>(af[1], ka[1]); else tr_read_frags<1, MI>(af[1], ta);
+    constexpr int R1 = (BKM ? NI : 2 * NI) + (AK ? MI : 2 * MI);   // read instructions of the second k-step
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R1 < 15 ? R1 : 15) : "memory");
+    __builtin_amdgcn_sched_barrier(0);   // MFMAs do not touch memory: without the fence hipcc may hoist them above the wait
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][ni], af[0][mi], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
-    }
+        for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][ni], af[1][mi], acc[mi][ni], 0, 0, 0);
 }
 
 }  // namespace nbci
