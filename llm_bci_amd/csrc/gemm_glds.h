@@ -43,24 +43,46 @@ __device__ __forceinline__ void glds_setup(GldsOperand<KMAJOR, NPIECES, NW>& g, 
     g.step = KMAJOR ? 64 : 64 * o.ld;
 }
 
-// Issue this wave's LDS-DMA pieces of K tile `kt`. VIEW = the operand is row-major-in-k AND an overlapping-window
-// view (k rows are not equidistant across groups: one division per piece per tile); every other case is
-// base + offset + kt * step with NO branch in the K loop — the per-piece "is it a view" / "does this wave own the
-// piece" tests used to cost ~60 scalar + vector instructions and half a dozen branches per piece per K tile.
+// Issue this wave's LDS-DMA pieces of K tile `kt`: base + offset + kt * step, with NO branch in the K loop — the
+// per-piece "is it a view" / "does this wave own the piece" tests used to cost ~60 scalar + vector instructions and
+// half a dozen branches per piece per K tile.
+// VIEW = a row-major-in-k operand may be an overlapping-window view (k rows are not equidistant across groups of
+// rpb rows). Those kernels walk K sequentially: glds_view_seek() positions every piece at the first K tile (one
+// division), then each call issues the CURRENT tile and steps 64 k rows ahead with adds only (`kt` is ignored).
 template <bool KMAJOR, int NPIECES, int NW = 4, bool VIEW = false>
-__device__ __forceinline__ void glds_stage(const GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
+__device__ __forceinline__ void glds_stage(GldsOperand<KMAJOR, NPIECES, NW>& g, const OperandK& o, char* lds, int kt, int w) {
     constexpr int PW = GldsOperand<KMAJOR, NPIECES, NW>::PER_WAVE;
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int p = w + NW * i;
         const bf16_t* src;
-        if constexpr (VIEW && !KMAJOR) src = g.base + row_offset(o, kt * 64 + g.krow[i]) + g.col[i];
-        else src = g.base + g.off[i] + (long long)kt * g.step;
+        if constexpr (VIEW && !KMAJOR) {
+            src = g.base + g.off[i];
+            g.off[i] += 64 * o.ld;
+            if (o.rpb > 0) {
+                g.krow[i] += 64;
+                while (g.krow[i] >= o.rpb) { g.krow[i] -= o.rpb; g.off[i] += o.gstride - (long long)o.rpb * o.ld; }
+            }
+        } else {
+            src = g.base + g.off[i] + (long long)kt * g.step;
+        }
         if constexpr (NPIECES % NW == 0) {
             __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
         } else {
             if (i < PW - 1 || p < NPIECES) __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(lds + p * 1024), 16, 0, 0);
         }
+    }
+}
+
+// (VIEW kernels) position a row-major-in-k operand at K tile kt0: off = element offset of this lane's chunk there,
+// krow = its k row's index inside the group of rpb rows
+template <int NPIECES, int NW>
+__device__ __forceinline__ void glds_view_seek(GldsOperand<false, NPIECES, NW>& g, const OperandK& o, int kt0) {
+#pragma unroll
+    for (int i = 0; i < GldsOperand<false, NPIECES, NW>::PER_WAVE; ++i) {
+        const int r = kt0 * 64 + g.krow[i];
+        g.off[i] = row_offset(o, r) + g.col[i];
+        g.krow[i] = o.rpb > 0 ? r % o.rpb : 0;
     }
 }
 

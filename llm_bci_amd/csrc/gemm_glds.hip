@@ -90,6 +90,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     glds_setup<AK, NPA>(ga, A, m0, d.M, w, lane);
     glds_setup<BKM, NPB>(gb, B, n0, d.N, w, lane);
 
+    if constexpr (VIEW) {
+        static_assert(!AK && !BKM, "view kernels exist for the weight-gradient layout");
+        glds_view_seek<NPA, 4>(ga, A, kt_begin);
+        glds_view_seek<NPB, 4>(gb, B, kt_begin);
+    }
     int cur = 0;
     if (kt_begin < kt_full_end) {
         glds_stage<AK, NPA, 4, VIEW>(ga, A, smem, kt_begin, w);
