@@ -202,6 +202,11 @@ int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_l
              int32_t blank, int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch,
              nbci_stream_t stream);
 
+/* Per-step bookkeeping of Trainer.train (models/trainer.py:353-362) in one launch, no host sync: stats (4 x f64 on the
+ * device) accumulates {sum of the per-sample losses, n_examples, per-batch PER ratio sum(errors[:,0]) / sum(errors[:,1]),
+ * number of batches}; errors = nbci_per's (B,2) output or NULL (no metric this step). */
+int nbci_step_stats(double* stats, const float* loss, int32_t B, double n_examples, const int32_t* errors, nbci_stream_t stream);
+
 /* torch.optim.AdamW step over a flat buffer (models/trainer.py:229,340); bc1/bc2 = 1 - beta^t.
  * p_lp: optional bf16 shadow of p refreshed in the same pass. g is multiplied by grad_scale first
  * (1/world_size turns an all-reduce SUM into DDP's mean). */

@@ -52,6 +52,9 @@ int nbci_ctc(const float* preds, const int64_t* targets, const int32_t* in_lens,
     return nbci::ctc_launch(preds, targets, in_lens, tgt_lens, B, Tp, V, S, blank, zero_infinity, loss, alpha_ws, dlogits, d_dtype,
                             ldd, grad_scale, (hipStream_t)stream);
 }
+int nbci_step_stats(double* stats, const float* loss, int32_t B, double n_examples, const int32_t* errors, nbci_stream_t stream) {
+    return nbci::step_stats_launch(stats, loss, B, n_examples, errors, (hipStream_t)stream);
+}
 int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int32_t B, int32_t Tp, int32_t S, int32_t blank,
              int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, nbci_stream_t stream) {
     return nbci::per_launch(argmax, targets, tgt_lens, B, Tp, S, blank, decoded, dec_lens, errors, scratch, (hipStream_t)stream);

@@ -936,6 +936,37 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
     return check_launch("per");
 }
 
+// Running statistics of the train loop, one launch per step instead of ~9 tiny framework kernels:
+// stats[0] += sum(loss), stats[1] += n_examples, and (PER on) stats[2] += sum(err[:,0]) / sum(err[:,1]), stats[3] += 1
+// — the reference's per-step bookkeeping (trainer.py:353-362: loss sum, example count, per-batch metric ratio).
+__global__ __launch_bounds__(64) void step_stats_kernel(double* __restrict__ stats, const float* __restrict__ loss, int B, double n_examples,
+                                                        const int32_t* __restrict__ err) {
+    const int lane = threadIdx.x;
+    double ls = 0.0;
+    long long e0 = 0, e1 = 0;
+    for (int i = lane; i < B; i += 64) {
+        ls += (double)loss[i];
+        if (err) { e0 += err[2 * i]; e1 += err[2 * i + 1]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ls += __shfl_xor(ls, o, 64);
+        e0 += __shfl_xor(e0, o, 64);
+        e1 += __shfl_xor(e1, o, 64);
+    }
+    if (lane == 0) {
+        stats[0] += ls;
+        stats[1] += n_examples;
+        if (err) { stats[2] += (double)e0 / (double)e1; stats[3] += 1.0; }
+    }
+}
+
+int step_stats_launch(double* stats, const float* loss, int B, double n_examples, const int32_t* err, hipStream_t s) {
+    NBCI_REQUIRE(stats && loss && B > 0, NBCI_EINVAL, "step_stats: null argument");
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(64), 0, s, stats, loss, B, n_examples, err);
+    return check_launch("step_stats");
+}
+
 // ------------------------------------------------------------------------------------------
 // BCI coupler splice (models/bci.py:143-166)
 // ------------------------------------------------------------------------------------------

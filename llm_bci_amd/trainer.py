@@ -78,6 +78,10 @@ class NativeTrainer:
         dec, dl, err, scr = self._per_bufs
         check(lib().nbci_per(_ptr(am), _ptr(tg), _ptr(tl), B, Tp, S, self.blank_id, _ptr(dec), _ptr(dl), _ptr(err), _ptr(scr),
                              _stream()), "nbci_per")
+        return err
+
+    @staticmethod
+    def _per_ratio(err):
         e = err.sum(0).double()
         return e[0] / e[1]
 
@@ -98,12 +102,20 @@ class NativeTrainer:
             m._run_backward(self.grads, seg, seg)
             if sync:
                 self.reducer.segment_done(self.grads, seg)
-        # bookkeeping while the last buckets are in flight
-        self.stats[0] += loss_vec.sum().double()
-        self.stats[1] += self._n_examples(loss_vec)
+        # bookkeeping while the last buckets are in flight: one small launch (loss sum, example count, batch PER ratio)
+        err = None
         if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
-            self.stats[2] += self._per(batch)
-            self.stats[3] += 1
+            err = self._per(batch)
+        n = getattr(m, "last_n_examples", None)
+        if n is None and loss_vec.dtype == torch.float32 and loss_vec.is_contiguous():
+            check(lib().nbci_step_stats(_ptr(self.stats), _ptr(loss_vec), loss_vec.numel(), float(loss_vec.numel()),
+                                        _ptr(err) if err is not None else None, _stream()), "nbci_step_stats")
+        else:
+            self.stats[0] += loss_vec.sum().double()
+            self.stats[1] += self._n_examples(loss_vec)
+            if err is not None:
+                self.stats[2] += self._per_ratio(err)
+                self.stats[3] += 1
         if sync:
             self.reducer.finish(self.grads)
             lr, beta1 = self.sched.at(self.opt_step)
@@ -145,7 +157,7 @@ class NativeTrainer:
             acc[0] += loss_vec.sum().double()
             acc[1] += self._n_examples(loss_vec)
             if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
-                acc[2] += self._per(batch)
+                acc[2] += self._per_ratio(self._per(batch))
                 acc[3] += 1
         m.train(was_training)
         s = reduce_stats(acc, self.group).cpu()
