@@ -26,9 +26,10 @@ int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* len
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean,
                          float* rstd, int M, int H, hipStream_t s, float* y32 = nullptr);  // y32: optional f32 copy of y
 // backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
-int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+// dy: f32, or (dy_bf16) bf16 as a bf16 data-gradient GEMM wrote it
+int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s,
-                         RepCfg rc = RepCfg{0, 1}, LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr});
+                         RepCfg rc = RepCfg{0, 1}, LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}, int dy_bf16 = 0);
 
 // masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437; tmask NULL = all valid),
 // writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP

@@ -216,8 +216,8 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
 constexpr int LNB_ITERS = 2;             // passes per block (the column partial sums stay in registers across them)
 constexpr int LNB_ROWS = 8 * LNB_ITERS;  // rows per block: 2 per wave and pass, both rows' loads in flight together
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NV, typename DY>   // DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
@@ -243,7 +243,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             const int c = (k * 64 + lane) * 4;
             const bool ok = r < M && c < H;
             xv[j][k] = ok ? *(const float4*)(x + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dv[j][k] = ok ? *(const float4*)(dy + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (sizeof(DY) == 4) {
+                dv[j][k] = ok ? *(const float4*)((const float*)dy + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                bf16x4 t = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (ok) t = *(const bf16x4*)((const bf16_t*)dy + (long long)r * H + c);
+                dv[j][k] = make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3]));
+            }
             od[j][k] = (ok && accumulate) ? *(const float4*)(dx + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -306,17 +312,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-int layernorm_bwd_launch(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz) {
+int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz, int dy_bf16) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
     const int nv = (H + 255) / 256;
     dim3 g((M + LNB_ROWS - 1) / LNB_ROWS);
-#define LNB(NVV)                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel<NVV>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, dy, x, w, mean, \
+#define LNB(NVV, DYT)                                                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, x, w, mean, \
                        rstd, dx, dw, db, M, H, accumulate_dx, rc, cz)
-    if (nv <= 1) LNB(1);
-    else if (nv <= 4) LNB(4);
-    else LNB(8);
+    if (dy_bf16) {
+        if (nv <= 1) LNB(1, bf16_t);
+        else if (nv <= 4) LNB(4, bf16_t);
+        else LNB(8, bf16_t);
+    } else {
+        if (nv <= 1) LNB(1, float);
+        else if (nv <= 4) LNB(4, float);
+        else LNB(8, float);
+    }
 #undef LNB
     return check_launch("layernorm_bwd");
 }

@@ -387,7 +387,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
         if (seg == c.n_layers + 1) {
             // ---- head: decoder Linear + out_norm (or an external gradient of the encoder output)
-            const float* d_xo = dtmp;
+            const void* d_xo = dtmp;   // (bf16 in bf16 mode: written by the decoder data-gradient GEMM)
             if (io->d_hidden) {
                 d_xo = io->d_hidden;
             } else {
@@ -395,12 +395,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
                 TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
                 {
-                    nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, NBCI_F32);
+                    nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, dt);
                     TRY(gemm_launch_timed(d, s));
                 }
             }
             TRY(layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
-                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1)));
+                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1),
+                                     (!io->d_hidden && dt == NBCI_BF16) ? 1 : 0));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
@@ -423,13 +424,14 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             TRY(wq.push(I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
             {
-                nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, NBCI_F32);
+                nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
                                      (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
                                      dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
-                                                    : LnCast{ws + w.dA2, 1, 0u, 1.f, 0u, RG(lo.ob)}));
+                                                    : LnCast{ws + w.dA2, 1, 0u, 1.f, 0u, RG(lo.ob)},
+                                     dt == NBCI_BF16 ? 1 : 0));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
             if (dt == NBCI_F32) {
@@ -489,12 +491,12 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
             TRY(wq.flush());   // all four operand pairs exist now; the LayerNorm backward below overwrites dA
             {
-                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H,
-                                      NBCI_F32);
+                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
-                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1)));
+                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1),
+                                     dt == NBCI_BF16 ? 1 : 0));
         } else {
             // ---- embedder backward (ndt1.py:160-203)
             const int KS = c.stack_size * D;
