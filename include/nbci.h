@@ -101,12 +101,15 @@ typedef struct nbci_gemm_desc {
     int32_t residual_first;       /* 1: residual is added BEFORE act/dropout */
     const void* gate;             /* optional [M][ldg] in in_dtype: result *= act'(gate) (GELU/softsign backward) */
     int64_t ldg;
-    int32_t gate_act;             /* < 0: gate already holds act' (see c2_grad): plain multiply */
+    int32_t gate_act;             /* < 0: gate already holds act' (see c2_grad): plain multiply; 0..63: NBCI_ACT_* of
+                                     the PRE-activation stored in gate; 64 + act: gate holds the activation's OUTPUT
+                                     (softsign / relu / tanh derivative from the output) */
     int32_t c2_grad;              /* 1: C2 receives act'(pre-activation) instead of the pre-activation */
     float* colsum;                /* optional f32 [N]: colsum[n] += sum_m C[m][n] of the STORED values (bias
                                      gradient fused into the GEMM that produces the activation gradient) */
     int64_t colsum_rep_stride;    /* colsum replicas (to spread same-address atomics): replica r at colsum + r*stride */
     int32_t colsum_nrep;          /* 0/1 = no replication */
+    int32_t gate_follows_c;       /* 1: batched GEMM whose gate has C's layout: the batch offset (czs1/czs2) applies to it too */
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);

@@ -42,7 +42,8 @@ class GemmDesc(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32), ("c2_grad", C.c_int32),
-                ("colsum", C.c_void_p), ("colsum_rep_stride", C.c_int64), ("colsum_nrep", C.c_int32)]
+                ("colsum", C.c_void_p), ("colsum_rep_stride", C.c_int64), ("colsum_nrep", C.c_int32),
+                ("gate_follows_c", C.c_int32)]
 
 
 class NDT1Config(C.Structure):

@@ -194,7 +194,7 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     k.tile_row = 0;
     k.residual = d.residual; k.ldr = d.ldr;
     k.residual_rows = (const long long*)d.residual_rows; k.residual_first = d.residual_first;
-    k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16;
+    k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16; k.gate_coff = d.gate_follows_c ? 1 : 0;
     k.c2_grad = d.c2_grad;
     // vector epilogue: 4 consecutive n at 16-byte (f32) / 8-byte (bf16) alignment
     bool cvec = (d.ldc % 4 == 0) && (d.czs1 % 4 == 0) && (d.czs2 % 4 == 0) && (((uintptr_t)d.C) % 16 == 0);

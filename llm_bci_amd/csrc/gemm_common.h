@@ -69,6 +69,7 @@ struct GemmK {
     int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
     const void* gate; long long ldg; int gate_act;  // v *= act'(gate[m][n]) (gate in the input dtype)
     int gate_bf16;
+    int gate_coff;   // the batch offset of C applies to the gate too (gate has C's layout)
     int c2_grad;   // C2 receives act'(pre-activation) instead of the pre-activation
     int cvec;  // vector C/residual accesses legal
     int dbg;   // NBCI_GEMM_DBG ablation bits (measurement only): 1 = epilogue computes but does not store, 2 = no K loop (both outside the K loop: a flag tested inside it slows the loop itself)
@@ -266,16 +267,21 @@ _Pragma("unroll")
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
     }
-    if (d.gate && full && d.gate_bf16 && d.gate_act < 0 && (d.ldg & 3) == 0) {   // the train step's case: one 8-byte load
-        const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (long long)m * d.ldg + n);
-        v[0] *= bf2f(g4[0]); v[1] *= bf2f(g4[1]); v[2] *= bf2f(g4[2]); v[3] *= bf2f(g4[3]);
+    if (d.gate && full && d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64)) {   // the train step's cases: one 8-byte load
+        const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n);
+        if (d.gate_act < 0) { v[0] *= bf2f(g4[0]); v[1] *= bf2f(g4[1]); v[2] *= bf2f(g4[2]); v[3] *= bf2f(g4[3]); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_bwd_from_output(d.gate_act - 64, bf2f(g4[e]));
+        }
     } else if (d.gate) {
-        const long long gi = (long long)m * d.ldg + n;
+        const long long gi = (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (n + e < d.N) {
                 const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
-                v[e] *= (d.gate_act < 0) ? gv : act_bwd(d.gate_act, gv);   // gate_act < 0: gate already holds act'
+                // gate_act < 0: gate already holds act'; >= 64: gate holds the activation's output
+                v[e] *= (d.gate_act < 0) ? gv : (d.gate_act >= 64 ? act_bwd_from_output(d.gate_act - 64, gv) : act_bwd(d.gate_act, gv));
             }
         }
     }
@@ -406,9 +412,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
 // rows: lane owns n = 4 * (t & 31) .. + 3 of row t / 32 (+ nthreads / 32 per pass): 512 B (f32) / 256 B (bf16)
 // contiguous per row for C, C2, the residual and the gate. The per-element work is epi_apply(), unchanged.
 constexpr int EPI_LD = 132;   // floats per LDS row: 16 B of padding spreads the 16 rows of a fragment over all banks
-template <int MI, int NI>
+// CH > 1: the tile goes through LDS in CH row chunks (tall tiles whose f32 image would not leave room for two
+// workgroups per CU); needs every wave to span all rows (mw_l = 0) and MI % CH == 0.
+template <int MI, int NI, int CH = 1>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[MI][NI], int mw_l, int nw_l, int m0, int n0, int bm,
                                                    long long coff, int t, int nthreads, char* smem) {
+    static_assert(MI % CH == 0, "row chunks must split the wave's row blocks evenly");
+    constexpr int MC = MI / CH;
     const int lane = t & 63, i16 = lane & 15, g = lane >> 4;
     float* tile = (float*)smem;
     if (d.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
@@ -420,24 +430,29 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[
         if (s == 1.2345e-30f) ((float*)d.C)[0] = s;
         return;
     }
-    __syncthreads();   // every wave has left the K loop: the staging buffers are dead
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-            *(float4*)(tile + (mw_l + mi * 16 + i16) * EPI_LD + nw_l + ni * 16 + 4 * g) =
-                make_float4(acc[mi][ni][0] * d.alpha, acc[mi][ni][1] * d.alpha, acc[mi][ni][2] * d.alpha, acc[mi][ni][3] * d.alpha);
-    __syncthreads();
     const int c4 = 4 * (t & 31), n = n0 + c4;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < d.N) {
-        const int rstep = nthreads >> 5;
-        for (int r = t >> 5; r < bm; r += rstep) {
-            const int m = m0 + r;
-            if (m >= d.M) break;
-            const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
-            float v[4] = {a.x, a.y, a.z, a.w};
-            epi_apply(d, v, m, n, coff, csum);
+    const int rows = bm / CH;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        __syncthreads();   // every wave has left the K loop (the previous chunk): the LDS tile is free
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                *(float4*)(tile + (mw_l + mi * 16 + i16) * EPI_LD + nw_l + ni * 16 + 4 * g) =
+                    make_float4(acc[ch * MC + mi][ni][0] * d.alpha, acc[ch * MC + mi][ni][1] * d.alpha, acc[ch * MC + mi][ni][2] * d.alpha,
+                                acc[ch * MC + mi][ni][3] * d.alpha);
+        __syncthreads();
+        if (n < d.N) {
+            const int rstep = nthreads >> 5;
+            for (int r = t >> 5; r < rows; r += rstep) {
+                const int m = m0 + ch * rows + r;
+                if (m >= d.M) break;
+                const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
+                float v[4] = {a.x, a.y, a.z, a.w};
+                epi_apply(d, v, m, n, coff, csum);
+            }
         }
     }
     if (d.colsum) {   // bias gradient: the two half-waves hold the same columns; one atomic per column per wave

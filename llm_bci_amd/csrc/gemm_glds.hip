@@ -91,8 +91,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     glds_setup<BKM, NPB>(gb, B, n0, d.N, w, lane);
 
     if constexpr (VIEW) {
-        static_assert(!AK && !BKM, "view kernels exist for the weight-gradient layout");
-        glds_view_seek<NPA, 4>(ga, A, kt_begin);
+        static_assert(!BKM, "view kernels: B is row-major-in-k (A too in the weight-gradient layout)");
+        if constexpr (!AK) glds_view_seek<NPA, 4>(ga, A, kt_begin);
         glds_view_seek<NPB, 4>(gb, B, kt_begin);
     }
     int cur = 0;
@@ -135,7 +135,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
             return;
         }
     }
-    gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, GEMM_THREADS, smem);
+    constexpr int CH = (WM == 1 && MI == 10) ? 2 : 1;   // 160-row tiles: two 80-row chunks (42 KB) keep two workgroups per CU
+    gemm_epilogue_tile<MI, NI, CH>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, GEMM_THREADS, smem);
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
@@ -281,13 +282,13 @@ bool glds_view(const nbci_gemm_desc& d) { return (!d.A.kmajor && d.A.rpb > 0) ||
 bool glds_eligible(const nbci_gemm_desc& d, const GemmK& k) {
     (void)k;
     if (d.in_dtype != NBCI_BF16 || d.K < 64) return false;
-    if (glds_view(d) && (d.A.kmajor || d.B.kmajor)) return false;   // the view loop exists for the weight-gradient layout only
+    if (glds_view(d) && d.B.kmajor) return false;   // the view loops exist for a row-major-in-k B (A: either layout)
     return glds_operand_ok(d.A, d.M) && glds_operand_ok(d.B, d.N);
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
-    constexpr int stage2 = 2 * (WM * MI * 16 * 128 + 16384), epi = WM * MI * 16 * EPI_LD * 4;   // K-loop stages / epilogue tile
+    constexpr int stage2 = 2 * (WM * MI * 16 * 128 + 16384), epi = WM * MI * 16 * EPI_LD * 4 / ((WM == 1 && MI == 10) ? 2 : 1);   // K-loop stages / epilogue tile (chunk)
     constexpr int lds = stage2 > epi ? stage2 : epi;
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
@@ -363,7 +364,7 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         const int cands[3] = {128, 144, 288};  // (160 / 192 rows spill accumulators to scratch with hipcc 7.2: not offered)
         static const bool g3_off = [] { const char* e = getenv("NBCI_GEMM3"); return !(e && e[0] == '1'); }();  // opt-in: measured no faster than the 2-stage kernel
         for (int c : cands) {
-            if (c == 288 && (g3_off || d.K < 192)) continue;
+            if (c == 288 && (g3_off || d.K < 192 || glds_view(d))) continue;
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
             if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
             const double cost = c == 288 ? (double)((tiles + 255) / 256) * c / 2.0 / 1.5 : (double)((tiles + 511) / 512) * c;
@@ -373,7 +374,20 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     k.tiles_m = (d.M + bm - 1) / bm;
     dim3 grid(k.tiles_m * k.tiles_n * (splitk > 1 ? splitk : 1), splitk > 1 ? 1 : batch);
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
-    if (glds_view(d)) return launch_glds<false, false, 2, 2, 4, 4, true>(k, grid, stream);   // (eligibility: both row-major-in-k)
+    if (glds_view(d)) {   // (eligibility: B row-major-in-k)
+        if (!ak) return launch_glds<false, false, 2, 2, 4, 4, true>(k, grid, stream);
+        // k-major A: 160-row tiles as well (the embedder's phase GEMM has M = B * T/stride = 9600 rows: 60 x 8 = 480 tiles, one round,
+        // where 128- / 144-row tiles need a second, mostly empty one)
+        if (d.K % 64 == 0 && splitk == 1) {
+            const long t160 = (long)((d.M + 159) / 160) * k.tiles_n * batch;
+            const double c160 = (double)((t160 + 511) / 512) * 160, ccur = (double)(((long)grid.x * grid.y + 511) / 512) * bm;
+            if (c160 < ccur) {
+                k.tiles_m = (d.M + 159) / 160;
+                return launch_glds<true, false, 1, 4, 10, 2, true>(k, dim3(k.tiles_m * k.tiles_n, batch), stream);
+            }
+        }
+        return bm == 144 ? launch_glds<true, false, 1, 4, 9, 2, true>(k, grid, stream) : launch_glds<true, false, 2, 2, 4, 4, true>(k, grid, stream);
+    }
     // small grids (at most one workgroup per CU): nothing else hides the per-tile load latency -> 4-stage pipeline
     static const bool ms_off = [] { const char* e = getenv("NBCI_GEMM_MS"); return e && e[0] == '0'; }();
     // very small grids (<= half the CUs at 128-row tiles): 64-row tiles double the workgroup count; 5 stages of 24 KB

@@ -282,11 +282,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
                                              od[j][k].z + rs[j] * (dh[k].z - s1 - xh[k].z * s2), od[j][k].w + rs[j] * (dh[k].w - s1 - xh[k].w * s2));
                 *(float4*)(dx + (long long)r * H + c) = o;
                 if (cz.out) {  // fused "dropcast" of the updated gradient stream for the next GEMMs (+ bias-grad sums)
-                    const long long i = (long long)r * H + c;
+                    const long long i = (long long)r * H + c;   // dropout stream index: the unpadded position
                     float v[4] = {o.x, o.y, o.z, o.w};
                     if (cz.thr) drop4(cz.key, cz.thr, (unsigned)i, cz.scale, v);
-                    if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + i) = ov; }
-                    else *(float4*)((float*)cz.out + i) = make_float4(v[0], v[1], v[2], v[3]);
+                    // optional row remap: groups of rpg rows land gpitch rows apart, goff rows in (zero-padded sample blocks)
+                    const long long io = cz.rpg > 0 ? ((long long)(r / cz.rpg) * cz.gpitch + cz.goff + r % cz.rpg) * H + c : i;
+                    if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + io) = ov; }
+                    else *(float4*)((float*)cz.out + io) = make_float4(v[0], v[1], v[2], v[3]);
                     gc[k].x += v[0]; gc[k].y += v[1]; gc[k].z += v[2]; gc[k].w += v[3];
                 }
             }
@@ -587,15 +589,6 @@ int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float*
 // ------------------------------------------------------------------------------------------
 // stack backward: col2im over the overlapping windows fused with the embed activation gradient
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float act_bwd_from_output(int act, float y) {
-    switch (act) {
-        case ACT_SOFTSIGN: { const float d = 1.0f - fabsf(y); return d * d; }  // y = x/(1+|x|) => 1/(1+|x|) = 1-|y|
-        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case ACT_TANH: return 1.f - y * y;
-        default: return 1.f;
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_actgrad_kernel(const T* __restrict__ dwin, const T* __restrict__ y,
                                                              T* __restrict__ dpre, int B, int Tt, int Tp, int D, int size,

@@ -104,7 +104,7 @@ __device__ __forceinline__ float* rep_ptr(float* p, RepCfg rc, unsigned blk) {
 
 // optional fused tail of the LayerNorm backward: out = dropout(dx_new) in the GEMM operand dtype,
 // colsum += column sums of out (the bias gradient of the Linear that produced the residual branch)
-struct LnCast { void* out; int bf16; unsigned thr; float scale; uint32_t key; float* colsum; };
+struct LnCast { void* out; int bf16; unsigned thr; float scale; uint32_t key; float* colsum; int rpg, gpitch, goff; };   // rpg > 0: output row remap (kernels.hip ln_bwd)
 
 // ---- wave64 reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -170,6 +170,16 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
         default: return 1.0f;
+    }
+}
+
+// derivative wrt the pre-activation, from the activation's OUTPUT y (activations whose derivative is a function of y)
+__device__ __forceinline__ float act_bwd_from_output(int act, float y) {
+    switch (act) {
+        case ACT_SOFTSIGN: { const float d = 1.0f - fabsf(y); return d * d; }  // y = x/(1+|x|) => 1/(1+|x|) = 1-|y|
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
     }
 }
 

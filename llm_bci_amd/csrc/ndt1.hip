@@ -129,6 +129,8 @@ struct WS {
     size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
     size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
+    size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
+    int phase_ok, Q, P, npad;          // Q = T / stride output groups, P = Q + size/stride - 1 padded rows, npad = size/stride - 1
     size_t bytes;
     int Tp, M, ldS, ldP, vpad;
 };
@@ -183,7 +185,13 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.dB2 = bump(cur, M * H * es);
     w.dqkv = bump(cur, M * 3 * H * es);
     w.dS = bump(cur, nP * es);
-    w.dwin = bump(cur, M * (size_t)c.stack_size * D * es);
+    // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
+    w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
+                  (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0) ? 1 : 0;
+    { static const bool off = [] { const char* e = getenv("NBCI_PHASE_DGRAD"); return e && e[0] == '0'; }(); if (off) w.phase_ok = 0; }
+    w.Q = T / c.stack_stride; w.npad = c.stack_size / c.stack_stride - 1; w.P = w.Q + w.npad;
+    w.dAp = w.phase_ok ? bump(cur, (size_t)B * w.P * H * es) : 0;
+    w.dwin = w.phase_ok ? 0 : bump(cur, M * (size_t)c.stack_size * D * es);
     w.dpre = bump(cur, (size_t)B * T * D * es);
     w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
     w.bytes = (cur + 255) / 256 * 256;
@@ -380,8 +388,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
         if (!need_cast) return LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr};
         const float pp = layer_below >= 0 ? p_lay : p_emb;
         const uint32_t site = layer_below >= 0 ? 18 + 4 * layer_below : 3;
+        if (layer_below < 0 && w.phase_ok)   // the embedder's phase GEMMs read zero-padded sample blocks
+            return LnCast{ws + w.dAp, 1, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site), RG(p.stkb),
+                          Tp, w.P, w.npad};
         return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
-                      RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb)};
+                      RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb), 0, 0, 0};
     };
 
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
@@ -399,6 +410,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                     TRY(gemm_launch_timed(d, s));
                 }
             }
+            if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
             TRY(layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
                                      (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1),
                                      (!io->d_hidden && dt == NBCI_BF16) ? 1 : 0));
@@ -494,6 +506,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
+            if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
                                      (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1),
                                      dt == NBCI_BF16 ? 1 : 0));
@@ -508,6 +521,23 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 dx0 = ws + w.dA;
             }
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
+            if (w.phase_ok) {
+                // dx0 sits in zero-padded sample blocks (B, P, H): token j of sample b at row b*P + npad + j.
+                const int st = c.stack_stride, nwin = c.stack_size / st;
+                TRY(wgrad(s, dt, H, KS, M, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tp, (int64_t)w.P * H),
+                          op(ws + w.y, es, 0, (int64_t)st * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
+                // d pre-activation WITHOUT the (M, size*D) window-gradient tensor and its col2im pass. The st bins t = st*q + ph of
+                // group q collect  sum_{i < nwin} dx0[q - i] . W_s[:, D*(st*i + ph) .. + D]; with n = D*ph + c and i' = nwin-1-i that
+                // is ONE GEMM: rows (b, q), N = st*D, a contraction over k = (i', h) of the nwin consecutive padded rows q .. q+nwin-1
+                // (an overlapping-row view, K = nwin*H contiguous) against the weight slices taken in reverse order (a row-major-in-k
+                // view with a negative group stride). Output row (b, q) IS bins st*q .. st*q+st-1 of d pre-activation; the
+                // activation gradient (from the stored output y, same layout) is the gate.
+                nbci_gemm_desc d = gd(B * w.Q, st * D, nwin * H, dt, op(ws + w.dAp, es, 0, H, 1, w.Q, (int64_t)w.P * H),
+                                      op(x.W(p.stkw), es, (int64_t)D * st * (nwin - 1), KS, 0, H, -(int64_t)D * st), ws + w.dpre,
+                                      (int64_t)st * D, dt);
+                d.gate = ws + w.y; d.ldg = (int64_t)st * D; d.gate_act = 64 + c.embed_act;
+                TRY(gemm_launch_timed(d, s));
+            } else {
             TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
                       op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
             {   // dwin = dx0 W_s  (M, S*D)
@@ -516,6 +546,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
                                       c.embed_act, s));
+            }
             TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, RG(p.embb), s, rc));
             TRY(wgrad(s, dt, D, c.n_channels, B * T, op(ws + w.dpre, es, 0, D, 0), op(ws + w.xs, es, 0, c.n_channels, 0),
                       grads + p.embw, c.n_channels));
