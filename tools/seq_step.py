@@ -6,7 +6,8 @@ import sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "per_kernel" in r["Kernel_Name"]]
-step = rows[idx[-2] + 1: idx[-1] + 1]
+mid = len(idx) // 2   # a step from the middle of the run (the last ones may belong to bench.py's event-instrumented pass)
+step = rows[idx[mid - 1] + 1: idx[mid] + 1]
 t0 = int(step[0]["Start_Timestamp"])
 for r in step:
     nm = r["Kernel_Name"].replace("nbci::", "").replace("void ", "").split("(")[0][:60]
