@@ -286,3 +286,42 @@ def test_multistage_small_grid_kernel_exact(ak, bk, shape):
                  in_dtype=ops.NBCI_BF16, c_dtype=ops.NBCI_F32)
         torch.cuda.synchronize()
         assert torch.equal(out.double().cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 21, 64, 16), (64, 143, 1024, 256)])   # (B, T', H, D): small -> 128-row tiles, real -> 160-row tiles
+def test_phase_gemm_views_match_col2im(shape):
+    """The embedder backward as ONE GEMM: overlapping-row k-major view of zero-padded sample blocks
+    x reversed weight slices (row-major-in-k view with a NEGATIVE group stride), gate = softsign' from the stored
+    OUTPUT. Exact integer data vs the explicit window gradient + col2im it replaces (reference ndt1.py:138-140,180)."""
+    ops = _ops()
+    import ctypes as C
+    from llm_bci_amd._lib import GemmDesc, check, lib
+    B, Tp, H, D = shape
+    st, nwin = 4, 8
+    size = st * nwin
+    T = st * (Tp - 1) + size
+    Q, npad = T // st, nwin - 1
+    P = Q + npad
+    dx0 = _ints((B, Tp, H), lo=-3, hi=4, seed=51).to(DEV)
+    W = _ints((H, size * D), lo=-2, hi=3, seed=52).to(DEV)
+    y = (_ints((B, T, D), lo=-7, hi=8, seed=53) / 8.0).to(DEV)          # activation outputs in (-1, 1), exact in bf16
+    # reference: dwin = dx0 W, fold the windows back onto the bins, times (1 - |y|)^2
+    dwin = (dx0.reshape(B * Tp, H) @ W).reshape(B, Tp, size * D)
+    dpre = torch.zeros(B, T, D, device=DEV)
+    for r in range(size):
+        dpre[:, r: r + st * Tp: st, :] += dwin[:, :, r * D:(r + 1) * D]
+    ref = dpre * (1.0 - y.abs()) ** 2
+    pad = torch.zeros(B, P, H, device=DEV, dtype=torch.bfloat16)
+    pad[:, npad:npad + Tp] = dx0.bfloat16()
+    Wb, yb = W.bfloat16().contiguous(), y.bfloat16().contiguous()
+    out = torch.full((B * Q, st * D), -7.0, device=DEV)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.in_dtype = B * Q, st * D, nwin * H, ops.NBCI_BF16
+    d.A = ops.operand(pad, H, True, rpb=Q, gstride=P * H)
+    d.B = ops.operand(Wb, size * D, False, rpb=H, gstride=-D * st, offset=D * st * (nwin - 1))
+    d.C, d.ldc, d.c_dtype, d.batch, d.zdiv, d.splitk, d.alpha, d.beta = out.data_ptr(), st * D, ops.NBCI_F32, 1, 1, 1, 1.0, 0.0
+    d.gate, d.ldg, d.gate_act = yb.data_ptr(), st * D, 64 + 1   # 64 + NBCI_ACT_SOFTSIGN: derivative from the output
+    for _ in range(2):
+        check(lib().nbci_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "phase gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(B, T, D).double().cpu(), ref.double().cpu())
