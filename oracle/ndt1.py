@@ -25,6 +25,7 @@ DEFAULTS = dict(  # configs/ndt1.yaml defaults, flattened
     constant_offset_sd=0.2, embed_act="softsign", mlp_act="gelu", embed_dropout=0.2, dropout=0.4,
     use_rope=False, rope_theta=10000.0, context_forward=-2, context_backward=-2, pos=True,
     blank_id=0, zero_infinity=True,
+    factors_size=0, factors_act="relu", factors_bias=True,   # NeuralFactorsProjection (ndt1.py:348-373); size 0 = inactive (identity)
 )
 
 
@@ -102,6 +103,8 @@ def act_fwd(name, x):
         return (0.5 * x * (1 + _erf(x / np.sqrt(2.0)))).astype(x.dtype)
     if name == "relu":
         return np.maximum(x, 0)
+    if name == "tanh":
+        return np.tanh(x)
     if name in ("identity", None):
         return x
     raise ValueError(name)
@@ -116,6 +119,8 @@ def act_bwd(name, x):
         return (cdf + x * pdf).astype(x.dtype)
     if name == "relu":
         return (x > 0).astype(x.dtype)
+    if name == "tanh":
+        return (1 - np.tanh(x) ** 2).astype(x.dtype)
     if name in ("identity", None):
         return np.ones_like(x)
     raise ValueError(name)
@@ -165,7 +170,13 @@ def init_params(cfg, seed=0, dtype=np.float32):
         w, b = lin(I, H); p[pre + "mlp.up_proj.weight"], p[pre + "mlp.up_proj.bias"] = (w * dtype(fix)).astype(dtype), b
         w, b = lin(H, I); p[pre + "mlp.down_proj.weight"], p[pre + "mlp.down_proj.bias"] = (w * dtype(fix)).astype(dtype), b
     p["encoder.out_norm.weight"] = np.ones(H, dtype); p["encoder.out_norm.bias"] = np.zeros(H, dtype)
-    p["decoder.0.weight"], p["decoder.0.bias"] = lin(V, H)
+    Fs = cfg.get("factors_size", 0)
+    if Fs:
+        w, b = lin(Fs, H)
+        p["encoder.out_proj.proj.0.weight"] = w
+        if cfg.get("factors_bias", True):
+            p["encoder.out_proj.proj.0.bias"] = b
+    p["decoder.0.weight"], p["decoder.0.bias"] = lin(V, Fs if Fs else H)
     return p
 
 
@@ -263,11 +274,18 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
     c["x_last"] = x
     xo, c["xhat_o"], c["rstd_o"] = layer_norm(x, P["encoder.out_norm.weight"], P["encoder.out_norm.bias"])
     c["xo"] = xo
-    logits = xo @ P["decoder.0.weight"].T + P["decoder.0.bias"]
+    enc_out = xo
+    if cfg.get("factors_size", 0):   # out_proj = act(Linear(dropout_{p=0}(x))) (ndt1.py:362-365,372-373)
+        fu = xo @ P["encoder.out_proj.proj.0.weight"].T
+        if "encoder.out_proj.proj.0.bias" in P:
+            fu = fu + P["encoder.out_proj.proj.0.bias"]
+        enc_out = act_fwd(cfg["factors_act"], fu)
+        c["fu"], c["fo"] = fu, enc_out
+    logits = enc_out @ P["decoder.0.weight"].T + P["decoder.0.bias"]
     z = logits - logits.max(-1, keepdims=True)
     lp = z - np.log(np.exp(z).sum(-1, keepdims=True))
     out = {"preds": lp.astype(f), "logits": logits, "token_mask": tmask, "token_lens": tlens, "x_embed": layers[0]["x_in"] if L else x,
-           "layer_out": [lc["x_mid"] for lc in layers], "x_final": xo, "xs": xs, "y": y}
+           "layer_out": [lc["x_mid"] for lc in layers], "x_final": xo, "enc_out": enc_out, "xs": xs, "y": y}
     if "targets" in batch and batch["targets"] is not None:
         losses, dlogits = ctc_loss_and_grad(lp, batch["targets"], tlens, np.asarray(batch["targets_lengths"]).reshape(-1),
                                             blank=cfg["blank_id"], zero_infinity=cfg["zero_infinity"])
@@ -289,9 +307,17 @@ def backward(c, grad_scale=1.0):
     scale = f(1.0 / math.sqrt(hd))
     g = {}
     dlogits = c["dlogits"] * f(grad_scale)                          # (B,Tp,V)
-    g["decoder.0.weight"] = dlogits.reshape(-1, dlogits.shape[-1]).T @ c["xo"].reshape(-1, H)
+    Fs = cfg.get("factors_size", 0)
+    dec_in = c["fo"] if Fs else c["xo"]
+    g["decoder.0.weight"] = dlogits.reshape(-1, dlogits.shape[-1]).T @ dec_in.reshape(-1, dec_in.shape[-1])
     g["decoder.0.bias"] = dlogits.reshape(-1, dlogits.shape[-1]).sum(0)
     dxo = dlogits @ P["decoder.0.weight"]
+    if Fs:
+        dfu = dxo * act_bwd(cfg["factors_act"], c["fu"])
+        g["encoder.out_proj.proj.0.weight"] = dfu.reshape(-1, Fs).T @ c["xo"].reshape(-1, H)
+        if "encoder.out_proj.proj.0.bias" in P:
+            g["encoder.out_proj.proj.0.bias"] = dfu.reshape(-1, Fs).sum(0)
+        dxo = dfu @ P["encoder.out_proj.proj.0.weight"]
     dx, g["encoder.out_norm.weight"], g["encoder.out_norm.bias"] = layer_norm_bwd(dxo, c["xhat_o"], c["rstd_o"], P["encoder.out_norm.weight"])
     for l in range(L - 1, -1, -1):
         pre_ = f"encoder.layers.{l}."

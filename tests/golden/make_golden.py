@@ -113,6 +113,8 @@ def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2):
           enc.out_norm.register_forward_hook(hook("out_norm"))]
     for i, lyr in enumerate(enc.layers):
         hs.append(lyr.register_forward_hook(hook(f"layer{i}")))
+    if ov.get("encoder", {}).get("factors", {}).get("active", False):
+        hs.append(enc.out_proj.register_forward_hook(hook("out_proj")))
     # --- eval forward
     model.eval()
     with torch.no_grad():
@@ -129,6 +131,8 @@ def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2):
         lo = inter[f"layer{i}"].numpy()
         fx[f"layer{i}_out"] = lo if full else lo[:, :, ::37]
     fx["out_norm"] = inter["out_norm"].numpy() if full else inter["out_norm"].numpy()[:, :, ::37]
+    if "out_proj" in inter:   # factors projection active: the encoder output handed to the decoder (ndt1.py:372-373,450)
+        fx["factors"] = inter["out_proj"].numpy() if full else inter["out_proj"].numpy()[:, :, ::37]
     # argmax path + margins + decode + PER through the reference's own metric code
     path = out.preds.argmax(-1)
     top2 = out.preds.topk(2, -1).values
@@ -235,6 +239,14 @@ def misc_cases():
         fx[f"ctx_{f}_{b}"] = create_context_mask(f, b, 24).numpy()
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
+
+if __name__ == "__main__" and "--factors" in sys.argv:
+    # NeuralFactorsProjection active (ndt1.py:348-373): Linear(hidden -> size) + act between out_norm and the decoder
+    run_case("g_tiny_factors", tiny(factors={"active": True, "size": 24, "act": "relu", "bias": True}), [30, 22, 17], [5, 4, 2], 16,
+             vocab=11, full=True)
+    run_case("g_tiny_factors_fix", tiny(factors={"active": True, "size": 40, "act": "tanh", "bias": True, "fixup_init": True,
+                                                 "init_range": 0.1}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
+    sys.exit(0)
 
 if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst")):
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)

@@ -35,6 +35,9 @@ def cfg_from_json(js, vocab):
             kw[dst] = tr[src]
     if "forward" in ctx:
         kw["context_forward"], kw["context_backward"] = ctx["forward"], ctx["backward"]
+    fac = enc.get("factors", {})
+    if fac.get("active", False):
+        kw["factors_size"], kw["factors_act"], kw["factors_bias"] = fac["size"], fac.get("act", "relu"), fac.get("bias", True)
     return O.make_config(**kw)
 
 
@@ -42,7 +45,7 @@ def batch_of(fx):
     return {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix"])
 def test_tiny_forward_backward_adamw(name):
     fx = load(name)
     cfg = cfg_from_json(str(fx["config_json"]), 11)
@@ -57,6 +60,8 @@ def test_tiny_forward_backward_adamw(name):
         lo = cache["layers"][l + 1]["x_in"] if l + 1 < cfg["n_layers"] else cache["x_last"]
         np.testing.assert_allclose(lo, fx[f"layer{l}_out"], atol=5e-5)
     np.testing.assert_allclose(out["x_final"], fx["out_norm"], atol=5e-5)
+    if "factors" in fx.files:
+        np.testing.assert_allclose(out["enc_out"], fx["factors"], atol=5e-5)
     np.testing.assert_allclose(out["preds"], fx["eval_preds"], atol=1e-4)   # north_star: logits <= 1e-3
     np.testing.assert_allclose(out["loss"], fx["eval_loss"], rtol=1e-5)
     assert int(out["n_examples"]) == int(fx["n_examples"])
