@@ -244,6 +244,10 @@ typedef struct nbci_ndt1_config { /* configs/ndt1.yaml, flattened */
     int32_t pos;
     int32_t blank_id, zero_infinity;
     int32_t dtype;                   /* NBCI_F32: exact-f32 parity path; NBCI_BF16: bf16 MFMA, f32 accumulate */
+    /* NeuralFactorsProjection (models/ndt1.py:348-373, configs/ndt1.yaml factors.*): encoder output =
+     * act(Linear(hidden -> factors_size)(out_norm(x))) instead of out_norm(x); 0 = inactive (identity). The decoder then
+     * reads factors_size inputs, hidden_out / d_hidden are (B,T',factors_size). factors.dropout must be 0. */
+    int32_t factors_size, factors_act, factors_bias;
 } nbci_ndt1_config;
 
 typedef struct nbci_ndt1_io {
@@ -263,7 +267,7 @@ typedef struct nbci_ndt1_io {
     float* preds;                       /* out (B,T',V) f32 log-probs */
     float* loss;                        /* out (B) per-sample CTC loss (sum it for NDT1Output.loss) */
     int32_t* argmax;                    /* out (B,T') greedy path or NULL */
-    void* hidden_out;                   /* out (B,T',H) encoder output in cfg.dtype, or NULL */
+    void* hidden_out;                   /* out (B,T',H or factors_size) encoder output in cfg.dtype, or NULL */
     int32_t* token_mask_out;            /* out (B,T') stacked validity mask (ndt1.py:182-183), or NULL */
     const float* d_hidden;              /* backward: d loss / d hidden_out, f32 (B,T',H). When set, the head segment
                                            starts from it (encoder used as a feature extractor, models/bci.py:125)

@@ -52,7 +52,8 @@ class NDT1Config(C.Structure):
         ("smooth_sd", C.c_float), ("noise", C.c_int32), ("white_noise_sd", C.c_float), ("constant_offset_sd", C.c_float),
         ("embed_act", C.c_int32), ("mlp_act", C.c_int32), ("embed_dropout", C.c_float), ("dropout", C.c_float),
         ("use_rope", C.c_int32), ("rope_theta", C.c_float), ("context_forward", C.c_int32), ("context_backward", C.c_int32),
-        ("pos", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32), ("dtype", C.c_int32)]
+        ("pos", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32), ("dtype", C.c_int32),
+        ("factors_size", C.c_int32), ("factors_act", C.c_int32), ("factors_bias", C.c_int32)]
 
 
 class NDT1IO(C.Structure):

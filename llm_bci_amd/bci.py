@@ -44,7 +44,7 @@ class _EncodeFn(torch.autograd.Function):
         B, T, _ = batch["spikes"].shape
         Tp = model.tokens(T)
         dt = torch.bfloat16 if model.compute_dtype == NBCI_BF16 else torch.float32
-        hidden = torch.empty(B, Tp, model._ccfg.hidden, dtype=dt, device=batch["spikes"].device)
+        hidden = torch.empty(B, Tp, model._ccfg.factors_size or model._ccfg.hidden, dtype=dt, device=batch["spikes"].device)
         tmask = torch.empty(B, Tp, dtype=torch.int32, device=hidden.device)
         model._run_forward(batch, want_grad=True, hidden_out=hidden, token_mask_out=tmask)
         ctx.model = model
@@ -198,7 +198,9 @@ class BCI(nn.Module):
             config["projector"] = update_config(config.projector, pc)
         pj = DictConfig(config["projector"])
         self.stacking = pj.stacking
-        H = self.ndt1._ccfg.hidden
+        H = self.ndt1._ccfg.hidden   # the reference sizes the projector by transformer.hidden_size (bci.py:91,96) ...
+        if self.ndt1._ccfg.factors_size not in (0, H):   # ... so a factors projection of another width cannot feed it there either
+            raise ValueError("BCI: encoder.factors.size must equal transformer.hidden_size (the projector reads hidden_size inputs)")
         self.projector = Projector(H * self.stacking, pj.inter_size, llm.config.hidden_size, pj.bias, pj.act)
         if pt_path is not None:
             self.projector.load_state_dict(torch.load(os.path.join(pt_path, "projector.bin")))

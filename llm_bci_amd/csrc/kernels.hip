@@ -941,6 +941,20 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
     return check_launch("per");
 }
 
+// out = src * gate, f32 -> activation dtype: an external f32 gradient pushed back through a stored activation derivative
+template <typename T>
+__global__ __launch_bounds__(256) void gate_cast_kernel(const float* __restrict__ src, const T* __restrict__ gate, T* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) stf<T>(out, i, src[i] * ldf<T>(gate, i));
+}
+
+int gate_cast_launch(const float* src, const void* gate, void* out, int dtype, long long n, hipStream_t s) {
+    NBCI_REQUIRE(src && gate && out && n > 0, NBCI_EINVAL, "gate_cast: null argument");
+    DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((gate_cast_kernel<TT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src,
+                                                 (const TT*)gate, (TT*)out, n));
+    return check_launch("gate_cast");
+}
+
 // Running statistics of the train loop, one launch per step instead of ~9 tiny framework kernels:
 // stats[0] += sum(loss), stats[1] += n_examples, and (PER on) stats[2] += sum(err[:,0]) / sum(err[:,1]), stats[3] += 1
 // — the reference's per-step bookkeeping (trainer.py:353-362: loss sum, example count, per-batch metric ratio).

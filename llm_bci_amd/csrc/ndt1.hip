@@ -28,6 +28,7 @@ struct Plan {
     std::vector<PInfo> params;
     std::vector<LayerOff> L;
     int64_t embw, embb, stkw, stkb, pos, onw, onb, decw, decb;
+    int64_t facw = -1, facb = -1;   // factors projection (head segment), -1 = absent
     int64_t total;
     std::vector<std::pair<int64_t, int64_t>> seg;  // [begin,end) per segment
     float* d_taps;
@@ -94,7 +95,11 @@ static void build_layout(Plan& p) {
     const int hs = c.n_layers + 1;
     p.onw = add_param(p, cur, "encoder.out_norm.weight", H, 0, hs);
     p.onb = add_param(p, cur, "encoder.out_norm.bias", H, 0, hs);
-    p.decw = add_param(p, cur, "decoder.0.weight", c.vocab, H, hs);
+    if (c.factors_size > 0) {   // NeuralFactorsProjection.proj[0] (ndt1.py:362-365)
+        p.facw = add_param(p, cur, "encoder.out_proj.proj.0.weight", c.factors_size, H, hs);
+        if (c.factors_bias) p.facb = add_param(p, cur, "encoder.out_proj.proj.0.bias", c.factors_size, 0, hs);
+    }
+    p.decw = add_param(p, cur, "decoder.0.weight", c.vocab, c.factors_size > 0 ? c.factors_size : H, hs);
     p.decb = add_param(p, cur, "decoder.0.bias", c.vocab, 0, hs);
     cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
     p.seg.push_back({begin, cur});
@@ -127,6 +132,7 @@ struct WS {
     size_t xs, y, tmask, tts, tlens;
     std::vector<LayerWS> L;
     size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
+    size_t fo, fgate, dfo;             // factors projection: output, act'(pre-activation), gradient (M, factors_size)
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
     size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
     size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
@@ -172,6 +178,11 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.x_last = bump(cur, M * H * 4);
     w.mean_o = bump(cur, M * 4); w.rstd_o = bump(cur, M * 4);
     w.xo = bump(cur, M * H * es);
+    if (c.factors_size > 0) {
+        w.fo = bump(cur, M * (size_t)c.factors_size * es);
+        w.fgate = bump(cur, M * (size_t)c.factors_size * es);
+        w.dfo = bump(cur, M * (size_t)c.factors_size * es);
+    }
     w.logits = bump(cur, M * w.vpad * 4);
     w.alpha = bump(cur, ctc_alpha_floats(B, Tp, S > 0 ? S : 1) * 4);
     w.dlogits = bump(cur, M * w.vpad * es);
@@ -333,8 +344,18 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     // ---- out_norm + decoder + log-softmax (+ CTC) (ndt1.py:442,494-499,545,581)
     TRY(layernorm_fwd_launch((const float*)(ws + w.x_last), params + p.onw, params + p.onb, ws + w.xo, dt,
                              (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
+    const int FS = c.factors_size;
+    const void* enc_out = ws + w.xo;   // what the decoder (and a coupler) reads: out_norm(x), or its factors projection
+    const int Kd = FS > 0 ? FS : H;
+    if (FS > 0) {   // act(Linear(hidden -> factors)); act'(pre-activation) kept for the backward (ndt1.py:372-373)
+        nbci_gemm_desc d = gd(M, FS, H, dt, op(ws + w.xo, es, 0, H, 1), op(x.W(p.facw), es, 0, H, 1), ws + w.fo, FS, dt);
+        if (p.facb >= 0) d.bias = params + p.facb;
+        d.act = c.factors_act; d.C2 = ws + w.fgate; d.c2_grad = 1;
+        TRY(gemm_launch_timed(d, s));
+        enc_out = ws + w.fo;
+    }
     {
-        nbci_gemm_desc d = gd(M, c.vocab, H, dt, op(ws + w.xo, es, 0, H, 1), op(x.W(p.decw), es, 0, H, 1), ws + w.logits,
+        nbci_gemm_desc d = gd(M, c.vocab, Kd, dt, op(enc_out, es, 0, Kd, 1), op(x.W(p.decw), es, 0, Kd, 1), ws + w.logits,
                               w.vpad, NBCI_F32);
         d.bias = params + p.decb;
         TRY(gemm_launch_timed(d, s));
@@ -344,7 +365,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     if (io->token_mask_out)
         NBCI_CHECK_HIP(hipMemcpyAsync(io->token_mask_out, ws + w.tmask, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
     if (io->hidden_out)  // optional copy-out of the encoder output (B,T',H) for BCI-style couplers
-        NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, ws + w.xo, (size_t)M * H * es, hipMemcpyDeviceToDevice, s));
+        NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, enc_out, (size_t)M * Kd * es, hipMemcpyDeviceToDevice, s));
     if (io->targets) {
         NBCI_REQUIRE(io->targets_lengths && io->loss && S > 0, NBCI_EINVAL, "ndt1: targets need targets_lengths, loss and S > 0");
         TRY(ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tp, c.vocab, S, c.blank_id,
@@ -399,21 +420,37 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
         if (seg == c.n_layers + 1) {
             // ---- head: decoder Linear + out_norm (or an external gradient of the encoder output)
             const void* d_xo = dtmp;   // (bf16 in bf16 mode: written by the decoder data-gradient GEMM)
-            if (io->d_hidden) {
-                d_xo = io->d_hidden;
+            int d_xo_lp = (dt == NBCI_BF16) ? 1 : 0;
+            const int FS = c.factors_size, Kd = FS > 0 ? FS : H;
+            const void* enc_out = FS > 0 ? ws + w.fo : ws + w.xo;
+            if (io->d_hidden && FS == 0) {
+                d_xo = io->d_hidden; d_xo_lp = 0;
             } else {
-                const void* dl = ws + w.dlogits;
-                TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
-                TRY(wgrad(s, dt, V, H, M, op(dl, es, 0, w.vpad, 0), op(ws + w.xo, es, 0, H, 0), grads + p.decw, H));
-                {
-                    nbci_gemm_desc d = gd(M, H, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, H, 0), dtmp, H, dt);
+                if (!io->d_hidden) {   // decoder Linear: bias / weight gradients, then d(encoder output) = dlogits W_d
+                    const void* dl = ws + w.dlogits;
+                    TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
+                    TRY(wgrad(s, dt, V, Kd, M, op(dl, es, 0, w.vpad, 0), op(enc_out, es, 0, Kd, 0), grads + p.decw, Kd));
+                    nbci_gemm_desc d = gd(M, Kd, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, Kd, 0), FS > 0 ? (void*)(ws + w.dfo) : (void*)dtmp,
+                                          Kd, dt);
+                    if (FS > 0) {   // through the factors activation: * act'(pre-activation), + the factors bias gradient
+                        d.gate = ws + w.fgate; d.ldg = FS; d.gate_act = -1;
+                        if (p.facb >= 0) { d.colsum = RG(p.facb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n; }
+                    }
+                    TRY(gemm_launch_timed(d, s));
+                } else {               // external gradient of the factors output (coupler): same activation gate, as a cast
+                    TRY(gate_cast_launch(io->d_hidden, ws + w.fgate, ws + w.dfo, dt, (long long)M * FS, s));
+                    if (p.facb >= 0) TRY(colsum_launch(ws + w.dfo, dt, FS, M, FS, RG(p.facb), s, rc));
+                }
+                if (FS > 0) {
+                    TRY(wgrad(s, dt, FS, H, M, op(ws + w.dfo, es, 0, FS, 0), op(ws + w.xo, es, 0, H, 0), grads + p.facw, H));
+                    nbci_gemm_desc d = gd(M, H, FS, dt, op(ws + w.dfo, es, 0, FS, 1), op(x.W(p.facw), es, 0, H, 0), dtmp, H, dt);
                     TRY(gemm_launch_timed(d, s));
                 }
             }
             if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
             TRY(layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
                                      (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1),
-                                     (!io->d_hidden && dt == NBCI_BF16) ? 1 : 0));
+                                     d_xo_lp));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
@@ -574,6 +611,7 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
     NBCI_REQUIRE(c.n_channels > 0 && c.stack_size > 0 && c.stack_stride > 0 && c.vocab > 0 && c.n_layers >= 0, NBCI_ESHAPE,
                  "bad NDT1 shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.factors_size >= 0 && c.factors_size % 8 == 0, NBCI_ESHAPE, "factors size must be a multiple of 8 (0 = no factors projection)");
     NBCI_REQUIRE(c.blank_id >= 0 && c.blank_id < c.vocab, NBCI_EINVAL, "blank_id out of range");
     NBCI_REQUIRE(!(c.use_rope && ((c.hidden / c.n_heads) % 2)), NBCI_ESHAPE, "rope needs an even head size");
     Plan* p = new Plan();

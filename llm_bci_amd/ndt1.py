@@ -80,8 +80,11 @@ class NDT1(nn.Module):
         emb, tr = enc.embedder, enc.transformer
         if not emb.stack.active or emb.adapt or emb.day_token or emb.block_token:
             raise Exception("HIP path supports embedder.stack.active=true, adapt/day_token/block_token=false")
-        if enc.factors.active:
-            raise Exception("HIP path supports factors.active=false (identity out_proj)")
+        fac = enc.factors
+        if fac.active and float(fac.dropout) != 0.0:
+            raise Exception("HIP path supports factors.dropout = 0 (the yaml default) when factors.active")
+        if fac.active and fac.act not in ACT:
+            raise Exception(f"factors.act {fac.act} is not available on the HIP path")
         if not (emb.bias and tr.attention_bias and tr.mlp_bias):
             raise Exception("HIP path expects bias=true in embedder / attention / mlp")
         dtype_name = kwargs.get("compute_dtype", "bf16")
@@ -103,6 +106,10 @@ class NDT1(nn.Module):
         c.pos = 1 if emb.pos else 0
         c.blank_id, c.zero_infinity = kwargs["blank_id"], 1 if kwargs["zero_infinity"] else 0
         c.dtype = self.compute_dtype
+        # NeuralFactorsProjection (ndt1.py:348-373): encoder output = act(Linear(hidden -> size)) when active
+        c.factors_size = int(fac.size) if fac.active else 0
+        c.factors_act = ACT[fac.act] if fac.active else 0
+        c.factors_bias = 1 if (fac.active and fac.bias) else 0
         self._ccfg = c
         self.config = config
         self.vocab_size = kwargs["vocab_size"]
@@ -162,7 +169,11 @@ class NDT1(nn.Module):
             self._segments.append((b, cur))
         b, hs = cur, c.n_layers + 1
         add("encoder.out_norm.weight", (H,), hs); add("encoder.out_norm.bias", (H,), hs)
-        add("decoder.0.weight", (c.vocab, H), hs); add("decoder.0.bias", (c.vocab,), hs)
+        if c.factors_size > 0:
+            add("encoder.out_proj.proj.0.weight", (c.factors_size, H), hs)
+            if c.factors_bias:
+                add("encoder.out_proj.proj.0.bias", (c.factors_size,), hs)
+        add("decoder.0.weight", (c.vocab, c.factors_size if c.factors_size > 0 else H), hs); add("decoder.0.bias", (c.vocab,), hs)
         cur = (cur + 7) // 8 * 8
         self._segments.append((b, cur))
         self._layout_total = cur
@@ -207,7 +218,17 @@ class NDT1(nn.Module):
             linear(pre + "mlp.up_proj", H, I, fix)
             linear(pre + "mlp.down_proj", I, H, fix)
         put("encoder.out_norm.weight", torch.ones(H)); put("encoder.out_norm.bias", torch.zeros(H))
-        linear("decoder.0", H, c.vocab)
+        if c.factors_size > 0:   # NeuralFactorsProjection.__init__ (ndt1.py:360-369): Linear, then the optional re-initialisation
+            fac = self.config["encoder"]["factors"]
+            m = nn.Linear(H, c.factors_size, bool(fac["bias"]))
+            if fac["fixup_init"]:
+                m.weight.data.uniform_(-fac["init_range"], fac["init_range"])
+                if fac["bias"]:
+                    m.bias.data.zero_()
+            put("encoder.out_proj.proj.0.weight", m.weight)
+            if fac["bias"]:
+                put("encoder.out_proj.proj.0.bias", m.bias)
+        linear("decoder.0", c.factors_size if c.factors_size > 0 else H, c.vocab)
 
     def _bind_parameters(self):
         """(Re)create nn.Parameters as views into self._flat under the reference's key names."""

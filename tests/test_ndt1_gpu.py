@@ -52,11 +52,15 @@ def _det_over(js):
     return over
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix"])
 def test_tiny_golden_fp32(name):
     fx = load(name)
     m = _model(_det_over(str(fx["config_json"])), 11)
     sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w0:")}
+    own = m.state_dict()
+    assert set(own) == set(sd)                      # the reference's state-dict keys, nothing more or less
+    for k, v in sd.items():                         # reference-order initialisation: bit-equal under torch.manual_seed(1)
+        assert torch.equal(own[k], v), k
     m.load_state_dict(sd)
     m.to(DEV)
     batch = _to_dev(batch_of(fx))
@@ -131,7 +135,9 @@ def _oracle_cfg(m, **kw):
                          hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads, inter=c.inter, vocab=c.vocab, max_F=c.max_F,
                          smooth_sd=int(c.smooth_sd), noise=bool(c.noise), white_noise_sd=c.white_noise_sd,
                          constant_offset_sd=c.constant_offset_sd, embed_dropout=c.embed_dropout, dropout=c.dropout,
-                         use_rope=bool(c.use_rope), context_forward=c.context_forward, context_backward=c.context_backward, **kw)
+                         use_rope=bool(c.use_rope), context_forward=c.context_forward, context_backward=c.context_backward,
+                         factors_size=c.factors_size, factors_act={0: None, 1: "softsign", 2: "gelu", 3: "relu", 4: "tanh"}[c.factors_act],
+                         factors_bias=bool(c.factors_bias), **kw)
 
 
 def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
@@ -147,12 +153,14 @@ def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
                 targets=g.integers(1, vocab, (B, S)).astype(np.int64), targets_lengths=np.array(tlens, np.int64))
 
 
-@pytest.mark.parametrize("which", ["tiny", "c1"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "c1"])
 def test_train_mode_matches_oracle_with_dropout_and_noise(which):
     """recipe dropout (0.2 / 0.4) and noise ON: HIP and oracle draw identical masks (same counter RNG)."""
-    if which == "tiny":
+    if which.startswith("tiny"):
         over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
                             "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+        if which == "tiny_factors":   # NeuralFactorsProjection between out_norm and the decoder (ndt1.py:348-373)
+            over["encoder"]["factors"] = {"active": True, "size": 24, "act": "relu", "bias": True}
         vocab, batch = 11, _rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2])
     else:
         over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
