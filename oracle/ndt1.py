@@ -26,6 +26,7 @@ DEFAULTS = dict(  # configs/ndt1.yaml defaults, flattened
     use_rope=False, rope_theta=10000.0, context_forward=-2, context_backward=-2, pos=True,
     blank_id=0, zero_infinity=True,
     factors_size=0, factors_act="relu", factors_bias=True,   # NeuralFactorsProjection (ndt1.py:348-373); size 0 = inactive (identity)
+    adapt_days=0,   # embedder.adapt: one embed_spikes Linear per recording day, picked by batch["day_idx"] (ndt1.py:124-129,170-171); 0 = shared
 )
 
 
@@ -152,7 +153,11 @@ def init_params(cfg, seed=0, dtype=np.float32):
         return g.uniform(-b, b, (o, i)).astype(dtype), g.uniform(-b, b, (o,)).astype(dtype)
 
     p = {}
-    p["encoder.embedder.embed_spikes.weight"], p["encoder.embedder.embed_spikes.bias"] = lin(D, N)
+    if cfg.get("adapt_days", 0):
+        for d in range(cfg["adapt_days"]):
+            p[f"encoder.embedder.embed_spikes.{d}.weight"], p[f"encoder.embedder.embed_spikes.{d}.bias"] = lin(D, N)
+    else:
+        p["encoder.embedder.embed_spikes.weight"], p["encoder.embedder.embed_spikes.bias"] = lin(D, N)
     p["encoder.embedder.stack_projection.weight"], p["encoder.embedder.stack_projection.bias"] = lin(H, D * S)
     p["encoder.embedder.embed_pos.weight"] = g.standard_normal((cfg["max_F"], H)).astype(dtype)
     fix = 0.67 * L ** (-0.25)
@@ -206,7 +211,13 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
             xs = xs + f(cfg["constant_offset_sd"]) * R.normal(seed, R.SITE_NOISE_OFFSET, B * N).reshape(B, 1, N).astype(f)
     c["xs"] = xs
     # 4. embed + activation (ndt1.py:173-176)
-    pre = xs @ P["encoder.embedder.embed_spikes.weight"].T + P["encoder.embedder.embed_spikes.bias"]
+    if cfg.get("adapt_days", 0):   # per-sample day-specific layer (ndt1.py:170-171)
+        days = np.asarray(batch["day_idx"], np.int64).reshape(-1)
+        pre = np.stack([xs[b] @ P[f"encoder.embedder.embed_spikes.{days[b]}.weight"].T + P[f"encoder.embedder.embed_spikes.{days[b]}.bias"]
+                        for b in range(B)], 0)
+        c["days"] = days
+    else:
+        pre = xs @ P["encoder.embedder.embed_spikes.weight"].T + P["encoder.embedder.embed_spikes.bias"]
     y = act_fwd(cfg["embed_act"], pre)
     c["y"] = y
     # 5. stack (nn.Unfold row-major flatten) + projection (ndt1.py:138-140,180)
@@ -374,6 +385,12 @@ def backward(c, grad_scale=1.0):
     for j in range(Tp):
         dy[:, j * st:j * st + S, :] += dwin[:, j].reshape(B, S, D)
     dpre = dy * act_bwd(cfg["embed_act"], c["pre_embed"])
-    g["encoder.embedder.embed_spikes.weight"] = dpre.reshape(-1, D).T @ c["xs"].reshape(-1, c["xs"].shape[-1])
-    g["encoder.embedder.embed_spikes.bias"] = dpre.reshape(-1, D).sum(0)
+    if cfg.get("adapt_days", 0):
+        for d in range(cfg["adapt_days"]):
+            sel = [b for b in range(B) if c["days"][b] == d]
+            g[f"encoder.embedder.embed_spikes.{d}.weight"] = sum((dpre[b].T @ c["xs"][b] for b in sel), np.zeros((D, c["xs"].shape[-1]), f))
+            g[f"encoder.embedder.embed_spikes.{d}.bias"] = sum((dpre[b].sum(0) for b in sel), np.zeros(D, f))
+    else:
+        g["encoder.embedder.embed_spikes.weight"] = dpre.reshape(-1, D).T @ c["xs"].reshape(-1, c["xs"].shape[-1])
+        g["encoder.embedder.embed_spikes.bias"] = dpre.reshape(-1, D).sum(0)
     return {k: v.astype(f) for k, v in g.items()}

@@ -68,12 +68,14 @@ def det(over):
     return o
 
 
-def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0):
+def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0, days=None):
     g = np.random.default_rng(seed)
     rows = []
-    for L, S in zip(lens, tgt_lens):
+    for i, (L, S) in enumerate(zip(lens, tgt_lens)):
         rows.append({"spikes": g.standard_normal((L, n_ch)).astype(np.float32),
                      "phonemes_idx": g.integers(1, vocab, (S,)).astype(np.int64)})
+        if days is not None:   # day-specific recordings (datasets.py:115-140 rows carry day_idx)
+            rows[-1]["day_idx"] = np.asarray(days[i], dtype=np.int64)
     ds = SpikingDatasetForDecoding(rows, targets_name="phonemes_idx")
     items = [ds[i] for i in range(len(ds))]
     names = list(inspect.signature(model.forward).parameters)
@@ -91,12 +93,12 @@ def summarise(t):
     return {"sum": float(a.sum()), "abssum": float(np.abs(a).sum()), "idx": idx, "val": a[idx].astype(np.float32)}
 
 
-def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2):
+def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2, days=None):
     over = dict(over)
     over["_vocab"] = vocab
     ov = {k: v for k, v in over.items() if k != "_vocab"}
     model = build({**det(ov), "_vocab": vocab})
-    rows, batch, unused = make_batch(model, lens, n_ch, tgt_lens, vocab)
+    rows, batch, unused = make_batch(model, lens, n_ch, tgt_lens, vocab, days=days)
     fx = {}
     for k, v in batch.items():
         fx["in_" + k] = v.numpy()
@@ -239,6 +241,12 @@ def misc_cases():
         fx[f"ctx_{f}_{b}"] = create_context_mask(f, b, 24).numpy()
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
+
+if __name__ == "__main__" and "--adapt" in sys.argv:
+    # embedder.adapt: one embed_spikes Linear per recording day, picked per sample by day_idx (ndt1.py:124-129,170-171)
+    run_case("g_tiny_adapt", tiny(embedder={"adapt": True, "n_days": 3}), [30, 22, 17, 26], [5, 4, 2, 3], 16, vocab=11, full=True,
+             days=[2, 0, 2, 1])
+    sys.exit(0)
 
 if __name__ == "__main__" and "--factors" in sys.argv:
     # NeuralFactorsProjection active (ndt1.py:348-373): Linear(hidden -> size) + act between out_norm and the decoder

@@ -35,6 +35,8 @@ def cfg_from_json(js, vocab):
             kw[dst] = tr[src]
     if "forward" in ctx:
         kw["context_forward"], kw["context_backward"] = ctx["forward"], ctx["backward"]
+    if emb.get("adapt", False):
+        kw["adapt_days"] = emb["n_days"]
     fac = enc.get("factors", {})
     if fac.get("active", False):
         kw["factors_size"], kw["factors_act"], kw["factors_bias"] = fac["size"], fac.get("act", "relu"), fac.get("bias", True)
@@ -45,7 +47,7 @@ def batch_of(fx):
     return {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt"])
 def test_tiny_forward_backward_adamw(name):
     fx = load(name)
     cfg = cfg_from_json(str(fx["config_json"]), 11)
