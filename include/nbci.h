@@ -97,7 +97,8 @@ typedef struct nbci_gemm_desc {
     uint32_t seed, site;   /* dropout stream id */
     const float* residual; /* f32 [M][ldr] or NULL */
     int64_t ldr;
-    const int64_t* residual_rows; /* optional gather: residual row index per output row (nn.Embedding add, ndt1.py:189) */
+    const int64_t* residual_rows; /* optional gather: residual row index per output row (nn.Embedding add, ndt1.py:189);
+                                     batched: indexed by the global row (batch offset czs / ldc + m) */
     int32_t residual_first;       /* 1: residual is added BEFORE act/dropout */
     const void* gate;             /* optional [M][ldg] in in_dtype: result *= act'(gate) (GELU/softsign backward) */
     int64_t ldg;
@@ -248,6 +249,9 @@ typedef struct nbci_ndt1_config { /* configs/ndt1.yaml, flattened */
      * act(Linear(hidden -> factors_size)(out_norm(x))) instead of out_norm(x); 0 = inactive (identity). The decoder then
      * reads factors_size inputs, hidden_out / d_hidden are (B,T',factors_size). factors.dropout must be 0. */
     int32_t factors_size, factors_act, factors_bias;
+    /* embedder.adapt (models/ndt1.py:124-129,170-171): adapt_days > 0 = one embed_spikes Linear per recording day
+     * ("encoder.embedder.embed_spikes.<d>.weight / .bias"), picked per sample by io.day_idx; 0 = one shared layer. */
+    int32_t adapt_days;
 } nbci_ndt1_config;
 
 typedef struct nbci_ndt1_io {
@@ -274,6 +278,7 @@ typedef struct nbci_ndt1_io {
                                            instead of the CTC gradient; decoder gradients are not touched. */
     void* workspace;
     int64_t workspace_bytes;
+    const int64_t* day_idx;             /* (B) recording day of each sample, 0 <= day < adapt_days; required when adapt_days > 0 */
 } nbci_ndt1_io;
 
 typedef void* nbci_ndt1_plan;

@@ -256,7 +256,7 @@ _Pragma("unroll")
         }
     }
     if (d.residual && d.residual_first) {
-        const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+        const long long rr = d.residual_rows ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
         const float* r = d.residual + rr * d.ldr + n;
         if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
         else {
@@ -297,7 +297,7 @@ _Pragma("unroll")
         }
     }
     if (d.residual && !d.residual_first) {
-        const long long rr = d.residual_rows ? d.residual_rows[m] : (long long)m;
+        const long long rr = d.residual_rows ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
         const float* r = d.residual + rr * d.ldr + n;
         if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
         else {

@@ -74,6 +74,10 @@ int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_len
 size_t ctc_alpha_floats(int B, int Tp, int S);
 
 // greedy decode (reference's format_ctc, utils/eval_bci.py:41-48) + Levenshtein vs targets (main.py:68-74)
+int adapt_gather_launch(const void* wsrc, long long day_stride, const int64_t* day, void* wsel, int64_t* rows, int dtype, int B, int wn,
+                        int T, int ndays, hipStream_t s);
+int adapt_grads_launch(const void* dpre, int dtype, const float* wpart, float* bpart, const int64_t* day, float* gw, float* gb,
+                       long long day_stride, int B, int T, int D, int wn, int ndays, hipStream_t s);
 int gate_cast_launch(const float* src, const void* gate, void* out, int dtype, long long n, hipStream_t s);
 int step_stats_launch(double* stats, const float* loss, int B, double n_examples, const int32_t* err, hipStream_t s);
 int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_lens, int B, int Tp, int S,

@@ -941,6 +941,68 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
     return check_launch("per");
 }
 
+// ------------------------------------------------------------------------------------------
+// embedder.adapt (ndt1.py:124-129,170-171): one embed_spikes Linear per recording day, picked per sample
+// ------------------------------------------------------------------------------------------
+// forward: copy each sample's day weights (D*N, activation dtype) next to each other so the embed is ONE batched GEMM,
+// and fill the per-row table the GEMM's residual gather uses to add that day's bias (row (b,t) -> day[b])
+template <typename T>
+__global__ __launch_bounds__(256) void adapt_gather_kernel(const T* __restrict__ wsrc, long long day_stride, const int64_t* __restrict__ day,
+                                                           T* __restrict__ wsel, int64_t* __restrict__ rows, int wn, int Tt, int ndays) {
+    const int b = blockIdx.y;
+    long long d = day[b];
+    d = d < 0 ? 0 : (d >= ndays ? ndays - 1 : d);   // (validated on the host side of the module; never index out of the table)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < wn; i += gridDim.x * 256) wsel[(long long)b * wn + i] = wsrc[d * day_stride + i];
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < Tt; t += 256) rows[(long long)b * Tt + t] = d;
+}
+
+int adapt_gather_launch(const void* wsrc, long long day_stride, const int64_t* day, void* wsel, int64_t* rows, int dtype, int B, int wn,
+                        int T, int ndays, hipStream_t s) {
+    NBCI_REQUIRE(wsrc && day && wsel && rows && B > 0 && wn > 0 && ndays > 0, NBCI_EINVAL, "adapt_gather: bad argument");
+    DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((adapt_gather_kernel<TT>), dim3((unsigned)((wn + 1023) / 1024), B), dim3(256), 0, s,
+                                                 (const TT*)wsrc, day_stride, day, (TT*)wsel, rows, wn, T, ndays));
+    return check_launch("adapt_gather");
+}
+
+// backward, step 1: per-sample column sums of d(pre-activation) (B,T,D) -> bsum (B,D) f32 (that sample's bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void adapt_bias_kernel(const T* __restrict__ dpre, float* __restrict__ bsum, int Tt, int D) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < D)
+        for (int t = g; t < Tt; t += 4) acc += ldf<T>(dpre, ((long long)b * Tt + t) * D + c);
+    red[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && c < D) bsum[(long long)b * D + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// backward, step 2: every thread owns one element of the day layer (weight then bias) and adds the samples' partial
+// gradients into the rows of their days in a FIXED order (deterministic; two samples of one day never race)
+__global__ __launch_bounds__(256) void adapt_scatter_kernel(const float* __restrict__ wpart, const float* __restrict__ bpart,
+                                                            const int64_t* __restrict__ day, float* __restrict__ gw, float* __restrict__ gb,
+                                                            long long day_stride, int B, int wn, int D, int ndays) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= wn + D) return;
+    for (int b = 0; b < B; ++b) {
+        long long d = day[b];
+        d = d < 0 ? 0 : (d >= ndays ? ndays - 1 : d);
+        if (e < wn) gw[d * day_stride + e] += wpart[(long long)b * wn + e];
+        else gb[d * day_stride + (e - wn)] += bpart[(long long)b * D + (e - wn)];
+    }
+}
+
+int adapt_grads_launch(const void* dpre, int dtype, const float* wpart, float* bpart, const int64_t* day, float* gw, float* gb,
+                       long long day_stride, int B, int T, int D, int wn, int ndays, hipStream_t s) {
+    NBCI_REQUIRE(dpre && wpart && bpart && day && gw && gb, NBCI_EINVAL, "adapt_grads: null argument");
+    DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((adapt_bias_kernel<TT>), dim3((unsigned)((D + 63) / 64), B), dim3(256), 0, s, (const TT*)dpre,
+                                                 bpart, T, D));
+    hipLaunchKernelGGL(adapt_scatter_kernel, dim3((unsigned)((wn + D + 255) / 256)), dim3(256), 0, s, wpart, (const float*)bpart, day, gw, gb,
+                       day_stride, B, wn, D, ndays);
+    return check_launch("adapt_grads");
+}
+
 // out = src * gate, f32 -> activation dtype: an external f32 gradient pushed back through a stored activation derivative
 template <typename T>
 __global__ __launch_bounds__(256) void gate_cast_kernel(const float* __restrict__ src, const T* __restrict__ gate, T* __restrict__ out, long long n) {

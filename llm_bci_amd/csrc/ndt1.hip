@@ -29,6 +29,7 @@ struct Plan {
     std::vector<LayerOff> L;
     int64_t embw, embb, stkw, stkb, pos, onw, onb, decw, decb;
     int64_t facw = -1, facb = -1;   // factors projection (head segment), -1 = absent
+    int64_t day_stride = 0;         // adapt: elements between consecutive days' embed layers (weight and bias alike)
     int64_t total;
     std::vector<std::pair<int64_t, int64_t>> seg;  // [begin,end) per segment
     float* d_taps;
@@ -59,8 +60,18 @@ static void build_layout(Plan& p) {
     const auto& c = p.c;
     int64_t cur = 0;
     const int H = c.hidden, I = c.inter, D = c.input_dim;
-    p.embw = add_param(p, cur, "encoder.embedder.embed_spikes.weight", D, c.n_channels, 0);
-    p.embb = add_param(p, cur, "encoder.embedder.embed_spikes.bias", D, 0, 0);
+    if (c.adapt_days > 0) {   // nn.ModuleList of per-day Linears (ndt1.py:124-129): <d>.weight, <d>.bias, uniform stride
+        for (int d = 0; d < c.adapt_days; ++d) {
+            const int64_t wo = add_param(p, cur, "encoder.embedder.embed_spikes." + std::to_string(d) + ".weight", D, c.n_channels, 0);
+            const int64_t bo = add_param(p, cur, "encoder.embedder.embed_spikes." + std::to_string(d) + ".bias", D, 0, 0);
+            if (d == 0) { p.embw = wo; p.embb = bo; }
+            if (d == 1) p.day_stride = wo - p.embw;
+        }
+        if (c.adapt_days == 1) p.day_stride = (int64_t)D * c.n_channels + D;
+    } else {
+        p.embw = add_param(p, cur, "encoder.embedder.embed_spikes.weight", D, c.n_channels, 0);
+        p.embb = add_param(p, cur, "encoder.embedder.embed_spikes.bias", D, 0, 0);
+    }
     p.stkw = add_param(p, cur, "encoder.embedder.stack_projection.weight", H, D * c.stack_size, 0);
     p.stkb = add_param(p, cur, "encoder.embedder.stack_projection.bias", H, 0, 0);
     p.pos = c.pos ? add_param(p, cur, "encoder.embedder.embed_pos.weight", c.max_F, H, 0) : -1;
@@ -133,6 +144,7 @@ struct WS {
     std::vector<LayerWS> L;
     size_t x_last, mean_o, rstd_o, xo, logits, alpha, dlogits, argmax;
     size_t fo, fgate, dfo;             // factors projection: output, act'(pre-activation), gradient (M, factors_size)
+    size_t wsel, rsel, wpart, bpart;   // adapt: per-sample day weights (B,D,N), row -> day table (B*T), per-sample weight / bias gradients
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
     size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
     size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
@@ -155,6 +167,12 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     size_t cur = 0;
     w.xs = bump(cur, (size_t)B * T * c.n_channels * es);
     w.y = bump(cur, (size_t)B * T * D * es);
+    if (c.adapt_days > 0) {
+        w.wsel = bump(cur, (size_t)B * D * c.n_channels * es);
+        w.rsel = bump(cur, (size_t)B * T * 8);
+        w.wpart = bump(cur, (size_t)B * D * c.n_channels * 4);
+        w.bpart = bump(cur, (size_t)B * D * 4);
+    }
     w.tmask = bump(cur, M * 4);
     w.tts = bump(cur, M * 8);
     w.tlens = bump(cur, (size_t)B * 4);
@@ -260,7 +278,19 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     TRY(smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
                             noise ? c.constant_offset_sd : 0.f, io->seed, s));
     // 1. embed Linear + activation (ndt1.py:173-176)
-    {
+    if (c.adapt_days > 0) {
+        // day-specific layers: each sample's day weights gathered side by side -> ONE batched GEMM (batch = sample); the day's bias
+        // arrives through the residual gather (row (b,t) -> day[b]; added before the activation)
+        NBCI_REQUIRE(io->day_idx, NBCI_EINVAL, "ndt1: embedder.adapt needs day_idx");
+        const int wn = D * c.n_channels;
+        TRY(adapt_gather_launch(x.W(p.embw), p.day_stride, io->day_idx, ws + w.wsel, (int64_t*)(ws + w.rsel), dt, B, wn, T, c.adapt_days, s));
+        nbci_gemm_desc d = gd(T, D, c.n_channels, dt, op(ws + w.xs, es, 0, c.n_channels, 1, 0, 0, (int64_t)T * c.n_channels),
+                              op(ws + w.wsel, es, 0, c.n_channels, 1, 0, 0, wn), ws + w.y, D, dt);
+        d.batch = B; d.zdiv = 1; d.czs1 = (int64_t)T * D;
+        d.residual = params + p.embb; d.ldr = p.day_stride; d.residual_rows = (const int64_t*)(ws + w.rsel); d.residual_first = 1;
+        d.act = c.embed_act;
+        TRY(gemm_launch_timed(d, s));
+    } else {
         nbci_gemm_desc d = gd(B * T, D, c.n_channels, dt, op(ws + w.xs, es, 0, c.n_channels, 1),
                               op(x.W(p.embw), es, 0, c.n_channels, 1), ws + w.y, D, dt);
         d.bias = params + p.embb; d.act = c.embed_act;
@@ -584,9 +614,20 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
                                       c.embed_act, s));
             }
+            if (c.adapt_days > 0) {   // per-sample partial gradients (batched), then a deterministic scatter into the days' rows
+                NBCI_REQUIRE(io->day_idx, NBCI_EINVAL, "ndt1: embedder.adapt needs day_idx");
+                const int wn = D * c.n_channels;
+                nbci_gemm_desc d = gd(D, c.n_channels, T, dt, op(ws + w.dpre, es, 0, D, 0, 0, 0, (int64_t)T * D),
+                                      op(ws + w.xs, es, 0, c.n_channels, 0, 0, 0, (int64_t)T * c.n_channels), ws + w.wpart, c.n_channels, NBCI_F32);
+                d.batch = B; d.zdiv = 1; d.czs1 = wn;
+                TRY(gemm_launch_timed(d, s));
+                TRY(adapt_grads_launch(ws + w.dpre, dt, (const float*)(ws + w.wpart), (float*)(ws + w.bpart), io->day_idx, grads + p.embw,
+                                       grads + p.embb, p.day_stride, B, T, D, wn, c.adapt_days, s));
+            } else {
             TRY(colsum_launch(ws + w.dpre, dt, D, B * T, D, RG(p.embb), s, rc));
             TRY(wgrad(s, dt, D, c.n_channels, B * T, op(ws + w.dpre, es, 0, D, 0), op(ws + w.xs, es, 0, c.n_channels, 0),
                       grads + p.embw, c.n_channels));
+            }
         }
         TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
@@ -611,6 +652,7 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
     NBCI_REQUIRE(c.n_channels > 0 && c.stack_size > 0 && c.stack_stride > 0 && c.vocab > 0 && c.n_layers >= 0, NBCI_ESHAPE,
                  "bad NDT1 shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.adapt_days >= 0 && c.adapt_days <= 4096, NBCI_EINVAL, "adapt_days out of range");
     NBCI_REQUIRE(c.factors_size >= 0 && c.factors_size % 8 == 0, NBCI_ESHAPE, "factors size must be a multiple of 8 (0 = no factors projection)");
     NBCI_REQUIRE(c.blank_id >= 0 && c.blank_id < c.vocab, NBCI_EINVAL, "blank_id out of range");
     NBCI_REQUIRE(!(c.use_rope && ((c.hidden / c.n_heads) % 2)), NBCI_ESHAPE, "rope needs an even head size");

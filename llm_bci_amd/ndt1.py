@@ -78,8 +78,8 @@ class NDT1(nn.Module):
             if m.get("active", False):
                 raise Exception("active Masker is only meaningful for mlm; not supported on the ctc HIP path")
         emb, tr = enc.embedder, enc.transformer
-        if not emb.stack.active or emb.adapt or emb.day_token or emb.block_token:
-            raise Exception("HIP path supports embedder.stack.active=true, adapt/day_token/block_token=false")
+        if not emb.stack.active or emb.day_token or emb.block_token:
+            raise Exception("HIP path supports embedder.stack.active=true, day_token/block_token=false")
         fac = enc.factors
         if fac.active and float(fac.dropout) != 0.0:
             raise Exception("HIP path supports factors.dropout = 0 (the yaml default) when factors.active")
@@ -110,6 +110,8 @@ class NDT1(nn.Module):
         c.factors_size = int(fac.size) if fac.active else 0
         c.factors_act = ACT[fac.act] if fac.active else 0
         c.factors_bias = 1 if (fac.active and fac.bias) else 0
+        # embedder.adapt: one embed_spikes Linear per recording day (ndt1.py:124-129), picked per sample by day_idx
+        c.adapt_days = int(emb.n_days) if emb.adapt else 0
         self._ccfg = c
         self.config = config
         self.vocab_size = kwargs["vocab_size"]
@@ -146,8 +148,13 @@ class NDT1(nn.Module):
             out.append((name, cur, n, tuple(shape), seg))
             cur += n
 
-        add("encoder.embedder.embed_spikes.weight", (D, c.n_channels), 0)
-        add("encoder.embedder.embed_spikes.bias", (D,), 0)
+        if c.adapt_days > 0:
+            for d in range(c.adapt_days):
+                add(f"encoder.embedder.embed_spikes.{d}.weight", (D, c.n_channels), 0)
+                add(f"encoder.embedder.embed_spikes.{d}.bias", (D,), 0)
+        else:
+            add("encoder.embedder.embed_spikes.weight", (D, c.n_channels), 0)
+            add("encoder.embedder.embed_spikes.bias", (D,), 0)
         add("encoder.embedder.stack_projection.weight", (H, D * c.stack_size), 0)
         add("encoder.embedder.stack_projection.bias", (H,), 0)
         if c.pos:
@@ -200,7 +207,11 @@ class NDT1(nn.Module):
             put(prefix + ".weight", w)
             put(prefix + ".bias", m.bias)
 
-        linear("encoder.embedder.embed_spikes", c.n_channels, D)
+        if c.adapt_days > 0:
+            for d in range(c.adapt_days):
+                linear(f"encoder.embedder.embed_spikes.{d}", c.n_channels, D)
+        else:
+            linear("encoder.embedder.embed_spikes", c.n_channels, D)
         linear("encoder.embedder.stack_projection", D * c.stack_size, H)
         if c.pos:
             put("encoder.embedder.embed_pos.weight", nn.Embedding(c.max_F, H).weight)
@@ -366,10 +377,19 @@ class NDT1(nn.Module):
         io.token_mask_out = _ptr(token_mask_out)
         io.d_hidden = None
         io.workspace, io.workspace_bytes = _ptr(ws), need
+        days = None
+        if self._ccfg.adapt_days > 0:   # day-specific embed layers (ndt1.py:170-171)
+            days = batch.get("day_idx")
+            if days is None:
+                raise ValueError("embedder.adapt is on: forward needs day_idx (the recording day of every sample)")
+            days = days.reshape(-1).contiguous().long()
+            if days.numel() != B:
+                raise ValueError(f"day_idx has {days.numel()} entries for a batch of {B}")
+        io.day_idx = _ptr(days)
         check(lib().nbci_ndt1_forward(self._plan, _ptr(self._flat), _ptr(self._flat_lp), C.byref(io), _stream()),
               "nbci_ndt1_forward")
         # keep every borrowed tensor alive until the backward of this step has been queued
-        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out)
+        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out, days)
         self.last_argmax = argmax
         return loss, preds
 
@@ -386,7 +406,7 @@ class NDT1(nn.Module):
     def forward(self, spikes, spikes_mask, spikes_timestamp, spikes_lengths, targets=None, targets_lengths=None,
                 block_idx=None, day_idx=None):
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_timestamp=spikes_timestamp,
-                     spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths)
+                     spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths, day_idx=day_idx)
         if torch.is_grad_enabled() and targets is not None and any(p.requires_grad for p in self._param_list):
             loss, preds = _NDT1Function.apply(self, batch, *self._param_list)
         else:

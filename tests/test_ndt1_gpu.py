@@ -52,7 +52,7 @@ def _det_over(js):
     return over
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt"])
 def test_tiny_golden_fp32(name):
     fx = load(name)
     m = _model(_det_over(str(fx["config_json"])), 11)
@@ -137,7 +137,7 @@ def _oracle_cfg(m, **kw):
                          constant_offset_sd=c.constant_offset_sd, embed_dropout=c.embed_dropout, dropout=c.dropout,
                          use_rope=bool(c.use_rope), context_forward=c.context_forward, context_backward=c.context_backward,
                          factors_size=c.factors_size, factors_act={0: None, 1: "softsign", 2: "gelu", 3: "relu", 4: "tanh"}[c.factors_act],
-                         factors_bias=bool(c.factors_bias), **kw)
+                         factors_bias=bool(c.factors_bias), adapt_days=c.adapt_days, **kw)
 
 
 def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
@@ -153,7 +153,25 @@ def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
                 targets=g.integers(1, vocab, (B, S)).astype(np.int64), targets_lengths=np.array(tlens, np.int64))
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "c1"])
+def _bf16_vs_oracle(over, vocab, batch):
+    """bf16 path vs the f32 oracle with identical dropout / noise draws: log-probs within 0.08, gradient L1 within 8 %."""
+    m = _model(over, vocab, dtype="bf16").to(DEV)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    loss, preds, g = _grads(m, _to_dev(batch), train=True, seed=1234)
+    o, cache = O.forward(_oracle_cfg(m), p, batch, train=True, seed=1234)
+    go = O.backward(cache)
+    assert np.abs(preds - o["preds"]).max() < 0.08
+    for k in g:
+        if k.endswith("attn.key.bias"):   # mathematically zero (softmax is shift-invariant along the keys): rounding noise only
+            continue
+        den = np.abs(go[k]).sum()
+        if den > 1e-3:
+            assert np.abs(g[k] - go[k]).sum() / den < 0.08, k
+        else:   # (a day no sample came from: both exactly zero)
+            assert np.abs(g[k]).sum() < 1e-3, k
+
+
+@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "tiny_adapt", "c1", "c1_adapt_bf16"])
 def test_train_mode_matches_oracle_with_dropout_and_noise(which):
     """recipe dropout (0.2 / 0.4) and noise ON: HIP and oracle draw identical masks (same counter RNG)."""
     if which.startswith("tiny"):
@@ -162,9 +180,18 @@ def test_train_mode_matches_oracle_with_dropout_and_noise(which):
         if which == "tiny_factors":   # NeuralFactorsProjection between out_norm and the decoder (ndt1.py:348-373)
             over["encoder"]["factors"] = {"active": True, "size": 24, "act": "relu", "bias": True}
         vocab, batch = 11, _rand_batch(3, 30, 16, 5, 11, [30, 22, 17], [5, 4, 2])
+        if which == "tiny_adapt":     # day-specific embed layers, two samples sharing a day (ndt1.py:124-129,170-171)
+            over["encoder"]["embedder"].update(adapt=True, n_days=3)
+            batch["day_idx"] = np.array([2, 0, 2], np.int64)
     else:
         over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
         vocab, batch = 41, _rand_batch(4, 100, 64, 10, 41, [100, 100, 80, 64], [10, 8, 6, 3])
+        if which == "c1_adapt_bf16":  # real widths: the batched direct-to-LDS GEMMs (K = 100 bins is not a multiple of 64)
+            over["encoder"]["embedder"].update(adapt=True, n_days=5)
+            batch["day_idx"] = np.array([4, 1, 4, 0], np.int64)
+    if which == "c1_adapt_bf16":
+        _bf16_vs_oracle(over, vocab, batch)
+        return
     m = _model(over, vocab).to(DEV)
     p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     loss, preds, g = _grads(m, _to_dev(batch), train=True, seed=1234)
