@@ -26,6 +26,7 @@ DEFAULTS = dict(  # configs/ndt1.yaml defaults, flattened
     use_rope=False, rope_theta=10000.0, context_forward=-2, context_backward=-2, pos=True,
     blank_id=0, zero_infinity=True,
     factors_size=0, factors_act="relu", factors_bias=True,   # NeuralFactorsProjection (ndt1.py:348-373); size 0 = inactive (identity)
+    day_token_days=0, block_token_blocks=0,   # embedder.day_token / block_token: learned prefix tokens, table sizes (ndt1.py:151-155,192-201); 0 = off
     adapt_days=0,   # embedder.adapt: one embed_spikes Linear per recording day, picked by batch["day_idx"] (ndt1.py:124-129,170-171); 0 = shared
 )
 
@@ -160,6 +161,10 @@ def init_params(cfg, seed=0, dtype=np.float32):
         p["encoder.embedder.embed_spikes.weight"], p["encoder.embedder.embed_spikes.bias"] = lin(D, N)
     p["encoder.embedder.stack_projection.weight"], p["encoder.embedder.stack_projection.bias"] = lin(H, D * S)
     p["encoder.embedder.embed_pos.weight"] = g.standard_normal((cfg["max_F"], H)).astype(dtype)
+    if cfg.get("block_token_blocks", 0):
+        p["encoder.embedder.block_embedding.weight"] = g.standard_normal((cfg["block_token_blocks"], H)).astype(dtype)
+    if cfg.get("day_token_days", 0):
+        p["encoder.embedder.day_embedding.weight"] = g.standard_normal((cfg["day_token_days"], H)).astype(dtype)
     fix = 0.67 * L ** (-0.25)
     for l in range(L):
         pre = f"encoder.layers.{l}."
@@ -232,16 +237,30 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
     # 7. position + dropout (ndt1.py:188-189,203)
     if cfg["pos"]:
         x = x + P["encoder.embedder.embed_pos.weight"][tts]
-    ed = R.keep_mask(seed, R.SITE_EMBED_DROP, B * Tp * H, cfg["embed_dropout"] if train else 0.0).reshape(B, Tp, H).astype(f)
+    # block token, then day token, prepended (ndt1.py:192-201): the sequence becomes [day, block, tokens...]; their mask entries are 1
+    pref = []
+    if cfg.get("day_token_days", 0):
+        c["day_sel"] = np.asarray(batch["day_idx"], np.int64).reshape(-1)
+        pref.append(P["encoder.embedder.day_embedding.weight"][c["day_sel"]])
+    if cfg.get("block_token_blocks", 0):
+        c["block_sel"] = np.asarray(batch["block_idx"], np.int64).reshape(-1)
+        pref.append(P["encoder.embedder.block_embedding.weight"][c["block_sel"]])
+    npre = len(pref)
+    if npre:
+        assert not cfg["use_rope"], "rope + prefix tokens: the reference passes T' timestamps for T'+n tokens (ndt1.py:181,441)"
+        x = np.concatenate([t[:, None, :] for t in pref] + [x], 1)
+        tmask = np.concatenate([np.ones((B, npre), tmask.dtype), tmask], 1)
+    Tq = Tp + npre   # sequence length inside the transformer
+    ed = R.keep_mask(seed, R.SITE_EMBED_DROP, B * Tq * H, cfg["embed_dropout"] if train else 0.0).reshape(B, Tq, H).astype(f)
     x = x * ed
     c["tts"] = tts
     # 8. attention mask (ndt1.py:435-437): eye | (ctx & key_valid)
-    ctx = context_mask(cfg["context_forward"], cfg["context_backward"], cfg["max_F"])[:Tp, :Tp]
-    amask = (np.eye(Tp, dtype=np.int64)[None] | (ctx[None] & tmask[:, None, :])).astype(bool)  # (B,Tp,Tp)
+    ctx = context_mask(cfg["context_forward"], cfg["context_backward"], cfg["max_F"])[:Tq, :Tq]
+    amask = (np.eye(Tq, dtype=np.int64)[None] | (ctx[None] & tmask[:, None, :])).astype(bool)  # (B,Tq,Tq)
     c["amask"] = amask
     if cfg["use_rope"]:
         cos_t, sin_t = rope_tables(hd, cfg["max_F"], cfg["rope_theta"])
-        cos, sin = cos_t[tts][:, None].astype(f), sin_t[tts][:, None].astype(f)  # (B,1,Tp,hd)
+        cos, sin = cos_t[tts][:, None].astype(f), sin_t[tts][:, None].astype(f)  # (B,1,Tq,hd)
         c["cos"], c["sin"] = cos, sin
     pl = cfg["dropout"] if train else 0.0
     scale = f(1.0 / math.sqrt(hd))
@@ -253,7 +272,7 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
         lc["h1"] = h1
 
         def heads(t):
-            return t.reshape(B, Tp, nh, hd).transpose(0, 2, 1, 3)
+            return t.reshape(B, Tq, nh, hd).transpose(0, 2, 1, 3)
 
         q = heads(h1 @ P[pre_ + "attn.query.weight"].T + P[pre_ + "attn.query.bias"])
         k = heads(h1 @ P[pre_ + "attn.key.weight"].T + P[pre_ + "attn.key.bias"])
@@ -266,10 +285,10 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
         s = s - s.max(-1, keepdims=True)
         e = np.exp(s)
         prob = e / e.sum(-1, keepdims=True)
-        pm = R.keep_mask(seed, R.site_attn_prob(l), B * nh * Tp * Tp, pl).reshape(B, nh, Tp, Tp).astype(f)
+        pm = R.keep_mask(seed, R.site_attn_prob(l), B * nh * Tq * Tq, pl).reshape(B, nh, Tq, Tq).astype(f)
         pd = prob * pm
-        a = (pd @ v).transpose(0, 2, 1, 3).reshape(B, Tp, H)
-        am = R.keep_mask(seed, R.site_attn_out(l), B * Tp * H, pl).reshape(B, Tp, H).astype(f)
+        a = (pd @ v).transpose(0, 2, 1, 3).reshape(B, Tq, H)
+        am = R.keep_mask(seed, R.site_attn_out(l), B * Tq * H, pl).reshape(B, Tq, H).astype(f)
         ad = a * am
         x = x + ad @ P[pre_ + "attn.out_proj.weight"].T + P[pre_ + "attn.out_proj.bias"]
         lc.update(q=q, k=k, v=v, prob=prob, pm=pm, pd=pd, am=am, ad=ad, x_mid=x)
@@ -277,13 +296,15 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
         u = h2 @ P[pre_ + "mlp.up_proj.weight"].T + P[pre_ + "mlp.up_proj.bias"]
         gact = act_fwd(cfg["mlp_act"], u)
         m = gact @ P[pre_ + "mlp.down_proj.weight"].T + P[pre_ + "mlp.down_proj.bias"]
-        mm = R.keep_mask(seed, R.site_mlp_out(l), B * Tp * H, pl).reshape(B, Tp, H).astype(f)
+        mm = R.keep_mask(seed, R.site_mlp_out(l), B * Tq * H, pl).reshape(B, Tq, H).astype(f)
         x = x + m * mm
         lc.update(h2=h2, u=u, g=gact, mm=mm)
         layers.append(lc)
     c["layers"] = layers
     c["x_last"] = x
     xo, c["xhat_o"], c["rstd_o"] = layer_norm(x, P["encoder.out_norm.weight"], P["encoder.out_norm.bias"])
+    xo_full = xo
+    xo = xo[:, npre:]              # prefix tokens dropped after out_norm, before out_proj / decoder (ndt1.py:444-450)
     c["xo"] = xo
     enc_out = xo
     if cfg.get("factors_size", 0):   # out_proj = act(Linear(dropout_{p=0}(x))) (ndt1.py:362-365,372-373)
@@ -296,7 +317,7 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
     z = logits - logits.max(-1, keepdims=True)
     lp = z - np.log(np.exp(z).sum(-1, keepdims=True))
     out = {"preds": lp.astype(f), "logits": logits, "token_mask": tmask, "token_lens": tlens, "x_embed": layers[0]["x_in"] if L else x,
-           "layer_out": [lc["x_mid"] for lc in layers], "x_final": xo, "enc_out": enc_out, "xs": xs, "y": y}
+           "layer_out": [lc["x_mid"] for lc in layers], "x_final": xo_full, "enc_out": enc_out, "xs": xs, "y": y}
     if "targets" in batch and batch["targets"] is not None:
         losses, dlogits = ctc_loss_and_grad(lp, batch["targets"], tlens, np.asarray(batch["targets_lengths"]).reshape(-1),
                                             blank=cfg["blank_id"], zero_infinity=cfg["zero_infinity"])
@@ -304,7 +325,7 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
         out["loss"] = f(losses.sum())
         out["n_examples"] = np.int64(B)
         c["dlogits"] = dlogits.astype(f)
-    c.update(cfg=cfg, P=P, B=B, T=T, Tp=Tp, train=train, seed=seed, ed=ed, f=f, pre_embed=pre)
+    c.update(cfg=cfg, P=P, B=B, T=T, Tp=Tp, Tq=Tq, npre=npre, train=train, seed=seed, ed=ed, f=f, pre_embed=pre)
     return out, (c if keep_cache else None)
 
 
@@ -329,6 +350,9 @@ def backward(c, grad_scale=1.0):
         if "encoder.out_proj.proj.0.bias" in P:
             g["encoder.out_proj.proj.0.bias"] = dfu.reshape(-1, Fs).sum(0)
         dxo = dfu @ P["encoder.out_proj.proj.0.weight"]
+    Tq, npre = c["Tq"], c["npre"]
+    if npre:   # the stripped prefix positions get no gradient from the head
+        dxo = np.concatenate([np.zeros((B, npre, H), f), dxo], 1)
     dx, g["encoder.out_norm.weight"], g["encoder.out_norm.bias"] = layer_norm_bwd(dxo, c["xhat_o"], c["rstd_o"], P["encoder.out_norm.weight"])
     for l in range(L - 1, -1, -1):
         pre_ = f"encoder.layers.{l}."
@@ -348,7 +372,7 @@ def backward(c, grad_scale=1.0):
         g[pre_ + "attn.out_proj.weight"] = dx.reshape(-1, H).T @ lc["ad"].reshape(-1, H)
         g[pre_ + "attn.out_proj.bias"] = dx.reshape(-1, H).sum(0)
         da = (dx @ P[pre_ + "attn.out_proj.weight"]) * lc["am"]
-        da = da.reshape(B, Tp, nh, hd).transpose(0, 2, 1, 3)         # (B,nh,Tp,hd)
+        da = da.reshape(B, Tq, nh, hd).transpose(0, 2, 1, 3)         # (B,nh,Tq,hd)
         dv = lc["pd"].transpose(0, 1, 3, 2) @ da
         dpd = da @ lc["v"].transpose(0, 1, 3, 2)
         dp = dpd * lc["pm"]
@@ -361,19 +385,28 @@ def backward(c, grad_scale=1.0):
             dk = dk * cos + rotate_half_T(dk * sin)
 
         def merge(t):
-            return t.transpose(0, 2, 1, 3).reshape(B * Tp, H)
+            return t.transpose(0, 2, 1, 3).reshape(B * Tq, H)
 
         dq, dk, dv = merge(dq), merge(dk), merge(dv)
         h1 = lc["h1"].reshape(-1, H)
-        dh1 = np.zeros((B * Tp, H), f)
+        dh1 = np.zeros((B * Tq, H), f)
         for nm, dd in (("query", dq), ("key", dk), ("value", dv)):
             g[pre_ + f"attn.{nm}.weight"] = dd.T @ h1
             g[pre_ + f"attn.{nm}.bias"] = dd.sum(0)
             dh1 = dh1 + dd @ P[pre_ + f"attn.{nm}.weight"]
-        d1, g[pre_ + "ln1.weight"], g[pre_ + "ln1.bias"] = layer_norm_bwd(dh1.reshape(B, Tp, H), lc["xhat1"], lc["rstd1"], P[pre_ + "ln1.weight"])
+        d1, g[pre_ + "ln1.weight"], g[pre_ + "ln1.bias"] = layer_norm_bwd(dh1.reshape(B, Tq, H), lc["xhat1"], lc["rstd1"], P[pre_ + "ln1.weight"])
         dx = dx + d1
     # embedder (ndt1.py:160-203)
     dx0 = dx * c["ed"]
+    if npre:   # prefix token tables: scatter-add of their (dropout-masked) gradient rows; then continue with the spike tokens
+        k = 0
+        if cfg.get("day_token_days", 0):
+            gd_ = np.zeros_like(P["encoder.embedder.day_embedding.weight"]); np.add.at(gd_, c["day_sel"], dx0[:, k]); k += 1
+            g["encoder.embedder.day_embedding.weight"] = gd_
+        if cfg.get("block_token_blocks", 0):
+            gb_ = np.zeros_like(P["encoder.embedder.block_embedding.weight"]); np.add.at(gb_, c["block_sel"], dx0[:, k])
+            g["encoder.embedder.block_embedding.weight"] = gb_
+        dx0 = dx0[:, npre:]
     gpos = np.zeros_like(P["encoder.embedder.embed_pos.weight"])
     if cfg["pos"]:
         np.add.at(gpos, c["tts"].reshape(-1), dx0.reshape(-1, H))

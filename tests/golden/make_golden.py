@@ -68,7 +68,7 @@ def det(over):
     return o
 
 
-def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0, days=None):
+def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0, days=None, blocks=None):
     g = np.random.default_rng(seed)
     rows = []
     for i, (L, S) in enumerate(zip(lens, tgt_lens)):
@@ -76,6 +76,8 @@ def make_batch(model, lens, n_ch, tgt_lens, vocab, seed=0, days=None):
                      "phonemes_idx": g.integers(1, vocab, (S,)).astype(np.int64)})
         if days is not None:   # day-specific recordings (datasets.py:115-140 rows carry day_idx)
             rows[-1]["day_idx"] = np.asarray(days[i], dtype=np.int64)
+        if blocks is not None:
+            rows[-1]["block_idx"] = np.asarray(blocks[i], dtype=np.int64)
     ds = SpikingDatasetForDecoding(rows, targets_name="phonemes_idx")
     items = [ds[i] for i in range(len(ds))]
     names = list(inspect.signature(model.forward).parameters)
@@ -93,12 +95,12 @@ def summarise(t):
     return {"sum": float(a.sum()), "abssum": float(np.abs(a).sum()), "idx": idx, "val": a[idx].astype(np.float32)}
 
 
-def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2, days=None):
+def run_case(name, over, lens, tgt_lens, n_ch, vocab=41, full=False, steps=2, days=None, blocks=None):
     over = dict(over)
     over["_vocab"] = vocab
     ov = {k: v for k, v in over.items() if k != "_vocab"}
     model = build({**det(ov), "_vocab": vocab})
-    rows, batch, unused = make_batch(model, lens, n_ch, tgt_lens, vocab, days=days)
+    rows, batch, unused = make_batch(model, lens, n_ch, tgt_lens, vocab, days=days, blocks=blocks)
     fx = {}
     for k, v in batch.items():
         fx["in_" + k] = v.numpy()
@@ -241,6 +243,14 @@ def misc_cases():
         fx[f"ctx_{f}_{b}"] = create_context_mask(f, b, 24).numpy()
     np.savez_compressed(os.path.join(OUT, "misc_cases.npz"), **fx)
 
+
+if __name__ == "__main__" and "--tokens" in sys.argv:
+    # learned prefix tokens (ndt1.py:151-155,192-201,444-448): [day, block, spike tokens...], stripped after out_norm
+    run_case("g_tiny_tokens", tiny(embedder={"day_token": True, "block_token": True, "n_days": 3, "n_blocks": 4}), [30, 22, 17, 26],
+             [5, 4, 2, 3], 16, vocab=11, full=True, days=[2, 0, 2, 1], blocks=[3, 3, 0, 1])
+    run_case("g_tiny_daytoken", tiny(embedder={"day_token": True, "n_days": 3}, context={"forward": 3, "backward": 2}), [30, 22, 17],
+             [5, 4, 2], 16, vocab=11, full=True, days=[1, 1, 0])
+    sys.exit(0)
 
 if __name__ == "__main__" and "--adapt" in sys.argv:
     # embedder.adapt: one embed_spikes Linear per recording day, picked per sample by day_idx (ndt1.py:124-129,170-171)

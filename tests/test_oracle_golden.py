@@ -37,6 +37,10 @@ def cfg_from_json(js, vocab):
         kw["context_forward"], kw["context_backward"] = ctx["forward"], ctx["backward"]
     if emb.get("adapt", False):
         kw["adapt_days"] = emb["n_days"]
+    if emb.get("day_token", False):
+        kw["day_token_days"] = emb["n_days"]
+    if emb.get("block_token", False):
+        kw["block_token_blocks"] = emb["n_blocks"]
     fac = enc.get("factors", {})
     if fac.get("active", False):
         kw["factors_size"], kw["factors_act"], kw["factors_bias"] = fac["size"], fac.get("act", "relu"), fac.get("bias", True)
@@ -47,7 +51,7 @@ def batch_of(fx):
     return {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt", "g_tiny_tokens", "g_tiny_daytoken"])
 def test_tiny_forward_backward_adamw(name):
     fx = load(name)
     cfg = cfg_from_json(str(fx["config_json"]), 11)
