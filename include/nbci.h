@@ -252,6 +252,10 @@ typedef struct nbci_ndt1_config { /* configs/ndt1.yaml, flattened */
     /* embedder.adapt (models/ndt1.py:124-129,170-171): adapt_days > 0 = one embed_spikes Linear per recording day
      * ("encoder.embedder.embed_spikes.<d>.weight / .bias"), picked per sample by io.day_idx; 0 = one shared layer. */
     int32_t adapt_days;
+    /* embedder.day_token / block_token (models/ndt1.py:151-155,192-201,444-448): a learned token per recording day / block put in
+     * front of the spike tokens ([day, block, tokens...]), always attendable, dropped again after out_norm. Table sizes (n_days /
+     * n_blocks); 0 = off. io.day_idx / io.block_idx pick the rows. Not with use_rope (the reference fails there). */
+    int32_t day_token_days, block_token_blocks;
 } nbci_ndt1_config;
 
 typedef struct nbci_ndt1_io {
@@ -278,7 +282,8 @@ typedef struct nbci_ndt1_io {
                                            instead of the CTC gradient; decoder gradients are not touched. */
     void* workspace;
     int64_t workspace_bytes;
-    const int64_t* day_idx;             /* (B) recording day of each sample, 0 <= day < adapt_days; required when adapt_days > 0 */
+    const int64_t* day_idx;             /* (B) recording day of each sample; required when adapt_days > 0 or day_token_days > 0 */
+    const int64_t* block_idx;           /* (B) block of each sample; required when block_token_blocks > 0 */
 } nbci_ndt1_io;
 
 typedef void* nbci_ndt1_plan;

@@ -53,7 +53,8 @@ class NDT1Config(C.Structure):
         ("embed_act", C.c_int32), ("mlp_act", C.c_int32), ("embed_dropout", C.c_float), ("dropout", C.c_float),
         ("use_rope", C.c_int32), ("rope_theta", C.c_float), ("context_forward", C.c_int32), ("context_backward", C.c_int32),
         ("pos", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32), ("dtype", C.c_int32),
-        ("factors_size", C.c_int32), ("factors_act", C.c_int32), ("factors_bias", C.c_int32), ("adapt_days", C.c_int32)]
+        ("factors_size", C.c_int32), ("factors_act", C.c_int32), ("factors_bias", C.c_int32), ("adapt_days", C.c_int32),
+        ("day_token_days", C.c_int32), ("block_token_blocks", C.c_int32)]
 
 
 class NDT1IO(C.Structure):
@@ -64,7 +65,7 @@ class NDT1IO(C.Structure):
                 ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
                 ("preds", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
                 ("token_mask_out", C.c_void_p), ("d_hidden", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("day_idx", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("day_idx", C.c_void_p), ("block_idx", C.c_void_p)]
 
 
 class MaskerDesc(C.Structure):

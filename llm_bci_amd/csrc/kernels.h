@@ -20,7 +20,12 @@ int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, in
 
 // models/ndt1.py:181-183,207-208 — token mask (prod over window), first-T' timestamps, stacked lens
 int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp,
-                      int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s);
+                      int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s, int npre = 0);
+// learned prefix tokens (day / block, ndt1.py:192-203): assemble [prefix rows | spike tokens] + embedder dropout; table gradients
+int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, float* x,
+                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+int prefix_grad_launch(const float* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
+                       uint32_t site, hipStream_t s);
 
 // nn.LayerNorm (eps 1e-5, affine) forward: x f32 (M,H) -> y act dtype, saves mean/rstd
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean,
@@ -58,7 +63,7 @@ int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype
                           int size, int stride, int act, hipStream_t s);
 // dpos[tts[row]][:] += dx[row][:] * keepmask  (nn.Embedding backward + embed dropout)
 int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
-                   uint32_t site, hipStream_t s);
+                   uint32_t site, hipStream_t s, int Tp = 0, int npre = 0);
 
 // RoPE on the q and k thirds of a packed (M, 3H) qkv buffer, in place (ndt1.py:62-71); inverse = backward
 int rope_launch(void* qkv, int dtype, const int64_t* tts, const float* cos_t, const float* sin_t, int M, int H,

@@ -124,16 +124,18 @@ int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, in
 // ------------------------------------------------------------------------------------------
 // token prep
 // ------------------------------------------------------------------------------------------
+// tmask is (B, npre + Tp): the npre learned prefix tokens (day / block, ndt1.py:192-201) are always valid keys
 __global__ void token_prep_kernel(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp,
-                                  int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens) {
+                                  int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, int npre) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * Tp) {
         const int b = i / Tp, j = i % Tp;
         int64_t prod = 1;
         for (int r = 0; r < size; ++r) prod *= mask[(long long)b * T + j * stride + r];
-        tmask[i] = prod != 0 ? 1 : 0;
+        tmask[(long long)b * (Tp + npre) + npre + j] = prod != 0 ? 1 : 0;
         tts[i] = ts[(long long)b * T + j];
     }
+    if (i < B * npre) tmask[(long long)(i / npre) * (Tp + npre) + i % npre] = 1;
     if (i < B) {
         // (1 + (len - size) / stride) in floating point, truncating cast (ndt1.py:208)
         const double v = 1.0 + ((double)lens[i] - (double)size) / (double)stride;
@@ -142,11 +144,62 @@ __global__ void token_prep_kernel(const int64_t* mask, const int64_t* ts, const 
 }
 
 int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp, int size,
-                      int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s) {
-    const int n = max(B * Tp, B);
+                      int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s, int npre) {
+    const int n = max(max(B * Tp, B), B * npre);
     hipLaunchKernelGGL(token_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, ts, lens, B, T, Tp, size, stride,
-                       tmask, tts, tlens);
+                       tmask, tts, tlens, npre);
     return check_launch("token_prep");
+}
+
+// prefix tokens, forward: x (B, npre + Tp, H) = [table0[idx0[b]], (table1[idx1[b]]), xtok[b, :]] then the embedder dropout over ALL of
+// it (ndt1.py:192-203), dropout stream index = element offset in x
+__global__ __launch_bounds__(256) void prefix_assemble_kernel(const float* __restrict__ xtok, const float* __restrict__ tab0,
+                                                              const int64_t* __restrict__ idx0, const float* __restrict__ tab1,
+                                                              const int64_t* __restrict__ idx1, float* __restrict__ x, int B, int Tp, int npre,
+                                                              int H, unsigned thr, float dscale, uint32_t key) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long total = (long long)B * (Tp + npre) * H;
+    if (i >= total) return;
+    const int c = (int)(i % H);
+    const long long row = i / H;
+    const int b = (int)(row / (Tp + npre)), j = (int)(row % (Tp + npre));
+    const float* src;
+    if (j >= npre) src = xtok + ((long long)b * Tp + (j - npre)) * H + c;
+    else if (j == 0) src = tab0 + idx0[b] * H + c;
+    else src = tab1 + idx1[b] * H + c;
+    const float4 a = *(const float4*)src;
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (thr) drop4(key, thr, (unsigned)i, dscale, v);
+    *(float4*)(x + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, float* x,
+                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+    NBCI_REQUIRE(xtok && tab0 && idx0 && x && npre >= 1 && npre <= 2 && H % 4 == 0 && (npre == 1 || (tab1 && idx1)), NBCI_EINVAL,
+                 "prefix_assemble: bad argument");
+    const long long n4 = (long long)B * (Tp + npre) * H / 4;
+    hipLaunchKernelGGL(prefix_assemble_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, xtok, tab0, idx0, tab1, idx1, x, B, Tp,
+                       npre, H, drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site));
+    return check_launch("prefix_assemble");
+}
+
+// prefix tokens, backward: table[idx[b]] += dropout-masked dx[b, k, :] for the k-th prefix position
+__global__ __launch_bounds__(256) void prefix_grad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ idx, float* __restrict__ dtab,
+                                                          int B, int Tt, int k, int H, unsigned thr, float dscale, uint32_t key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, c = i % H;
+    const long long o = ((long long)b * Tt + k) * H + c;
+    float v = dx[o];
+    if (thr) v = drop_keep(key, thr, (unsigned)o) ? v * dscale : 0.f;
+    if (v != 0.f) atomicAdd(dtab + idx[b] * H + c, v);
+}
+
+int prefix_grad_launch(const float* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
+                       uint32_t site, hipStream_t s) {
+    hipLaunchKernelGGL(prefix_grad_kernel, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, dx, idx, dtab, B, Tt, k, H,
+                       drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site));
+    return check_launch("prefix_grad");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -289,7 +342,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
                     const long long io = cz.rpg > 0 ? ((long long)(r / cz.rpg) * cz.gpitch + cz.goff + r % cz.rpg) * H + c : i;
                     if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + io) = ov; }
                     else *(float4*)((float*)cz.out + io) = make_float4(v[0], v[1], v[2], v[3]);
-                    gc[k].x += v[0]; gc[k].y += v[1]; gc[k].z += v[2]; gc[k].w += v[3];
+                    if (cz.nskip == 0 || (r % cz.rpg) >= cz.nskip) {   // (prefix-token rows do not feed the consumer's bias gradient)
+                        gc[k].x += v[0]; gc[k].y += v[1]; gc[k].z += v[2]; gc[k].w += v[3];
+                    }
                 }
             }
         }
@@ -621,24 +676,26 @@ int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype
     return check_launch("col2im_actgrad");
 }
 
+// M = B * Tp spike-token rows; dx holds npre extra prefix rows in front of every sample's Tp (0 = none)
 __global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tts,
                                                       float* __restrict__ dpos, int M, int H, unsigned thr, float dscale,
-                                                      uint32_t key) {
+                                                      uint32_t key, int Tp, int npre) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), c = (int)(i % H);
-    float v = dx[i];
-    if (thr) v = drop_keep(key, thr, (unsigned)i) ? v * dscale : 0.f;
+    const long long o = npre ? ((long long)(row / Tp) * (Tp + npre) + npre + row % Tp) * H + c : i;
+    float v = dx[o];
+    if (thr) v = drop_keep(key, thr, (unsigned)o) ? v * dscale : 0.f;
     if (v != 0.f) atomicAdd(dpos + tts[row] * H + c, v);
 }
 
 int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
-                   uint32_t site, hipStream_t s) {
+                   uint32_t site, hipStream_t s, int Tp, int npre) {
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const long long total = (long long)M * H;
     hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, tts, dpos, M, H, thr,
-                       dscale, drop_key(seed, site));
+                       dscale, drop_key(seed, site), Tp > 0 ? Tp : 1, npre);
     return check_launch("posgrad");
 }
 

@@ -104,7 +104,7 @@ __device__ __forceinline__ float* rep_ptr(float* p, RepCfg rc, unsigned blk) {
 
 // optional fused tail of the LayerNorm backward: out = dropout(dx_new) in the GEMM operand dtype,
 // colsum += column sums of out (the bias gradient of the Linear that produced the residual branch)
-struct LnCast { void* out; int bf16; unsigned thr; float scale; uint32_t key; float* colsum; int rpg, gpitch, goff; };   // rpg > 0: output row remap (kernels.hip ln_bwd)
+struct LnCast { void* out; int bf16; unsigned thr; float scale; uint32_t key; float* colsum; int rpg, gpitch, goff, nskip; };   // nskip: first rows of every rpg-row group left out of colsum   // rpg > 0: output row remap (kernels.hip ln_bwd)
 
 // ---- wave64 reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -29,6 +29,7 @@ struct Plan {
     std::vector<LayerOff> L;
     int64_t embw, embb, stkw, stkb, pos, onw, onb, decw, decb;
     int64_t facw = -1, facb = -1;   // factors projection (head segment), -1 = absent
+    int64_t dayemb = -1, blkemb = -1;   // prefix-token tables (embedder segment)
     int64_t day_stride = 0;         // adapt: elements between consecutive days' embed layers (weight and bias alike)
     int64_t total;
     std::vector<std::pair<int64_t, int64_t>> seg;  // [begin,end) per segment
@@ -75,6 +76,8 @@ static void build_layout(Plan& p) {
     p.stkw = add_param(p, cur, "encoder.embedder.stack_projection.weight", H, D * c.stack_size, 0);
     p.stkb = add_param(p, cur, "encoder.embedder.stack_projection.bias", H, 0, 0);
     p.pos = c.pos ? add_param(p, cur, "encoder.embedder.embed_pos.weight", c.max_F, H, 0) : -1;
+    if (c.block_token_blocks > 0) p.blkemb = add_param(p, cur, "encoder.embedder.block_embedding.weight", c.block_token_blocks, H, 0);
+    if (c.day_token_days > 0) p.dayemb = add_param(p, cur, "encoder.embedder.day_embedding.weight", c.day_token_days, H, 0);
     cur = (cur + PALIGN - 1) / PALIGN * PALIGN;
     p.seg.push_back({0, cur});
     for (int l = 0; l < c.n_layers; ++l) {
@@ -147,10 +150,12 @@ struct WS {
     size_t wsel, rsel, wpart, bpart;   // adapt: per-sample day weights (B,D,N), row -> day table (B*T), per-sample weight / bias gradients
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
     size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
+    size_t xtok;                       // (prefix tokens) stack-projection output of the spike tokens before the prefix rows are put in front
     size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
     int phase_ok, Q, P, npad;          // Q = T / stride output groups, P = Q + size/stride - 1 padded rows, npad = size/stride - 1
     size_t bytes;
     int Tp, M, ldS, ldP, vpad;
+    int npre, Tt, Mk;                  // learned prefix tokens per sequence (day / block), Tt = npre + Tp tokens in the transformer (M = B*Tt rows), Mk = B*Tp
 };
 
 static int carve(const Plan& p, int B, int T, int S, WS& w) {
@@ -159,10 +164,11 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     const int Tp = 1 + (T - c.stack_size) / c.stack_stride;
     NBCI_REQUIRE(Tp <= c.max_F && Tp <= 1024, NBCI_ESHAPE, "ndt1: more tokens than max_F / 1024");
     const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
-    const size_t M = (size_t)B * Tp, H = c.hidden, I = c.inter, D = c.input_dim;
-    w.Tp = Tp; w.M = (int)M;
-    w.ldS = (Tp + 3) / 4 * 4;
-    w.ldP = (Tp + 7) / 8 * 8;
+    const int npre = (c.day_token_days > 0 ? 1 : 0) + (c.block_token_blocks > 0 ? 1 : 0), Tt = Tp + npre;
+    const size_t M = (size_t)B * Tt, Mk = (size_t)B * Tp, H = c.hidden, I = c.inter, D = c.input_dim;
+    w.Tp = Tp; w.M = (int)M; w.npre = npre; w.Tt = Tt; w.Mk = (int)Mk;
+    w.ldS = (Tt + 3) / 4 * 4;
+    w.ldP = (Tt + 7) / 8 * 8;
     w.vpad = (c.vocab + 7) / 8 * 8;
     size_t cur = 0;
     w.xs = bump(cur, (size_t)B * T * c.n_channels * es);
@@ -173,11 +179,12 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
         w.wpart = bump(cur, (size_t)B * D * c.n_channels * 4);
         w.bpart = bump(cur, (size_t)B * D * 4);
     }
+    w.xtok = npre ? bump(cur, Mk * H * 4) : 0;
     w.tmask = bump(cur, M * 4);
     w.tts = bump(cur, M * 8);
     w.tlens = bump(cur, (size_t)B * 4);
     w.L.resize(c.n_layers);
-    const size_t nP = (size_t)B * c.n_heads * Tp * w.ldP;
+    const size_t nP = (size_t)B * c.n_heads * Tt * w.ldP;
     for (auto& l : w.L) {
         l.x_in = bump(cur, M * H * 4);
         l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
@@ -186,7 +193,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
         l.P = bump(cur, nP * es);
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * H * es);
-        l.lse = bump(cur, (size_t)B * c.n_heads * Tp * 4);
+        l.lse = bump(cur, (size_t)B * c.n_heads * Tt * 4);
         l.x_mid = bump(cur, M * H * 4);
         l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
         l.h2 = bump(cur, M * H * es);
@@ -205,7 +212,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.alpha = bump(cur, ctc_alpha_floats(B, Tp, S > 0 ? S : 1) * 4);
     w.dlogits = bump(cur, M * w.vpad * es);
     w.argmax = bump(cur, M * 4);
-    w.scores = bump(cur, (size_t)B * c.n_heads * Tp * w.ldS * 4);
+    w.scores = bump(cur, (size_t)B * c.n_heads * Tt * w.ldS * 4);
     w.dx = bump(cur, M * H * 4);
     w.dtmp = bump(cur, M * H * 4);
     w.dA = bump(cur, M * H * es);
@@ -216,7 +223,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.dS = bump(cur, nP * es);
     // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
     w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
-                  (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0) ? 1 : 0;
+                  (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0 && npre == 0) ? 1 : 0;
     { static const bool off = [] { const char* e = getenv("NBCI_PHASE_DGRAD"); return e && e[0] == '0'; }(); if (off) w.phase_ok = 0; }
     w.Q = T / c.stack_stride; w.npad = c.stack_size / c.stack_stride - 1; w.P = w.Q + w.npad;
     w.dAp = w.phase_ok ? bump(cur, (size_t)B * w.P * H * es) : 0;
@@ -262,18 +269,21 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "ndt1: workspace too small");
     NBCI_REQUIRE(io->preds, NBCI_EINVAL, "ndt1: preds output is required");
     const WS& w = x.w;
-    const int Tp = w.Tp, M = w.M, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh;
+    // Tk spike tokens per sample; Tp = npre + Tk tokens in the transformer once the learned prefix tokens (day / block) are in front
+    const int Tk = w.Tp, Tp = w.Tt, npre = w.npre, M = w.M, Mk = w.Mk, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh;
     const int dt = c.dtype;
     const size_t es = x.es;
     const bool train = io->train != 0;
     const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
     char* ws = x.ws;
+    NBCI_REQUIRE(c.day_token_days == 0 || io->day_idx, NBCI_EINVAL, "ndt1: embedder.day_token needs day_idx");
+    NBCI_REQUIRE(c.block_token_blocks == 0 || io->block_idx, NBCI_EINVAL, "ndt1: embedder.block_token needs block_idx");
 
     if (io->want_grad)  // replicated small-gradient accumulators start each step at zero
         NBCI_CHECK_HIP(hipMemsetAsync(ws + w.rep, 0, (size_t)NREP * p.compact_total * 4, s));
     // 0. token bookkeeping + smoothing/noise (ndt1.py:92-107,181-183,207-208)
-    TRY(token_prep_launch(io->spikes_mask, io->spikes_timestamp, io->spikes_lengths, B, T, Tp, c.stack_size, c.stack_stride,
-                          (int32_t*)(ws + w.tmask), (int64_t*)(ws + w.tts), (int32_t*)(ws + w.tlens), s));
+    TRY(token_prep_launch(io->spikes_mask, io->spikes_timestamp, io->spikes_lengths, B, T, Tk, c.stack_size, c.stack_stride,
+                          (int32_t*)(ws + w.tmask), (int64_t*)(ws + w.tts), (int32_t*)(ws + w.tlens), s, npre));
     const bool noise = train && c.noise;
     TRY(smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
                             noise ? c.constant_offset_sd : 0.f, io->seed, s));
@@ -301,14 +311,22 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     float* x_cur = (float*)(ws + (c.n_layers ? w.L[0].x_in : w.x_last));
     {
         const int KS = c.stack_size * D;
-        nbci_gemm_desc d = gd(M, H, KS, dt, op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 1, Tp, (int64_t)T * D),
-                              op(x.W(p.stkw), es, 0, KS, 1), x_cur, H, NBCI_F32);
+        // with prefix tokens the spike tokens go to a side buffer first: the prefix rows are put in front and the embedder dropout is
+        // drawn over the whole (B, npre + T', H) block afterwards
+        nbci_gemm_desc d = gd(Mk, H, KS, dt, op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 1, Tk, (int64_t)T * D),
+                              op(x.W(p.stkw), es, 0, KS, 1), npre ? (float*)(ws + w.xtok) : x_cur, H, NBCI_F32);
         d.bias = params + p.stkb;
         if (c.pos) {
             d.residual = params + p.pos; d.ldr = H; d.residual_rows = (const int64_t*)(ws + w.tts); d.residual_first = 1;
         }
-        d.drop_p = p_emb; d.seed = io->seed; d.site = 3;
+        if (!npre) { d.drop_p = p_emb; d.seed = io->seed; d.site = 3; }
         TRY(gemm_launch_timed(d, s));
+        if (npre) {   // [day, block, tokens...] (ndt1.py:192-201: the block token is prepended first, then the day token)
+            const float* tab0 = params + (c.day_token_days > 0 ? p.dayemb : p.blkemb);
+            const int64_t* idx0 = c.day_token_days > 0 ? io->day_idx : io->block_idx;
+            TRY(prefix_assemble_launch((const float*)(ws + w.xtok), tab0, idx0, npre == 2 ? params + p.blkemb : nullptr,
+                                       npre == 2 ? io->block_idx : nullptr, x_cur, B, Tk, npre, H, p_emb, io->seed, 3, s));
+        }
     }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -384,21 +402,26 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         TRY(gemm_launch_timed(d, s));
         enc_out = ws + w.fo;
     }
-    {
-        nbci_gemm_desc d = gd(M, c.vocab, Kd, dt, op(enc_out, es, 0, Kd, 1), op(x.W(p.decw), es, 0, Kd, 1), ws + w.logits,
-                              w.vpad, NBCI_F32);
+    {   // decoder on the spike tokens only: the prefix tokens are dropped after out_norm (ndt1.py:444-448) -> one GEMM per sample block
+        nbci_gemm_desc d = npre ? gd(Tk, c.vocab, Kd, dt, op(enc_out, es, (int64_t)npre * Kd, Kd, 1, 0, 0, (int64_t)Tp * Kd),
+                                     op(x.W(p.decw), es, 0, Kd, 1), ws + w.logits, w.vpad, NBCI_F32)
+                                : gd(M, c.vocab, Kd, dt, op(enc_out, es, 0, Kd, 1), op(x.W(p.decw), es, 0, Kd, 1), ws + w.logits,
+                                     w.vpad, NBCI_F32);
+        if (npre) { d.batch = B; d.zdiv = 1; d.czs1 = (int64_t)Tk * w.vpad; }
         d.bias = params + p.decb;
         TRY(gemm_launch_timed(d, s));
     }
     int32_t* amax = io->argmax ? io->argmax : (int32_t*)(ws + w.argmax);
-    TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, M, c.vocab, s));
-    if (io->token_mask_out)
-        NBCI_CHECK_HIP(hipMemcpyAsync(io->token_mask_out, ws + w.tmask, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+    TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, Mk, c.vocab, s));
+    if (io->token_mask_out)   // (B,T'): the spike tokens' validity (the reference's mask also carries the prefix ones; its x does not)
+        NBCI_CHECK_HIP(hipMemcpy2DAsync(io->token_mask_out, (size_t)Tk * 4, ws + w.tmask + (size_t)npre * 4, (size_t)Tp * 4, (size_t)Tk * 4, B,
+                                        hipMemcpyDeviceToDevice, s));
     if (io->hidden_out)  // optional copy-out of the encoder output (B,T',H) for BCI-style couplers
-        NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, enc_out, (size_t)M * Kd * es, hipMemcpyDeviceToDevice, s));
+        NBCI_CHECK_HIP(hipMemcpy2DAsync(io->hidden_out, (size_t)Tk * Kd * es, (const char*)enc_out + (size_t)npre * Kd * es, (size_t)Tp * Kd * es,
+                                        (size_t)Tk * Kd * es, B, hipMemcpyDeviceToDevice, s));
     if (io->targets) {
         NBCI_REQUIRE(io->targets_lengths && io->loss && S > 0, NBCI_EINVAL, "ndt1: targets need targets_lengths, loss and S > 0");
-        TRY(ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tp, c.vocab, S, c.blank_id,
+        TRY(ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tk, c.vocab, S, c.blank_id,
                        c.zero_infinity, io->loss, (float*)(ws + w.alpha), io->want_grad ? ws + w.dlogits : nullptr, dt, w.vpad,
                        io->grad_scale, s));
     }
@@ -420,7 +443,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     TRY(carve(p, B, T, S, x.w));
     NBCI_REQUIRE((size_t)io->workspace_bytes >= x.w.bytes, NBCI_EWORKSPACE, "ndt1: workspace too small");
     const WS& w = x.w;
-    const int Tp = w.Tp, M = w.M, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh, V = c.vocab;
+    const int Tk = w.Tp, Tp = w.Tt, npre = w.npre, M = w.M, Mk = w.Mk;   // (see ndt1_forward)
+    const int H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh, V = c.vocab;
     const int dt = c.dtype;
     const size_t es = x.es;
     const bool train = io->train != 0;
@@ -434,16 +458,19 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };  // replica-0 slot of a 1-D param's grad
     // The f32 gradient stream dx is consumed by GEMMs in the operand dtype: the LayerNorm backward that
     // finalises dx also writes that (dropout-masked) copy into ws.dA and sums its columns (bias grad).
-    const bool need_cast = !(dt == NBCI_F32 && p_lay == 0.f && p_emb == 0.f);
+    const bool need_cast = !(dt == NBCI_F32 && p_lay == 0.f && p_emb == 0.f) || npre > 0;   // (prefix tokens: the cast also keeps their rows out of the bias sums)
     auto cast_for = [&](int layer_below) -> LnCast {   // consumer = MLP backward of `layer_below`, or the embedder if < 0
         if (!need_cast) return LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr};
         const float pp = layer_below >= 0 ? p_lay : p_emb;
         const uint32_t site = layer_below >= 0 ? 18 + 4 * layer_below : 3;
         if (layer_below < 0 && w.phase_ok)   // the embedder's phase GEMMs read zero-padded sample blocks
             return LnCast{ws + w.dAp, 1, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site), RG(p.stkb),
-                          Tp, w.P, w.npad};
+                          Tk, w.P, w.npad, 0};
+        if (layer_below < 0 && npre > 0)     // same layout, but the prefix-token rows stay out of the stack-projection bias gradient
+            return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
+                          RG(p.stkb), Tp, Tp, 0, npre};
         return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
-                      RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb), 0, 0, 0};
+                      RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb), 0, 0, 0, 0};
     };
 
     for (int seg = seg_hi; seg >= seg_lo; --seg) {
@@ -453,17 +480,34 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             int d_xo_lp = (dt == NBCI_BF16) ? 1 : 0;
             const int FS = c.factors_size, Kd = FS > 0 ? FS : H;
             const void* enc_out = FS > 0 ? ws + w.fo : ws + w.xo;
+            NBCI_REQUIRE(!(io->d_hidden && FS > 0 && npre > 0), NBCI_EINVAL, "ndt1: external encoder gradient with factors AND prefix tokens is not supported");
             if (io->d_hidden && FS == 0) {
-                d_xo = io->d_hidden; d_xo_lp = 0;
+                if (npre) {   // (B,T',H) gradient of the stripped output -> the (B, npre + T', H) layout, prefix rows zero
+                    NBCI_CHECK_HIP(hipMemsetAsync(dtmp, 0, (size_t)M * H * 4, s));
+                    NBCI_CHECK_HIP(hipMemcpy2DAsync((char*)dtmp + (size_t)npre * H * 4, (size_t)Tp * H * 4, io->d_hidden, (size_t)Tk * H * 4,
+                                                    (size_t)Tk * H * 4, B, hipMemcpyDeviceToDevice, s));
+                } else {
+                    d_xo = io->d_hidden;
+                }
+                d_xo_lp = 0;
             } else {
                 if (!io->d_hidden) {   // decoder Linear: bias / weight gradients, then d(encoder output) = dlogits W_d
                     const void* dl = ws + w.dlogits;
-                    TRY(colsum_launch(dl, dt, w.vpad, M, V, RG(p.decb), s, rc));
-                    TRY(wgrad(s, dt, V, Kd, M, op(dl, es, 0, w.vpad, 0), op(enc_out, es, 0, Kd, 0), grads + p.decw, Kd));
-                    nbci_gemm_desc d = gd(M, Kd, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, Kd, 0), FS > 0 ? (void*)(ws + w.dfo) : (void*)dtmp,
-                                          Kd, dt);
+                    TRY(colsum_launch(dl, dt, w.vpad, Mk, V, RG(p.decb), s, rc));
+                    TRY(wgrad(s, dt, V, Kd, Mk, op(dl, es, 0, w.vpad, 0),
+                              npre ? op(enc_out, es, (int64_t)npre * Kd, Kd, 0, Tk, (int64_t)Tp * Kd) : op(enc_out, es, 0, Kd, 0), grads + p.decw, Kd));
+                    char* tgt = FS > 0 ? ws + w.dfo : (char*)dtmp;
+                    nbci_gemm_desc d;
+                    if (npre) {   // spike-token rows only (one GEMM per sample block); the prefix rows of the target stay zero
+                        NBCI_CHECK_HIP(hipMemsetAsync(tgt, 0, (size_t)M * Kd * es, s));
+                        d = gd(Tk, Kd, V, dt, op(dl, es, 0, w.vpad, 1, 0, 0, (int64_t)Tk * w.vpad), op(x.W(p.decw), es, 0, Kd, 0),
+                               tgt + (size_t)npre * Kd * es, Kd, dt);
+                        d.batch = B; d.zdiv = 1; d.czs1 = (int64_t)Tp * Kd;
+                    } else {
+                        d = gd(M, Kd, V, dt, op(dl, es, 0, w.vpad, 1), op(x.W(p.decw), es, 0, Kd, 0), tgt, Kd, dt);
+                    }
                     if (FS > 0) {   // through the factors activation: * act'(pre-activation), + the factors bias gradient
-                        d.gate = ws + w.fgate; d.ldg = FS; d.gate_act = -1;
+                        d.gate = ws + w.fgate + (size_t)npre * FS * es; d.ldg = FS; d.gate_act = -1; d.gate_follows_c = 1;
                         if (p.facb >= 0) { d.colsum = RG(p.facb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n; }
                     }
                     TRY(gemm_launch_timed(d, s));
@@ -587,12 +631,20 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             } else {
                 dx0 = ws + w.dA;
             }
-            if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, M, H, p_emb, io->seed, 3, s));
+            if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre));
+            if (npre) {   // the prefix tokens' tables: [day, block] order as assembled in the forward
+                int k = 0;
+                if (c.day_token_days > 0) TRY(prefix_grad_launch(dx, io->day_idx, grads + p.dayemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
+                if (c.block_token_blocks > 0) TRY(prefix_grad_launch(dx, io->block_idx, grads + p.blkemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
+            }
+            // the spike-token rows of dx0: all of it, or (prefix tokens) a view that skips the first npre rows of every sample block
+            const nbci_operand dx0_km = npre ? op(dx0, es, (int64_t)npre * H, H, 1, Tk, (int64_t)Tp * H) : op(dx0, es, 0, H, 1);
+            const nbci_operand dx0_rm = npre ? op(dx0, es, (int64_t)npre * H, H, 0, Tk, (int64_t)Tp * H) : op(dx0, es, 0, H, 0);
             if (w.phase_ok) {
                 // dx0 sits in zero-padded sample blocks (B, P, H): token j of sample b at row b*P + npad + j.
                 const int st = c.stack_stride, nwin = c.stack_size / st;
-                TRY(wgrad(s, dt, H, KS, M, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tp, (int64_t)w.P * H),
-                          op(ws + w.y, es, 0, (int64_t)st * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
+                TRY(wgrad(s, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
+                          op(ws + w.y, es, 0, (int64_t)st * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
                 // d pre-activation WITHOUT the (M, size*D) window-gradient tensor and its col2im pass. The st bins t = st*q + ph of
                 // group q collect  sum_{i < nwin} dx0[q - i] . W_s[:, D*(st*i + ph) .. + D]; with n = D*ph + c and i' = nwin-1-i that
                 // is ONE GEMM: rows (b, q), N = st*D, a contraction over k = (i', h) of the nwin consecutive padded rows q .. q+nwin-1
@@ -605,13 +657,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 d.gate = ws + w.y; d.ldg = (int64_t)st * D; d.gate_act = 64 + c.embed_act;
                 TRY(gemm_launch_timed(d, s));
             } else {
-            TRY(wgrad(s, dt, H, KS, M, op(dx0, es, 0, H, 0),
-                      op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tp, (int64_t)T * D), grads + p.stkw, KS));
-            {   // dwin = dx0 W_s  (M, S*D)
-                nbci_gemm_desc d = gd(M, KS, H, dt, op(dx0, es, 0, H, 1), op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
+            TRY(wgrad(s, dt, H, KS, Mk, dx0_rm,
+                      op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
+            {   // dwin = dx0 W_s  (B*T', S*D)
+                nbci_gemm_desc d = gd(Mk, KS, H, dt, dx0_km, op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tp, D, c.stack_size, c.stack_stride,
+            TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tk, D, c.stack_size, c.stack_stride,
                                       c.embed_act, s));
             }
             if (c.adapt_days > 0) {   // per-sample partial gradients (batched), then a deterministic scatter into the days' rows
@@ -653,6 +705,9 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
                  "bad NDT1 shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
     NBCI_REQUIRE(c.adapt_days >= 0 && c.adapt_days <= 4096, NBCI_EINVAL, "adapt_days out of range");
+    NBCI_REQUIRE(c.day_token_days >= 0 && c.block_token_blocks >= 0, NBCI_EINVAL, "token table sizes must be >= 0");
+    NBCI_REQUIRE(!(c.use_rope && (c.day_token_days > 0 || c.block_token_blocks > 0)), NBCI_EINVAL,
+                 "rope with day / block tokens: the reference hands T' timestamps to T'+n tokens (ndt1.py:181,441) and fails; not supported");
     NBCI_REQUIRE(c.factors_size >= 0 && c.factors_size % 8 == 0, NBCI_ESHAPE, "factors size must be a multiple of 8 (0 = no factors projection)");
     NBCI_REQUIRE(c.blank_id >= 0 && c.blank_id < c.vocab, NBCI_EINVAL, "blank_id out of range");
     NBCI_REQUIRE(!(c.use_rope && ((c.hidden / c.n_heads) % 2)), NBCI_ESHAPE, "rope needs an even head size");

@@ -6,6 +6,9 @@ same constructor `(config, **kwargs)`, same forward keyword names, returns `NDT1
 same checkpoint files. Underneath, all parameters are views into ONE flat f32 buffer (plus a
 bf16 shadow in bf16 mode) so the C side sees a single pointer, AdamW is one fused launch and
 each backward segment's gradients are one contiguous RCCL bucket.
+Config options of configs/ndt1.yaml beyond the defaults that run on the HIP path: context spans, RoPE,
+`embedder.adapt` (day-specific embed layers), `embedder.day_token / block_token` (learned prefix tokens),
+`factors.active` (NeuralFactorsProjection); inputs `day_idx` / `block_idx` as in the reference's forward.
 
 There is no CPU execution path: forward raises NbciUnavailable without the HIP library / a GPU.
 """
@@ -78,8 +81,10 @@ class NDT1(nn.Module):
             if m.get("active", False):
                 raise Exception("active Masker is only meaningful for mlm; not supported on the ctc HIP path")
         emb, tr = enc.embedder, enc.transformer
-        if not emb.stack.active or emb.day_token or emb.block_token:
-            raise Exception("HIP path supports embedder.stack.active=true, day_token/block_token=false")
+        if not emb.stack.active:
+            raise Exception("HIP path supports embedder.stack.active=true")
+        if (emb.day_token or emb.block_token) and tr.use_rope:
+            raise Exception("use_rope with day / block tokens: the reference hands T' timestamps to T'+n tokens (ndt1.py:181,441) and fails")
         fac = enc.factors
         if fac.active and float(fac.dropout) != 0.0:
             raise Exception("HIP path supports factors.dropout = 0 (the yaml default) when factors.active")
@@ -112,6 +117,9 @@ class NDT1(nn.Module):
         c.factors_bias = 1 if (fac.active and fac.bias) else 0
         # embedder.adapt: one embed_spikes Linear per recording day (ndt1.py:124-129), picked per sample by day_idx
         c.adapt_days = int(emb.n_days) if emb.adapt else 0
+        # learned prefix tokens (ndt1.py:151-155,192-201): [day, block, spike tokens...], dropped after out_norm
+        c.day_token_days = int(emb.n_days) if emb.day_token else 0
+        c.block_token_blocks = int(emb.n_blocks) if emb.block_token else 0
         self._ccfg = c
         self.config = config
         self.vocab_size = kwargs["vocab_size"]
@@ -159,6 +167,10 @@ class NDT1(nn.Module):
         add("encoder.embedder.stack_projection.bias", (H,), 0)
         if c.pos:
             add("encoder.embedder.embed_pos.weight", (c.max_F, H), 0)
+        if c.block_token_blocks > 0:
+            add("encoder.embedder.block_embedding.weight", (c.block_token_blocks, H), 0)
+        if c.day_token_days > 0:
+            add("encoder.embedder.day_embedding.weight", (c.day_token_days, H), 0)
         cur = (cur + 7) // 8 * 8
         self._segments = [(0, cur)]
         for l in range(c.n_layers):
@@ -215,6 +227,10 @@ class NDT1(nn.Module):
         linear("encoder.embedder.stack_projection", D * c.stack_size, H)
         if c.pos:
             put("encoder.embedder.embed_pos.weight", nn.Embedding(c.max_F, H).weight)
+        if c.block_token_blocks > 0:   # construction order of NeuralEmbeddingLayer.__init__ (ndt1.py:148-155)
+            put("encoder.embedder.block_embedding.weight", nn.Embedding(c.block_token_blocks, H).weight)
+        if c.day_token_days > 0:
+            put("encoder.embedder.day_embedding.weight", nn.Embedding(c.day_token_days, H).weight)
         tr = self.config["encoder"]["transformer"]
         fix = 0.67 * (L ** (-1.0 / 4.0)) if tr["fixup_init"] and L > 0 else None
         vpre = (2 ** 0.5) if fix is not None else None
@@ -377,19 +393,23 @@ class NDT1(nn.Module):
         io.token_mask_out = _ptr(token_mask_out)
         io.d_hidden = None
         io.workspace, io.workspace_bytes = _ptr(ws), need
-        days = None
-        if self._ccfg.adapt_days > 0:   # day-specific embed layers (ndt1.py:170-171)
-            days = batch.get("day_idx")
-            if days is None:
-                raise ValueError("embedder.adapt is on: forward needs day_idx (the recording day of every sample)")
-            days = days.reshape(-1).contiguous().long()
-            if days.numel() != B:
-                raise ValueError(f"day_idx has {days.numel()} entries for a batch of {B}")
-        io.day_idx = _ptr(days)
+        def _index(name, need, why):
+            t = batch.get(name)
+            if not need:
+                return None
+            if t is None:
+                raise ValueError(f"{why}: forward needs {name} (one entry per sample)")
+            t = t.reshape(-1).contiguous().long()
+            if t.numel() != B:
+                raise ValueError(f"{name} has {t.numel()} entries for a batch of {B}")
+            return t
+        days = _index("day_idx", self._ccfg.adapt_days > 0 or self._ccfg.day_token_days > 0, "embedder.adapt / day_token is on")
+        blocks = _index("block_idx", self._ccfg.block_token_blocks > 0, "embedder.block_token is on")
+        io.day_idx, io.block_idx = _ptr(days), _ptr(blocks)
         check(lib().nbci_ndt1_forward(self._plan, _ptr(self._flat), _ptr(self._flat_lp), C.byref(io), _stream()),
               "nbci_ndt1_forward")
         # keep every borrowed tensor alive until the backward of this step has been queued
-        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out, days)
+        self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out, days, blocks)
         self.last_argmax = argmax
         return loss, preds
 
@@ -406,7 +426,7 @@ class NDT1(nn.Module):
     def forward(self, spikes, spikes_mask, spikes_timestamp, spikes_lengths, targets=None, targets_lengths=None,
                 block_idx=None, day_idx=None):
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_timestamp=spikes_timestamp,
-                     spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths, day_idx=day_idx)
+                     spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths, day_idx=day_idx, block_idx=block_idx)
         if torch.is_grad_enabled() and targets is not None and any(p.requires_grad for p in self._param_list):
             loss, preds = _NDT1Function.apply(self, batch, *self._param_list)
         else:

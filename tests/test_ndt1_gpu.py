@@ -52,7 +52,7 @@ def _det_over(js):
     return over
 
 
-@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt"])
+@pytest.mark.parametrize("name", ["g_tiny", "g_tiny_ctx", "g_tiny_rope", "g_tiny_factors", "g_tiny_factors_fix", "g_tiny_adapt", "g_tiny_tokens", "g_tiny_daytoken"])
 def test_tiny_golden_fp32(name):
     fx = load(name)
     m = _model(_det_over(str(fx["config_json"])), 11)
@@ -137,7 +137,8 @@ def _oracle_cfg(m, **kw):
                          constant_offset_sd=c.constant_offset_sd, embed_dropout=c.embed_dropout, dropout=c.dropout,
                          use_rope=bool(c.use_rope), context_forward=c.context_forward, context_backward=c.context_backward,
                          factors_size=c.factors_size, factors_act={0: None, 1: "softsign", 2: "gelu", 3: "relu", 4: "tanh"}[c.factors_act],
-                         factors_bias=bool(c.factors_bias), adapt_days=c.adapt_days, **kw)
+                         factors_bias=bool(c.factors_bias), adapt_days=c.adapt_days, day_token_days=c.day_token_days,
+                         block_token_blocks=c.block_token_blocks, **kw)
 
 
 def _rand_batch(B, T, N, S, vocab, lens, tlens, seed=0):
@@ -171,7 +172,7 @@ def _bf16_vs_oracle(over, vocab, batch):
             assert np.abs(g[k]).sum() < 1e-3, k
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "tiny_adapt", "c1", "c1_adapt_bf16"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "tiny_adapt", "tiny_tokens", "c1", "c1_adapt_bf16", "c1_tokens_factors_bf16"])
 def test_train_mode_matches_oracle_with_dropout_and_noise(which):
     """recipe dropout (0.2 / 0.4) and noise ON: HIP and oracle draw identical masks (same counter RNG)."""
     if which.startswith("tiny"):
@@ -183,13 +184,20 @@ def test_train_mode_matches_oracle_with_dropout_and_noise(which):
         if which == "tiny_adapt":     # day-specific embed layers, two samples sharing a day (ndt1.py:124-129,170-171)
             over["encoder"]["embedder"].update(adapt=True, n_days=3)
             batch["day_idx"] = np.array([2, 0, 2], np.int64)
+        if which == "tiny_tokens":    # learned day + block tokens in front of the spike tokens (ndt1.py:192-201)
+            over["encoder"]["embedder"].update(day_token=True, block_token=True, n_days=3, n_blocks=4)
+            batch["day_idx"], batch["block_idx"] = np.array([2, 0, 2], np.int64), np.array([1, 3, 3], np.int64)
     else:
         over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
         vocab, batch = 41, _rand_batch(4, 100, 64, 10, 41, [100, 100, 80, 64], [10, 8, 6, 3])
         if which == "c1_adapt_bf16":  # real widths: the batched direct-to-LDS GEMMs (K = 100 bins is not a multiple of 64)
             over["encoder"]["embedder"].update(adapt=True, n_days=5)
             batch["day_idx"] = np.array([4, 1, 4, 0], np.int64)
-    if which == "c1_adapt_bf16":
+        if which == "c1_tokens_factors_bf16":   # real widths (fused attention with 18 + 2 tokens), block token + factors projection together
+            over["encoder"]["embedder"].update(day_token=True, block_token=True, n_days=5, n_blocks=6)
+            over["encoder"]["factors"] = {"active": True, "size": 512, "act": "relu", "bias": True}
+            batch["day_idx"], batch["block_idx"] = np.array([4, 1, 4, 0], np.int64), np.array([5, 5, 2, 0], np.int64)
+    if which.endswith("_bf16"):
         _bf16_vs_oracle(over, vocab, batch)
         return
     m = _model(over, vocab).to(DEV)
