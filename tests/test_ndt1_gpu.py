@@ -172,7 +172,7 @@ def _bf16_vs_oracle(over, vocab, batch):
             assert np.abs(g[k]).sum() < 1e-3, k
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "tiny_adapt", "tiny_tokens", "c1", "c1_adapt_bf16", "c1_tokens_factors_bf16"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_factors", "tiny_adapt", "tiny_tokens", "tiny_all", "c1", "c1_adapt_bf16", "c1_tokens_factors_bf16"])
 def test_train_mode_matches_oracle_with_dropout_and_noise(which):
     """recipe dropout (0.2 / 0.4) and noise ON: HIP and oracle draw identical masks (same counter RNG)."""
     if which.startswith("tiny"):
@@ -187,6 +187,11 @@ def test_train_mode_matches_oracle_with_dropout_and_noise(which):
         if which == "tiny_tokens":    # learned day + block tokens in front of the spike tokens (ndt1.py:192-201)
             over["encoder"]["embedder"].update(day_token=True, block_token=True, n_days=3, n_blocks=4)
             batch["day_idx"], batch["block_idx"] = np.array([2, 0, 2], np.int64), np.array([1, 3, 3], np.int64)
+        if which == "tiny_all":       # every optional piece at once: day-specific layers + both tokens + factors + a context span
+            over["encoder"]["embedder"].update(adapt=True, day_token=True, block_token=True, n_days=3, n_blocks=2)
+            over["encoder"]["factors"] = {"active": True, "size": 16, "act": "tanh", "bias": False}
+            over["encoder"]["context"] = {"forward": 4, "backward": 3}
+            batch["day_idx"], batch["block_idx"] = np.array([1, 1, 0], np.int64), np.array([0, 1, 1], np.int64)
     else:
         over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
         vocab, batch = 41, _rand_batch(4, 100, 64, 10, 41, [100, 100, 80, 64], [10, 8, 6, 3])
