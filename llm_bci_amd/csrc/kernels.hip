@@ -266,8 +266,9 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
     return check_launch("layernorm_fwd");
 }
 
-constexpr int LNB_ITERS = 2;             // passes per block (the column partial sums stay in registers across them)
-constexpr int LNB_ROWS = 8 * LNB_ITERS;  // rows per block: 2 per wave and pass, both rows' loads in flight together
+constexpr int LNB_RPW = 1;                          // rows per wave and pass (their loads are in flight together)
+constexpr int LNB_ITERS = 4;                        // passes per block (the column partial sums stay in registers across them)
+constexpr int LNB_ROWS = 4 * LNB_RPW * LNB_ITERS;   // rows per block
 
 template <int NV, typename DY>   // DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const float* __restrict__ x,
@@ -284,11 +285,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
     for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; gc[k] = gw[k]; }
 #pragma unroll 1
   for (int it = 0; it < LNB_ITERS; ++it) {
-    const int ra = blockIdx.x * LNB_ROWS + it * 8 + wv * 2;
-    float4 xv[2][NV], dv[2][NV], od[2][NV];
-    float mu[2], rs[2];
+    const int ra = blockIdx.x * LNB_ROWS + it * 4 * LNB_RPW + wv * LNB_RPW;
+    float4 xv[LNB_RPW][NV], dv[LNB_RPW][NV], od[LNB_RPW][NV];
+    float mu[LNB_RPW], rs[LNB_RPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < LNB_RPW; ++j) {
         const int r = ra + j;
         mu[j] = r < M ? mean[r] : 0.f; rs[j] = r < M ? rstd[r] : 0.f;
 #pragma unroll
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < LNB_RPW; ++j) {
         const int r = ra + j;
         float4 xh[NV], dh[NV];
         float s1 = 0.f, s2 = 0.f;
