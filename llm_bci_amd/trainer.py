@@ -61,6 +61,7 @@ class NativeTrainer:
         # device-side running stats: [loss_sum, n_examples, per_ratio_sum, n_batches]
         self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
         self._per_bufs = None
+        self._mstream = None   # side stream for the per-step metric (train_step)
 
     # -------------------------------------------------------------------------------------
     def _per(self, batch):
@@ -96,26 +97,33 @@ class NativeTrainer:
         m = self.model
         m.train()
         sync = ((self.global_step - 1) % self.ga == 0)
+        main = torch.cuda.current_stream()
+        if self._mstream is None:
+            self._mstream = torch.cuda.Stream(device=self.stats.device)
+        main.wait_stream(self._mstream)   # the previous step's metric has read its inputs before their memory is recycled
         loss_vec, preds = m._run_forward(batch, want_grad=True, seed=seed, grad_scale=1.0 / self.ga)
+        # The reference computes its metric every step (trainer.py:359-362): greedy decode + PER and the loss bookkeeping read
+        # forward outputs only, so they run on a second stream BESIDE the backward (two latency-bound launches, ~40 us).
+        self._mstream.wait_stream(main)
+        with torch.cuda.stream(self._mstream):
+            err = None
+            if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
+                err = self._per(batch)
+            n = getattr(m, "last_n_examples", None)
+            if n is None and loss_vec.dtype == torch.float32 and loss_vec.is_contiguous():
+                check(lib().nbci_step_stats(_ptr(self.stats), _ptr(loss_vec), loss_vec.numel(), float(loss_vec.numel()),
+                                            _ptr(err) if err is not None else None, _stream()), "nbci_step_stats")
+            else:
+                self.stats[0] += loss_vec.sum().double()
+                self.stats[1] += self._n_examples(loss_vec)
+                if err is not None:
+                    self.stats[2] += self._per_ratio(err)
+                    self.stats[3] += 1
         nseg = len(m._segments)
         for seg in range(nseg - 1, -1, -1):
             m._run_backward(self.grads, seg, seg)
             if sync:
                 self.reducer.segment_done(self.grads, seg)
-        # bookkeeping while the last buckets are in flight: one small launch (loss sum, example count, batch PER ratio)
-        err = None
-        if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
-            err = self._per(batch)
-        n = getattr(m, "last_n_examples", None)
-        if n is None and loss_vec.dtype == torch.float32 and loss_vec.is_contiguous():
-            check(lib().nbci_step_stats(_ptr(self.stats), _ptr(loss_vec), loss_vec.numel(), float(loss_vec.numel()),
-                                        _ptr(err) if err is not None else None, _stream()), "nbci_step_stats")
-        else:
-            self.stats[0] += loss_vec.sum().double()
-            self.stats[1] += self._n_examples(loss_vec)
-            if err is not None:
-                self.stats[2] += self._per_ratio(err)
-                self.stats[3] += 1
         if sync:
             self.reducer.finish(self.grads)
             lr, beta1 = self.sched.at(self.opt_step)
@@ -132,6 +140,8 @@ class NativeTrainer:
     def read_stats(self, reset=True):
         """{'loss': sum_loss/sum_examples, 'PER': mean of per-batch ratios} over the steps since the
         last read (trainer.py:306-307,370-371); ONE host sync, one small all-reduce."""
+        if self._mstream is not None:
+            torch.cuda.current_stream().wait_stream(self._mstream)
         s = reduce_stats(self.stats.clone(), self.group).cpu()
         out = {"loss": (s[0] / s[1]).item() if s[1] > 0 else 0.0, "n_examples": int(s[1].item()),
                "PER": (s[2] / s[3]).item() if s[3] > 0 else None}
