@@ -534,8 +534,9 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
                                          (const float*)(ws + w.rstd_r), grads + p.rgw, RG(p.rgnw), RG(p.rgnb), c.n_regions, H, 1, s, rc,
                                          no_cast));
         }
-        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
+    // the replicated small-vector gradients of every segment of this call, folded in ONE launch (their compact ranges are adjacent)
+    TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg_lo].first, p.cseg[seg_hi].second, grads, s));
     return NBCI_OK;
 }
 

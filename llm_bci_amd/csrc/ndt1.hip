@@ -681,8 +681,9 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                       grads + p.embw, c.n_channels));
             }
         }
-        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
+    // the replicated small-vector gradients of every segment of this call, folded in ONE launch (their compact ranges are adjacent)
+    TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg_lo].first, p.cseg[seg_hi].second, grads, s));
     return NBCI_OK;
 }
 

@@ -505,8 +505,9 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             }
             TRY(wgrad(s, NBCI_F32, D, pl, Mi, op(de, 4, 0, D, 0), op(ws + w.xm, 4, 0, pl, 0), grads + p.embw, pl));
         }
-        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg].first, p.cseg[seg].second, grads, s));
     }
+    // the replicated small-vector gradients of every segment of this call, folded in ONE launch (their compact ranges are adjacent)
+    TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg_lo].first, p.cseg[seg_hi].second, grads, s));
     return NBCI_OK;
 }
 

@@ -120,9 +120,11 @@ class NativeTrainer:
                     self.stats[2] += self._per_ratio(err)
                     self.stats[3] += 1
         nseg = len(m._segments)
-        for seg in range(nseg - 1, -1, -1):
-            m._run_backward(self.grads, seg, seg)
-            if sync:
+        if self.reducer.world == 1 or not sync:   # nothing to overlap with: the whole backward is one call (one fold of the small-vector gradients)
+            m._run_backward(self.grads, nseg - 1, 0)
+        else:
+            for seg in range(nseg - 1, -1, -1):
+                m._run_backward(self.grads, seg, seg)
                 self.reducer.segment_done(self.grads, seg)
         if sync:
             self.reducer.finish(self.grads)
