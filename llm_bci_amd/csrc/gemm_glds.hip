@@ -361,10 +361,11 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel
         // runs one workgroup per CU (rounds of 256 tiles) but streams ~1.5x faster per row.
         double best = -1;
-        const int cands[3] = {128, 144, 288};  // (160 / 192 rows spill accumulators to scratch with hipcc 7.2: not offered)
+        const int cands[4] = {128, 144, 160, 288};  // (160 rows: two-chunk epilogue, 208 VGPRs; 192 rows spill accumulators with hipcc 7.2: not offered)
         static const bool g3_off = [] { const char* e = getenv("NBCI_GEMM3"); return !(e && e[0] == '1'); }();  // opt-in: measured no faster than the 2-stage kernel
         for (int c : cands) {
             if (c == 288 && (g3_off || d.K < 192 || glds_view(d))) continue;
+            if (c == 160 && glds_view(d)) continue;   // (view launches pick their own 160-row case below)
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
             if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
             const double cost = c == 288 ? (double)((tiles + 255) / 256) * c / 2.0 / 1.5 : (double)((tiles + 511) / 512) * c;
@@ -405,6 +406,7 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     }
     switch (bm) {
         case 144: return launch_glds_layout<1, 4, 9, 2>(k, ak, bk, grid, stream);
+        case 160: return launch_glds_layout<1, 4, 10, 2>(k, ak, bk, grid, stream);
         case 288:
             return bk ? launch_ms<true, true, 2, 4, 9, 2, 3>(k, grid, stream) : launch_ms<true, false, 2, 4, 9, 2, 3>(k, grid, stream);
         default: return launch_glds_layout<2, 2, 4, 4>(k, ak, bk, grid, stream);
