@@ -844,6 +844,45 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     __syncthreads();
     const bool is_alpha = tid < 128;
     const int ht = tid & 127;
+    // Usual case (2S + 1 <= 128: one lattice state per thread): everything that depends only on the state — its label, whether the
+    // skip transition is allowed, its column of the log-probabilities — is taken out of the frame loop, so a step is one round of
+    // independent LDS reads (three lattice entries + one log-probability), the log-add, one LDS write and the barrier.
+    if (L <= 128) {
+        const int s = ht;
+        const bool live = s < L;
+        const int e = live ? ext[s] : 0;
+        const bool skipa = live && s >= 2 && e != blank && e != ext[s - 2];
+        const bool skipb = live && s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e;
+        const float* lpe = lp + e;
+        float* row = is_alpha ? rowA : rowB;
+        float* lat = is_alpha ? aw : bw;
+        for (int step = 0; step < Tb; ++step) {
+            const int t = is_alpha ? step : Tb - 1 - step;
+            const float* prev = row + ((step + 1) & 1) * Lmax;
+            float* cur = row + (step & 1) * Lmax;
+            if (live) {
+                const float lpv = lpe[(long long)t * V];
+                float v;
+                if (step == 0) {
+                    v = (is_alpha ? (s < 2) : (s >= L - 2)) ? lpv : -INFINITY;
+                } else if (is_alpha) {
+                    const float a0 = prev[s];
+                    const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+                    const float a2 = skipa ? prev[s - 2] : -INFINITY;
+                    v = log_add3(a0, a1, a2) + lpv;
+                } else {
+                    const float b0 = prev[s];
+                    const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+                    const float b2 = skipb ? prev[s + 2] : -INFINITY;
+                    v = log_add3(b0, b1, b2) + lpv;
+                }
+                cur[s] = v; lat[(long long)t * Lmax + s] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's row write has landed in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    } else
     for (int step = 0; step < Tb; ++step) {
         if (is_alpha) {
             const int t = step;
