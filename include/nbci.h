@@ -284,6 +284,9 @@ typedef struct nbci_ndt1_io {
     int64_t workspace_bytes;
     const int64_t* day_idx;             /* (B) recording day of each sample; required when adapt_days > 0 or day_token_days > 0 */
     const int64_t* block_idx;           /* (B) block of each sample; required when block_token_blocks > 0 */
+    int32_t embed_part;                 /* backward of segment 0 only: 0 = whole segment; 1 = the stack-projection / position /
+                                           token-table gradients (everything after embed_spikes.* in the flat layout), 2 = the rest.
+                                           Lets a data-parallel caller all-reduce the large first part while part 2 computes. */
 } nbci_ndt1_io;
 
 typedef void* nbci_ndt1_plan;

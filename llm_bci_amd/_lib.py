@@ -65,7 +65,8 @@ class NDT1IO(C.Structure):
                 ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
                 ("preds", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
                 ("token_mask_out", C.c_void_p), ("d_hidden", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("day_idx", C.c_void_p), ("block_idx", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("day_idx", C.c_void_p), ("block_idx", C.c_void_p),
+                ("embed_part", C.c_int32)]
 
 
 class MaskerDesc(C.Structure):

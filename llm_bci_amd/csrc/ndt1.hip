@@ -627,15 +627,22 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const void* dx0;
             if (!need_cast) {
                 dx0 = dx;
-                TRY(colsum_launch(dx0, dt, H, M, H, RG(p.stkb), s, rc));
+                if (io->embed_part != 2) TRY(colsum_launch(dx0, dt, H, M, H, RG(p.stkb), s, rc));
             } else {
                 dx0 = ws + w.dA;
             }
+            // io->embed_part splits this segment for the data-parallel trainer: 1 = everything that finishes the stack-projection /
+            // position / token-table gradients (35 of the segment's 38 MB: their all-reduce then runs beside part 2), 2 = the rest
+            // (d pre-activation + the embed_spikes gradients), 0 = both.
+            const int part = io->embed_part;
+            NBCI_REQUIRE(part >= 0 && part <= 2, NBCI_EINVAL, "ndt1: embed_part must be 0, 1 or 2");
+            if (part != 2) {
             if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre));
             if (npre) {   // the prefix tokens' tables: [day, block] order as assembled in the forward
                 int k = 0;
                 if (c.day_token_days > 0) TRY(prefix_grad_launch(dx, io->day_idx, grads + p.dayemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
                 if (c.block_token_blocks > 0) TRY(prefix_grad_launch(dx, io->block_idx, grads + p.blkemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
+            }
             }
             // the spike-token rows of dx0: all of it, or (prefix tokens) a view that skips the first npre rows of every sample block
             const nbci_operand dx0_km = npre ? op(dx0, es, (int64_t)npre * H, H, 1, Tk, (int64_t)Tp * H) : op(dx0, es, 0, H, 1);
@@ -643,8 +650,10 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             if (w.phase_ok) {
                 // dx0 sits in zero-padded sample blocks (B, P, H): token j of sample b at row b*P + npad + j.
                 const int st = c.stack_stride, nwin = c.stack_size / st;
-                TRY(wgrad(s, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
-                          op(ws + w.y, es, 0, (int64_t)st * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
+                if (part != 2)
+                    TRY(wgrad(s, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
+                              op(ws + w.y, es, 0, (int64_t)st * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
+                if (part != 1) {
                 // d pre-activation WITHOUT the (M, size*D) window-gradient tensor and its col2im pass. The st bins t = st*q + ph of
                 // group q collect  sum_{i < nwin} dx0[q - i] . W_s[:, D*(st*i + ph) .. + D]; with n = D*ph + c and i' = nwin-1-i that
                 // is ONE GEMM: rows (b, q), N = st*D, a contraction over k = (i', h) of the nwin consecutive padded rows q .. q+nwin-1
@@ -656,17 +665,21 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                                       (int64_t)st * D, dt);
                 d.gate = ws + w.y; d.ldg = (int64_t)st * D; d.gate_act = 64 + c.embed_act;
                 TRY(gemm_launch_timed(d, s));
+                }
             } else {
-            TRY(wgrad(s, dt, H, KS, Mk, dx0_rm,
-                      op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
-            {   // dwin = dx0 W_s  (B*T', S*D)
+            if (part != 2)
+                TRY(wgrad(s, dt, H, KS, Mk, dx0_rm,
+                          op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
+            if (part != 1) {   // dwin = dx0 W_s  (B*T', S*D)
                 nbci_gemm_desc d = gd(Mk, KS, H, dt, dx0_km, op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
                 TRY(gemm_launch_timed(d, s));
+                TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tk, D, c.stack_size, c.stack_stride,
+                                          c.embed_act, s));
             }
-            TRY(col2im_actgrad_launch(ws + w.dwin, ws + w.y, ws + w.dpre, dt, B, T, Tk, D, c.stack_size, c.stack_stride,
-                                      c.embed_act, s));
             }
-            if (c.adapt_days > 0) {   // per-sample partial gradients (batched), then a deterministic scatter into the days' rows
+            if (part == 1) {
+                // (the embed_spikes gradients belong to part 2)
+            } else if (c.adapt_days > 0) {   // per-sample partial gradients (batched), then a deterministic scatter into the days' rows
                 NBCI_REQUIRE(io->day_idx, NBCI_EINVAL, "ndt1: embedder.adapt needs day_idx");
                 const int wn = D * c.n_channels;
                 nbci_gemm_desc d = gd(D, c.n_channels, T, dt, op(ws + w.dpre, es, 0, D, 0, 0, 0, (int64_t)T * D),
@@ -683,7 +696,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
         }
     }
     // the replicated small-vector gradients of every segment of this call, folded in ONE launch (their compact ranges are adjacent)
-    TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, p.cseg[seg_lo].first, p.cseg[seg_hi].second, grads, s));
+    // A part of segment 0 folds (and so writes) only ITS side of the split: the other side may be in an all-reduce by then.
+    int clo = p.cseg[seg_lo].first, chi = p.cseg[seg_hi].second;
+    if (seg_lo == 0 && io->embed_part == 1) clo = p.compact_of(p.stkb);
+    if (seg_lo == 0 && io->embed_part == 2) chi = p.compact_of(p.stkb);
+    if (chi > clo) TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, s));
     return NBCI_OK;
 }
 

@@ -54,6 +54,16 @@ class GradReducer:
         if self._pending[1] - self._pending[0] >= self.min_bucket or seg == 0:
             self._launch(flat)
 
+    def range_done(self, flat, b, e):
+        """All-reduce [b, e) now: for a caller that finishes a segment in parts (NDT1's embedder: the 33 MB
+        stack-projection gradient is exchanged while the rest of the segment still computes)."""
+        if self.world == 1 or e <= b:
+            return
+        if self._pending is not None:
+            self._launch(flat)
+        self._pending = [b, e]
+        self._launch(flat)
+
     def _launch(self, flat):
         b, e = self._pending
         self._pending = None

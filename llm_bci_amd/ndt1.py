@@ -173,6 +173,8 @@ class NDT1(nn.Module):
             add("encoder.embedder.day_embedding.weight", (c.day_token_days, H), 0)
         cur = (cur + 7) // 8 * 8
         self._segments = [(0, cur)]
+        # segment 0's backward can run in two parts (nbci_ndt1_io.embed_part): [_embed_split, end) is finished by part 1
+        self._embed_split = next(o for (nm, o, _n, _s, _g) in out if nm == "encoder.embedder.stack_projection.weight")
         for l in range(c.n_layers):
             b, pre = cur, f"encoder.layers.{l}."
             add(pre + "ln1.weight", (H,), l + 1); add(pre + "ln1.bias", (H,), l + 1)
@@ -413,9 +415,10 @@ class NDT1(nn.Module):
         self.last_argmax = argmax
         return loss, preds
 
-    def _run_backward(self, grads, seg_hi=None, seg_lo=0, d_hidden=None):
+    def _run_backward(self, grads, seg_hi=None, seg_lo=0, d_hidden=None, embed_part=0):
         io = self._io_keepalive[0]
         io.d_hidden = _ptr(d_hidden)   # f32 (B,T',H): backward starts from the encoder output instead of the CTC head
+        io.embed_part = embed_part     # segment 0 only: 1 = stack-projection/position/token gradients, 2 = the rest, 0 = both
         if not io.want_grad:
             raise RuntimeError("backward called but the forward pass ran without want_grad/targets")
         if seg_hi is None:

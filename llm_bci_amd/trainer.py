@@ -123,9 +123,16 @@ class NativeTrainer:
         if self.reducer.world == 1 or not sync:   # nothing to overlap with: the whole backward is one call (one fold of the small-vector gradients)
             m._run_backward(self.grads, nseg - 1, 0)
         else:
-            for seg in range(nseg - 1, -1, -1):
+            split = getattr(m, "_embed_split", None)
+            for seg in range(nseg - 1, 0 if split is not None else -1, -1):
                 m._run_backward(self.grads, seg, seg)
                 self.reducer.segment_done(self.grads, seg)
+            if split is not None:   # the embedder in two parts: its big stack-projection bucket is on the wire during part 2
+                b0, e0 = m._segments[0]
+                m._run_backward(self.grads, 0, 0, embed_part=1)
+                self.reducer.range_done(self.grads, split, e0)
+                m._run_backward(self.grads, 0, 0, embed_part=2)
+                self.reducer.range_done(self.grads, b0, split)
         if sync:
             self.reducer.finish(self.grads)
             lr, beta1 = self.sched.at(self.opt_step)

@@ -54,8 +54,12 @@ def _worker(rank, world, port, ga, out_dir):
         flat.zero_()
         for (name, off, numel, shape, _seg) in m._layout:
             flat[off:off + numel] = torch.from_numpy(gd[name].reshape(-1))
-        for seg in range(len(m._segments) - 1, -1, -1):     # backward order: head first, embedder last
+        for seg in range(len(m._segments) - 1, 0, -1):      # backward order: head first, embedder last
             red.segment_done(flat, seg)
+        b0, e0 = m._segments[0]                             # the embedder goes in two ranges, as NativeTrainer.train_step does
+        assert b0 < m._embed_split < e0
+        red.range_done(flat, m._embed_split, e0)
+        red.range_done(flat, b0, m._embed_split)
         red.finish(flat)
         return {name: flat[off:off + numel].view(shape).numpy().copy() for (name, off, numel, shape, _s) in m._layout}
 

@@ -353,3 +353,40 @@ def test_segmentwise_backward_equals_single_call():
     assert float(g1.abs().sum()) > 0
     # bit-equal except where f32 atomics order the sums (bias / LayerNorm replicas, position table): compare with a tight tolerance
     assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5 * float(g1.abs().max()))
+
+
+@pytest.mark.parametrize("variant", ["plain", "adapt_tokens", "f32"])
+def test_embedder_backward_in_two_parts(variant):
+    """The DP trainer runs segment 0 as embed_part=1 (stack projection / position / token tables: all-reduced at once)
+    then embed_part=2 (embed_spikes). Part 1 must leave [begin, split) untouched and already hold the final values of
+    [split, end); part 2 must not write [split, end); together they equal the one-call backward."""
+    over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 1}}}
+    extra = {}
+    if variant == "adapt_tokens":
+        over["encoder"]["embedder"].update({"adapt": True, "n_days": 3, "day_token": True, "block_token": True, "n_blocks": 2})
+        extra = {"day_idx": torch.tensor([0, 2, 2, 1]), "block_idx": torch.tensor([1, 0, 1, 1])}
+    batch = _rand_batch(4, 100, 64, 10, 41, [100, 100, 80, 64], [10, 8, 6, 3])
+    batch.update(extra)
+    batch = _to_dev(batch)
+    m = _model(over, 41, dtype="fp32" if variant == "f32" else "bf16").to(DEV)
+    m.train()
+    nseg = len(m._segments)
+    b0, e0 = m._segments[0]
+    split = m._embed_split
+    assert b0 < split < e0
+    m._run_forward(batch, want_grad=True, seed=9)
+    g1 = torch.zeros_like(m._flat)
+    m._run_backward(g1)
+    m._run_forward(batch, want_grad=True, seed=9)
+    g2 = torch.zeros_like(m._flat)
+    for seg in range(nseg - 1, 0, -1):
+        m._run_backward(g2, seg, seg)
+    m._run_backward(g2, 0, 0, embed_part=1)
+    torch.cuda.synchronize()
+    after1 = g2.clone()
+    assert float(after1[b0:split].abs().sum()) == 0.0
+    m._run_backward(g2, 0, 0, embed_part=2)
+    torch.cuda.synchronize()
+    assert torch.equal(after1[split:e0], g2[split:e0])          # part 2 writes nothing on part 1's side
+    assert float(g2[b0:split].abs().sum()) > 0
+    assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5 * float(g1.abs().max()))
