@@ -67,14 +67,21 @@ class GradReducer:
     def _launch(self, flat):
         b, e = self._pending
         self._pending = None
-        self._works.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._works.append((b, e, dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def finish(self, flat=None):
+        for _ in self.drain(flat):
+            pass
+
+    def drain(self, flat=None):
+        """Yield each reduced range (b, e) in launch order once the current stream waits on its all-reduce: the caller can
+        start consuming the early buckets (the optimizer update) while the last ones are still on the wire."""
         if self._pending is not None and flat is not None:
             self._launch(flat)
-        for w in self._works:
+        works, self._works = self._works, []
+        for (b, e, w) in works:
             w.wait()
-        self._works = []
+            yield (b, e)
 
 
 def reduce_stats(stats, group=None):

@@ -134,13 +134,22 @@ class NativeTrainer:
                 m._run_backward(self.grads, 0, 0, embed_part=2)
                 self.reducer.range_done(self.grads, b0, split)
         if sync:
-            self.reducer.finish(self.grads)
             lr, beta1 = self.sched.at(self.opt_step)
             t = self.opt_step + 1
             lp = m._flat_lp if m.compute_dtype == NBCI_BF16 else None
-            check(lib().nbci_adamw(_ptr(m._flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(lp), m._total, lr, beta1,
-                                   self.beta2, self.eps, self.wd, 1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world,
-                                   _stream()), "nbci_adamw")
+            pw, pg, pm, pv = (x.data_ptr() for x in (m._flat, self.grads, self.m, self.v))
+            plp = lp.data_ptr() if lp is not None else 0
+            # One launch per reduced bucket, in the order the buckets were put on the wire: the update of the head / layer
+            # ranges runs while the embedder's all-reduce is still in flight (AdamW is elementwise: same bits as one launch).
+            # drain() is lazy: the stream waits on bucket i only just before bucket i's update is queued.
+            done = 0
+            for b, e in (self.reducer.drain(self.grads) if self.reducer.world > 1 else [(0, m._total)]):
+                check(lib().nbci_adamw(C.c_void_p(pw + 4 * b), C.c_void_p(pg + 4 * b), C.c_void_p(pm + 4 * b), C.c_void_p(pv + 4 * b),
+                                       C.c_void_p(plp + 2 * b) if plp else None, e - b, lr, beta1, self.beta2, self.eps, self.wd,
+                                       1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world, _stream()), "nbci_adamw")
+                done += e - b
+            if done != m._total:
+                raise RuntimeError("gradient buckets do not cover the flat parameter buffer")
             self.grads.zero_()
             self.opt_step += 1
         self.global_step += 1

@@ -1,0 +1,110 @@
+"""Data-parallel NativeTrainer against a single-process run of the same global batch, on real devices.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 tools/dp_check.py
+
+W ranks (RCCL by default; NBCI_DIST_BACKEND=gloo lets several ranks share one GPU) each take their shard of a global batch
+(Accelerator(split_batches=True), reference models/trainer.py:77-80) and run NativeTrainer.train_step: segment-wise backward,
+bucketed async all-reduce, the embedder in two parts, one AdamW launch per drained bucket. Every rank also runs the reference
+schedule alone: the whole global batch in one backward call, the summed gradient divided by W in one AdamW launch (= DDP's
+mean of per-rank sum-losses, reference trainer.py:339). Both must end with the same parameters.
+Dropout and noise are off (their streams are per rank by design). Exit code 0 and 'DP_CHECK OK' on success.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from llm_bci_amd.dp import shard_batch  # noqa: E402
+from llm_bci_amd.ndt1 import NDT1  # noqa: E402
+from llm_bci_amd.trainer import NativeTrainer  # noqa: E402
+
+STEPS = 3
+
+
+def _over(variant):
+    emb = {"n_channels": 64, "dropout": 0.0}
+    if variant == "adapt_tokens":
+        emb.update({"adapt": True, "n_days": 3, "day_token": True, "block_token": True, "n_blocks": 2})
+    return {"encoder": {"smooth_and_noise": {"noise": False}, "embedder": emb, "transformer": {"n_layers": 2, "dropout": 0.0}}}
+
+
+def _batch(world, variant, dev):
+    g = np.random.default_rng(3)
+    B, T, N, S = 4 * world, 100, 64, 10
+    lens = g.integers(60, T + 1, B)
+    lens[0] = T
+    b = dict(spikes=g.poisson(0.4, (B, T, N)).astype(np.float32), spikes_mask=(np.arange(T)[None] < lens[:, None]).astype(np.int64),
+             spikes_timestamp=np.tile(np.arange(T), (B, 1)), spikes_lengths=lens.astype(np.int64),
+             targets=g.integers(1, 41, (B, S)).astype(np.int64), targets_lengths=g.integers(2, S + 1, B).astype(np.int64))
+    if variant == "adapt_tokens":
+        b["day_idx"] = g.integers(0, 3, B).astype(np.int64)
+        b["block_idx"] = g.integers(0, 2, B).astype(np.int64)
+    return {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+
+
+def _model(variant, dtype, dev):
+    torch.manual_seed(1)
+    return NDT1(_over(variant), method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=dtype).to(dev)
+
+
+def run(variant, dtype, rank, world, dev):
+    full = _batch(world, variant, dev)
+    # --- the data-parallel run
+    m = _model(variant, dtype, dev)
+    tr = NativeTrainer(m, total_steps=20)
+    assert tr.world == world
+    mine = shard_batch(full, rank, world)
+    for s in range(STEPS):
+        tr.train_step(mine, seed=s)
+    st = tr.read_stats()
+    # --- the same optimizer steps by one process over the global batch
+    r = _model(variant, dtype, dev)
+    rt = NativeTrainer(r, total_steps=20)
+    rt.reducer.world, rt.world = 1, world      # no exchange; AdamW still divides the summed gradient by W
+    for s in range(STEPS):
+        rt.train_step(full, seed=s)
+    rs_loss = float(rt.stats[0] / rt.stats[1])
+    torch.cuda.synchronize()
+    assert tr.opt_step == rt.opt_step == STEPS
+    a, b = m._flat.float().cpu().numpy(), r._flat.float().cpu().numpy()
+    d = np.abs(a - b)
+    moved = np.abs(b - _model(variant, dtype, "cpu")._flat.numpy()).max()
+    ok = bool((d > 2e-5).mean() < 0.01 and d.max() < 8e-3 and moved > 1e-3 and abs(st["loss"] - rs_loss) <= 1e-4 * abs(rs_loss)
+              and st["n_examples"] == STEPS * full["spikes"].shape[0])
+    if dtype == "bf16":
+        ok = ok and torch.equal(m._flat_lp, m._flat.bfloat16())
+    print(f"[rank {rank}] {variant}/{dtype}: max|dp-single| {d.max():.3e}  frac>2e-5 {(d > 2e-5).mean():.2e}  moved {moved:.2e}  "
+          f"loss {st['loss']:.5f} vs {rs_loss:.5f}  -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    return ok
+
+
+def main():
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    backend = os.environ.get("NBCI_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend, device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    ok = True
+    for variant, dtype in (("plain", "fp32"), ("plain", "bf16"), ("adapt_tokens", "bf16")):
+        ok = run(variant, dtype, rank, world, dev) and ok
+    flag = torch.tensor([0.0 if ok else 1.0], device=dev)
+    dist.all_reduce(flag)
+    dist.barrier()
+    dist.destroy_process_group()
+    if float(flag) != 0:
+        print("DP_CHECK FAILED", flush=True)
+        sys.exit(1)
+    if rank == 0:
+        print("DP_CHECK OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()
