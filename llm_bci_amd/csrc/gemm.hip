@@ -15,6 +15,8 @@
 //    lane) for every full K tile, tile height chosen per problem so the grid fills whole rounds.
 // The MFMA is issued with operands swapped (B fragment first) so every lane ends up with
 // 4 CONSECUTIVE n for one m: epilogue loads/stores are 16-byte (f32) / 8-byte (bf16) wide.
+#include <set>
+#include <cstdio>
 #include "gemm_common.h"
 
 namespace nbci {
@@ -203,6 +205,15 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     if (d.residual) cvec = cvec && (d.ldr % 4 == 0) && (((uintptr_t)d.residual) % 16 == 0);
     k.cvec = cvec ? 1 : 0;
     { static const int dbg = [] { const char* e = getenv("NBCI_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+    k.epi_mode = epi_mode_of(k);
+    {   // NBCI_GEMM_LOGMODE=1: print each distinct epilogue feature set once (which ones deserve a specialised row loop)
+        static const bool logm = [] { const char* e = getenv("NBCI_GEMM_LOGMODE"); return e && e[0] == '1'; }();
+        if (logm) {
+            static std::set<int> seen;
+            if (seen.insert(k.epi_mode).second) fprintf(stderr, "[nbci] gemm epilogue mode 0x%x (M %d N %d K %d)\n", k.epi_mode, d.M, d.N, d.K);
+        }
+    }
+    { static const bool gen = getenv("NBCI_GEMM_GENERIC_EPI") != nullptr; if (gen) k.epi_mode = EPI_GENERIC; }   // A/B: force the run-time-tested row loop
     return NBCI_OK;
 }
 

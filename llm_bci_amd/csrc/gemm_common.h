@@ -39,6 +39,16 @@ template <> struct GemmTile<float> {
 constexpr int F32_KM_STRIDE = 17;   // dwords per row, k-major f32 tile [128][16+1]
 constexpr int F32_RM_STRIDE = 144;  // dwords per row, row-major f32 tile [16][128+16]
 
+#ifdef NBCI_STAMPS   // measurement build only (tools/gemm_stamps.py): per-workgroup wall-clock stamps (100 MHz) of the kernel's phases
+static __device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(slot)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 struct OperandK {  // device copy of nbci_operand, batch offset already applied
     const void* ptr;
     long long ld;
@@ -72,6 +82,7 @@ struct GemmK {
     int gate_coff;   // the batch offset of C applies to the gate too (gate has C's layout)
     int c2_grad;   // C2 receives act'(pre-activation) instead of the pre-activation
     int cvec;  // vector C/residual accesses legal
+    int epi_mode;   // EPI_* feature bits of this problem's epilogue (epi_mode_of), set by the host: picks a specialised row loop
     int dbg;   // NBCI_GEMM_DBG ablation bits (measurement only): 1 = epilogue computes but does not store, 2 = no K loop (both outside the K loop: a flag tested inside it slows the loop itself)
 };
 
@@ -220,11 +231,67 @@ __device__ __forceinline__ void compute_tile(const char* sA, const char* sB, f32
 // One lane's share of the fused epilogue: v[0..3] = alpha * accumulator of C[m][n .. n+3] (m < M, n < N checked by
 // the caller). Applies bias / activation / gate / dropout / residual in the order the model needs, stores C (and C2),
 // and adds the stored values into csum[0..3] when column sums are requested.
-__device__ __forceinline__ void epi_apply(const GemmK& d, float (&v)[4], int m, int n, long long coff, float (&csum)[4]) {
+// The activation ladders with the switch OUTSIDE the 4-element loop: one uniform branch ladder per output row instead of four
+// (called with a constant code, act_fwd & co fold to the one formula: same arithmetic, same bits).
+__device__ __forceinline__ void act_fwd4(int act, float (&v)[4]) {
+#define NBCI_ACT4(CODE) case CODE: _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = act_fwd(CODE, v[e]); break;
+    switch (act) { NBCI_ACT4(ACT_SOFTSIGN) NBCI_ACT4(ACT_GELU) NBCI_ACT4(ACT_RELU) NBCI_ACT4(ACT_TANH) default: break; }
+#undef NBCI_ACT4
+}
+__device__ __forceinline__ void act_fwd_bwd4(int act, float (&v)[4], float (&dact)[4]) {
+#define NBCI_ACT4(CODE) case CODE: _Pragma("unroll") for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(CODE, v[e], y, dact[e]); v[e] = y; } break;
+    switch (act) {
+        NBCI_ACT4(ACT_SOFTSIGN) NBCI_ACT4(ACT_GELU) NBCI_ACT4(ACT_RELU) NBCI_ACT4(ACT_TANH)
+        default: _Pragma("unroll") for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(ACT_NONE, v[e], y, dact[e]); v[e] = y; } break;
+    }
+#undef NBCI_ACT4
+}
+__device__ __forceinline__ void act_bwd_from_output_mul4(int act, const float (&g)[4], float (&v)[4]) {
+#define NBCI_ACT4(CODE) case CODE: _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= act_bwd_from_output(CODE, g[e]); break;
+    switch (act) {
+        NBCI_ACT4(ACT_SOFTSIGN) NBCI_ACT4(ACT_GELU) NBCI_ACT4(ACT_RELU) NBCI_ACT4(ACT_TANH)
+        default: _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= act_bwd_from_output(ACT_NONE, g[e]); break;
+    }
+#undef NBCI_ACT4
+}
+
+// FULL: the lane's 4 elements are inside N and 16-byte accesses are legal -- decided ONCE per thread by the caller, so the row
+// loop carries one copy of each step instead of a vector / scalar branch at every load and store. (In-kernel stamps,
+// tools/gemm_stamps.py: the branch maze of the one-size-fits-all version cost ~900 cycles per output row, 7.2 us of a 24 us
+// K = 1024 tile.)
+// MODE >= 0: the feature set is a compile-time constant (EPI_* bits) and the row loop is straight-line code for exactly that
+// epilogue; MODE < 0: every feature is tested at run time (any combination). The row-contiguous epilogue issues one wave64
+// VALU instruction per 4 cycles per SIMD with two waves per SIMD: at ~70 instructions per 4 outputs the run-time-tested loop
+// cost 6 us of a 24 us K = 1024 tile after the first clean-up (7.2 before).
+enum : int {
+    EPI_BIAS = 1, EPI_C2GRAD = 2, EPI_RES_FIRST = 4, EPI_RES_LAST = 8, EPI_RES_ROWS = 16, EPI_ACT = 32, EPI_GATE_MUL = 64,
+    EPI_GATE_OUT = 128, EPI_DROP = 256, EPI_COLSUM = 512, EPI_CBF16 = 1024, EPI_BETA = 2048, EPI_GENERIC = 1 << 30
+};
+__host__ __device__ inline int epi_mode_of(const GemmK& d) {
+    int m = 0;
+    if (d.bias) m |= EPI_BIAS;
+    if (d.C2) m |= d.c2_grad ? EPI_C2GRAD : EPI_GENERIC;
+    if (d.residual) m |= d.residual_first ? EPI_RES_FIRST : EPI_RES_LAST;
+    if (d.residual && d.residual_rows) m |= EPI_RES_ROWS;
+    if (d.act != 0 && !(d.C2 && d.c2_grad)) m |= EPI_ACT;
+    if (d.gate) {
+        const bool fast = d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64);
+        m |= !fast ? EPI_GENERIC : (d.gate_act < 0 ? EPI_GATE_MUL : EPI_GATE_OUT);
+    }
+    if (d.drop_thr) m |= EPI_DROP;
+    if (d.colsum) m |= EPI_COLSUM;
+    if (d.c_bf16) m |= EPI_CBF16;
+    if (d.beta != 0.f) m |= d.c_bf16 ? EPI_GENERIC : EPI_BETA;
+    return m;
+}
+#define EPI_HAS(bit, cond) ((MODE < 0) ? bool(cond) : bool(MODE & (bit)))
+
+template <bool FULL, int MODE = -1>
+__device__ __forceinline__ void epi_apply_t(const GemmK& d, float (&v)[4], int m, int n, long long coff, float (&csum)[4]) {
+    static_assert(FULL || MODE < 0, "specialised epilogues are for whole 4-element groups");
     const long long cidx = coff + (long long)m * d.ldc + n;
-    const bool full = (n + 3 < d.N) && d.cvec;
-    if (d.bias) {
-        if (full) {
+    if (EPI_HAS(EPI_BIAS, d.bias)) {
+        if constexpr (FULL) {
             const float4 b4 = *(const float4*)(d.bias + n);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         } else {
@@ -234,58 +301,63 @@ __device__ __forceinline__ void epi_apply(const GemmK& d, float (&v)[4], int m, 
     }
     float dact[4] = {1.f, 1.f, 1.f, 1.f};
     bool act_done = false;
-    if (d.C2 && d.c2_grad) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float y; act_fwd_bwd(d.act, v[e], y, dact[e]); v[e] = y; }
+    if (EPI_HAS(EPI_C2GRAD, d.C2 && d.c2_grad)) {
+        act_fwd_bwd4(d.act, v, dact);
         act_done = true;
     }
-    if (d.C2) {
-        const float* src = d.c2_grad ? dact : v;
-        if (d.c_bf16) {
+    if (EPI_HAS(EPI_C2GRAD, d.C2)) {
+        const float* src = EPI_HAS(EPI_C2GRAD, d.c2_grad) ? dact : v;
+        if (EPI_HAS(EPI_CBF16, d.c_bf16)) {
             bf16_t* c2 = (bf16_t*)d.C2 + cidx;
-            if (full) { bf16x4 o = {f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3])}; *(bf16x4*)c2 = o; }
+            if constexpr (FULL) { bf16x4 o = {f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3])}; *(bf16x4*)c2 = o; }
             else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(src[e]); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = f2bf(src[e]);
+            }
         } else {
             float* c2 = (float*)d.C2 + cidx;
-            if (full) *(float4*)c2 = make_float4(src[0], src[1], src[2], src[3]);
+            if constexpr (FULL) *(float4*)c2 = make_float4(src[0], src[1], src[2], src[3]);
             else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = src[e]; }
-        }
-    }
-    if (d.residual && d.residual_first) {
-        const long long rr = d.residual_rows ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
-        const float* r = d.residual + rr * d.ldr + n;
-        if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-        else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
-    }
-    if (d.act != ACT_NONE && !act_done) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fwd(d.act, v[e]);
-    }
-    if (d.gate && full && d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64)) {   // the train step's cases: one 8-byte load
-        const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n);
-        if (d.gate_act < 0) { v[0] *= bf2f(g4[0]); v[1] *= bf2f(g4[1]); v[2] *= bf2f(g4[2]); v[3] *= bf2f(g4[3]); }
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_bwd_from_output(d.gate_act - 64, bf2f(g4[e]));
-        }
-    } else if (d.gate) {
-        const long long gi = (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (n + e < d.N) {
-                const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
-                // gate_act < 0: gate already holds act'; >= 64: gate holds the activation's output
-                v[e] *= (d.gate_act < 0) ? gv : (d.gate_act >= 64 ? act_bwd_from_output(d.gate_act - 64, gv) : act_bwd(d.gate_act, gv));
+                for (int e = 0; e < 4; ++e) if (n + e < d.N) c2[e] = src[e];
             }
         }
     }
-    if (d.drop_thr) {
+    auto add_residual = [&]() {
+        const long long rr = EPI_HAS(EPI_RES_ROWS, d.residual_rows) ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
+        const float* r = d.residual + rr * d.ldr + n;
+        if constexpr (FULL) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e];
+        }
+    };
+    if (EPI_HAS(EPI_RES_FIRST, d.residual && d.residual_first)) add_residual();
+    if (EPI_HAS(EPI_ACT, d.act != ACT_NONE && !act_done)) act_fwd4(d.act, v);
+    if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT, d.gate)) {
+        bool done = false;
+        if constexpr (FULL) {
+            if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT, d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64))) {   // the train step's cases: one 8-byte load
+                const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n);
+                const float g[4] = {bf2f(g4[0]), bf2f(g4[1]), bf2f(g4[2]), bf2f(g4[3])};
+                if (EPI_HAS(EPI_GATE_MUL, d.gate_act < 0)) { v[0] *= g[0]; v[1] *= g[1]; v[2] *= g[2]; v[3] *= g[3]; }
+                else act_bwd_from_output_mul4(d.gate_act - 64, g, v);
+                done = true;
+            }
+        }
+        if (!done) {
+            const long long gi = (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < d.N) {
+                    const float gv = d.gate_bf16 ? bf2f(((const bf16_t*)d.gate)[gi + e]) : ((const float*)d.gate)[gi + e];
+                    // gate_act < 0: gate already holds act'; >= 64: gate holds the activation's output
+                    v[e] *= (d.gate_act < 0) ? gv : (d.gate_act >= 64 ? act_bwd_from_output(d.gate_act - 64, gv) : act_bwd(d.gate_act, gv));
+                }
+            }
+        }
+    }
+    if (EPI_HAS(EPI_DROP, d.drop_thr)) {
         // dropout stream index = element offset inside C (so a head-batched GEMM that writes
         // the merged (B*T', H) layout draws the same bits as a flat pass over that layout)
         const unsigned idx = (unsigned)cidx;
@@ -296,37 +368,38 @@ _Pragma("unroll")
             for (int e = 0; e < 4; ++e) v[e] = drop_keep(d.drop_key, d.drop_thr, idx + e) ? v[e] * d.drop_scale : 0.f;
         }
     }
-    if (d.residual && !d.residual_first) {
-        const long long rr = d.residual_rows ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
-        const float* r = d.residual + rr * d.ldr + n;
-        if (full) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-        else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += r[e]; }
-    }
-    if (d.colsum) {
+    if (EPI_HAS(EPI_RES_LAST, d.residual && !d.residual_first)) add_residual();
+    if (EPI_HAS(EPI_COLSUM, d.colsum)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) csum[e] += v[e];
     }
-    if (d.c_bf16) {
+    if (EPI_HAS(EPI_CBF16, d.c_bf16)) {
         bf16_t* c = (bf16_t*)d.C + cidx;
-        if (full) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
+        if constexpr (FULL) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)c = o; }
         else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = f2bf(v[e]);
+        }
     } else {
         float* c = (float*)d.C + cidx;
-        if (d.beta != 0.f) {
-            if (full) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
+        if (EPI_HAS(EPI_BETA, d.beta != 0.f)) {
+            if constexpr (FULL) { const float4 o = *(const float4*)c; v[0] += d.beta * o.x; v[1] += d.beta * o.y; v[2] += d.beta * o.z; v[3] += d.beta * o.w; }
             else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += d.beta * c[e];
+            }
         }
-        if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (FULL) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
         else {
-_Pragma("unroll")
-            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < d.N) c[e] = v[e];
+        }
     }
+}
+
+__device__ __forceinline__ void epi_apply(const GemmK& d, float (&v)[4], int m, int n, long long coff, float (&csum)[4]) {
+    if ((n + 3 < d.N) && d.cvec) epi_apply_t<true>(d, v, m, n, coff, csum);
+    else epi_apply_t<false>(d, v, m, n, coff, csum);
 }
 
 // ---- epilogue shared by both kernels. The wave owns rows [mw, mw + 16*MI) x cols [nw, nw + 16*NI);
@@ -444,14 +517,48 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[
                     make_float4(acc[ch * MC + mi][ni][0] * d.alpha, acc[ch * MC + mi][ni][1] * d.alpha, acc[ch * MC + mi][ni][2] * d.alpha,
                                 acc[ch * MC + mi][ni][3] * d.alpha);
         __syncthreads();
+        if (ch == 0) STAMP(6);
         if (n < d.N) {
             const int rstep = nthreads >> 5;
-            for (int r = t >> 5; r < rows; r += rstep) {
-                const int m = m0 + ch * rows + r;
-                if (m >= d.M) break;
-                const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
-                float v[4] = {a.x, a.y, a.z, a.w};
-                epi_apply(d, v, m, n, coff, csum);
+            if ((n + 3 < d.N) && d.cvec) {   // (the thread's columns are fixed: one decision for all its rows)
+#define NBCI_EPI_ROWS(MODE_)                                                         \
+    for (int r = t >> 5; r < rows; r += rstep) {                                     \
+        const int m = m0 + ch * rows + r;                                            \
+        if (m >= d.M) break;                                                         \
+        const float4 a = *(const float4*)(tile + r * EPI_LD + c4);                   \
+        float v[4] = {a.x, a.y, a.z, a.w};                                           \
+        epi_apply_t<true, MODE_>(d, v, m, n, coff, csum);                            \
+    }
+#define NBCI_EPI_CASE(MODE_) case (MODE_): NBCI_EPI_ROWS(MODE_) break;
+                switch (d.epi_mode) {   // the train steps' epilogues, straight-line; anything else: the run-time-tested loop
+                    NBCI_EPI_CASE(0)
+                    NBCI_EPI_CASE(EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_ACT | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_C2GRAD | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_DROP | EPI_RES_LAST)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_LAST)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS | EPI_DROP)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS)
+                    NBCI_EPI_CASE(EPI_DROP | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_COLSUM | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_MUL | EPI_COLSUM | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_MUL | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_OUT | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BETA)
+                    default: NBCI_EPI_ROWS(-1) break;
+                }
+#undef NBCI_EPI_CASE
+#undef NBCI_EPI_ROWS
+            } else {
+                for (int r = t >> 5; r < rows; r += rstep) {
+                    const int m = m0 + ch * rows + r;
+                    if (m >= d.M) break;
+                    const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
+                    float v[4] = {a.x, a.y, a.z, a.w};
+                    epi_apply_t<false>(d, v, m, n, coff, csum);
+                }
             }
         }
     }

@@ -21,6 +21,7 @@
 
 namespace nbci {
 
+
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x, const int block_y, char* smem) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -35,6 +36,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w / WN, wn = w % WN;
+    STAMP(0);
 
     // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (round-robin dispatch), so give every
     // XCD a contiguous run of work items. Split-K launches are 1-D over (split, tile) with the split
@@ -101,6 +103,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
         glds_stage<BKM, NPB, 4, VIEW>(gb, B, smem + A_BYTES, kt_begin, w);
     }
     __syncthreads();  // drains the LDS-DMA (hipcc emits vmcnt(0) ahead of the barrier)
+    STAMP(1);
     for (int kt = kt_begin; kt < kt_full_end; ++kt) {
 #if defined(NBCI_ABLATE) && NBCI_ABLATE == 2
         if (false) {
@@ -136,7 +139,17 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
         }
     }
     constexpr int CH = (WM == 1 && MI == 10) ? 2 : 1;   // 160-row tiles: two 80-row chunks (42 KB) keep two workgroups per CU
+    STAMP(2);
     gemm_epilogue_tile<MI, NI, CH>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, GEMM_THREADS, smem);
+    STAMP(3);
+#ifdef NBCI_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): this wave's stores acknowledged)
+    STAMP(4);
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
+        unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        g_stamps[blockIdx.x * 8 + 5] = hwid | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // XCC_ID
+    }
+#endif
 }
 
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
@@ -414,3 +427,9 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
 }
 
 }  // namespace nbci
+
+#ifdef NBCI_STAMPS
+extern "C" int nbci_debug_read_stamps(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nbci::g_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif
