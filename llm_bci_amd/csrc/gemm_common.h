@@ -255,6 +255,15 @@ __device__ __forceinline__ void act_bwd_from_output_mul4(int act, const float (&
 #undef NBCI_ACT4
 }
 
+__device__ __forceinline__ void act_bwd_mul4(int act, const float (&g)[4], float (&v)[4]) {
+#define NBCI_ACT4(CODE) case CODE: _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= act_bwd(CODE, g[e]); break;
+    switch (act) {
+        NBCI_ACT4(ACT_SOFTSIGN) NBCI_ACT4(ACT_GELU) NBCI_ACT4(ACT_RELU) NBCI_ACT4(ACT_TANH)
+        default: _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= act_bwd(ACT_NONE, g[e]); break;
+    }
+#undef NBCI_ACT4
+}
+
 // FULL: the lane's 4 elements are inside N and 16-byte accesses are legal -- decided ONCE per thread by the caller, so the row
 // loop carries one copy of each step instead of a vector / scalar branch at every load and store. (In-kernel stamps,
 // tools/gemm_stamps.py: the branch maze of the one-size-fits-all version cost ~900 cycles per output row, 7.2 us of a 24 us
@@ -265,7 +274,7 @@ __device__ __forceinline__ void act_bwd_from_output_mul4(int act, const float (&
 // cost 6 us of a 24 us K = 1024 tile after the first clean-up (7.2 before).
 enum : int {
     EPI_BIAS = 1, EPI_C2GRAD = 2, EPI_RES_FIRST = 4, EPI_RES_LAST = 8, EPI_RES_ROWS = 16, EPI_ACT = 32, EPI_GATE_MUL = 64,
-    EPI_GATE_OUT = 128, EPI_DROP = 256, EPI_COLSUM = 512, EPI_CBF16 = 1024, EPI_BETA = 2048, EPI_GENERIC = 1 << 30
+    EPI_GATE_OUT = 128, EPI_DROP = 256, EPI_COLSUM = 512, EPI_CBF16 = 1024, EPI_BETA = 2048, EPI_GATE_PRE = 4096, EPI_GENERIC = 1 << 30
 };
 __host__ __device__ inline int epi_mode_of(const GemmK& d) {
     int m = 0;
@@ -275,8 +284,8 @@ __host__ __device__ inline int epi_mode_of(const GemmK& d) {
     if (d.residual && d.residual_rows) m |= EPI_RES_ROWS;
     if (d.act != 0 && !(d.C2 && d.c2_grad)) m |= EPI_ACT;
     if (d.gate) {
-        const bool fast = d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64);
-        m |= !fast ? EPI_GENERIC : (d.gate_act < 0 ? EPI_GATE_MUL : EPI_GATE_OUT);
+        const bool fast = d.gate_bf16 && (d.ldg & 3) == 0;   // one 8-byte load per 4 outputs
+        m |= !fast ? EPI_GENERIC : (d.gate_act < 0 ? EPI_GATE_MUL : (d.gate_act >= 64 ? EPI_GATE_OUT : EPI_GATE_PRE));
     }
     if (d.drop_thr) m |= EPI_DROP;
     if (d.colsum) m |= EPI_COLSUM;
@@ -334,14 +343,15 @@ __device__ __forceinline__ void epi_apply_t(const GemmK& d, float (&v)[4], int m
     };
     if (EPI_HAS(EPI_RES_FIRST, d.residual && d.residual_first)) add_residual();
     if (EPI_HAS(EPI_ACT, d.act != ACT_NONE && !act_done)) act_fwd4(d.act, v);
-    if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT, d.gate)) {
+    if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT | EPI_GATE_PRE, d.gate)) {
         bool done = false;
         if constexpr (FULL) {
-            if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT, d.gate_bf16 && (d.ldg & 3) == 0 && (d.gate_act < 0 || d.gate_act >= 64))) {   // the train step's cases: one 8-byte load
+            if (EPI_HAS(EPI_GATE_MUL | EPI_GATE_OUT | EPI_GATE_PRE, d.gate_bf16 && (d.ldg & 3) == 0)) {   // the train step's cases: one 8-byte load
                 const bf16x4 g4 = *(const bf16x4*)((const bf16_t*)d.gate + (d.gate_coff ? coff : 0) + (long long)m * d.ldg + n);
                 const float g[4] = {bf2f(g4[0]), bf2f(g4[1]), bf2f(g4[2]), bf2f(g4[3])};
                 if (EPI_HAS(EPI_GATE_MUL, d.gate_act < 0)) { v[0] *= g[0]; v[1] *= g[1]; v[2] *= g[2]; v[3] *= g[3]; }
-                else act_bwd_from_output_mul4(d.gate_act - 64, g, v);
+                else if (EPI_HAS(EPI_GATE_OUT, d.gate_act >= 64)) act_bwd_from_output_mul4(d.gate_act - 64, g, v);   // gate = the activation's output
+                else act_bwd_mul4(d.gate_act, g, v);                                                                    // gate = the pre-activation
                 done = true;
             }
         }
@@ -547,6 +557,14 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[
                     NBCI_EPI_CASE(EPI_GATE_MUL | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_GATE_OUT | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_BETA)
+                    NBCI_EPI_CASE(EPI_RES_LAST)                                             // iTransformer / PatchTST
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_DROP)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_ACT | EPI_DROP | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_C2GRAD | EPI_DROP | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_MUL | EPI_DROP | EPI_COLSUM | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_PRE | EPI_DROP | EPI_COLSUM)
+                    NBCI_EPI_CASE(EPI_GATE_PRE | EPI_COLSUM | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_GATE_PRE | EPI_DROP | EPI_COLSUM | EPI_CBF16)
                     default: NBCI_EPI_ROWS(-1) break;
                 }
 #undef NBCI_EPI_CASE
