@@ -41,6 +41,40 @@ __device__ __forceinline__ void load_image(char* img, const bf16_t* src, long lo
     }
 }
 
+// per-workgroup key table in LDS: 1 = the key exists and is unmasked. (Read from global per score element it was 40 dependent
+// loads per lane and the longest phase of the forward kernel: 6.2 of 17 us per workgroup, in-kernel stamps, tools/attn_stamps.py.)
+__device__ __forceinline__ void load_key_valid(int* kv, const int32_t* tmask_row, int Tp, int tid) {
+    for (int i = tid; i < AT_TPAD; i += (int)blockDim.x) kv[i] = (i < Tp && tmask_row[i] != 0) ? 1 : 0;
+}
+
+// K and V images together, every global load of a pass issued before the first LDS store. (One load -> one store per
+// iteration, as load_image does, exposed a memory round trip per 16-byte chunk: 4.2 of the forward kernel's 15 us.)
+__device__ __forceinline__ void load_images_kv(char* sK, char* sV, const bf16_t* srcK, const bf16_t* srcV, long long ld, int nrows, int tid) {
+    constexpr int U = 5;   // 2560 chunks per image / 576 threads (143 tokens -> 9 waves)
+    const int nthr = (int)blockDim.x;
+    for (int i0 = tid; i0 < AT_TPAD * 16; i0 += U * nthr) {
+        uint4 vk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr, row = i >> 4, ch = i & 15;
+            vk[u] = make_uint4(0u, 0u, 0u, 0u);
+            vv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < AT_TPAD * 16 && row < nrows) {
+                vk[u] = *(const uint4*)(srcK + (long long)row * ld + ch * 8);
+                vv[u] = *(const uint4*)(srcV + (long long)row * ld + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr, row = i >> 4, ch = i & 15;
+            if (i < AT_TPAD * 16) {
+                *(uint4*)(sK + img_off(row, ch)) = vk[u];
+                *(uint4*)(sV + img_off(row, ch)) = vv[u];
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int ks, int g) {
     return *(const bf16x8*)(img + img_off(row, 4 * ks + g));
 }
@@ -98,18 +132,21 @@ __device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4
 }
 
 // masked softmax of the register-resident row; returns normalised probabilities in place
-__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, int b, int query, int g, float* lse_out) {
+__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, const int* kv, int query, int g, float* lse_out) {
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
+    for (int kb = 0; kb < AT_NB; ++kb) {
+        const int4 k4 = *(const int4*)(kv + 16 * kb + 4 * g);
+        const int kvr[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * kb + 4 * g + r;
-            const bool ok = key < a.Tp && ((key == query) || (ctx_ok(query, key, a.cf, a.cb) && a.tmask[b * a.Tp + key] != 0));
+            const bool ok = (key == query) || (ctx_ok(query, key, a.cf, a.cb) && kvr[r] != 0);   // (query < Tp; kv = 0 beyond Tp)
             const float s = ok ? acc[kb][r] * a.scale : -INFINITY;
             acc[kb][r] = s;
             mx = fmaxf(mx, s);
         }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -136,8 +173,16 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
     return o;
 }
 
+#ifdef NBCI_STAMPS   // measurement build only (tools/attn_stamps.py): wall-clock stamps (100 MHz) of wave 0's phases per workgroup
+static __device__ unsigned long long g_astamps[1024 * 8];
+#define ASTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_astamps[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define ASTAMP(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ASTAMP(0);
     char* sK = smem;
     char* sV = smem + AT_TPAD * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,9 +190,11 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
-    load_image(sK, base + a.H, ld, a.Tp, tid);
-    load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
+    load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid);
+    int* sKV = (int*)(smem + 2 * AT_TPAD * 256);
+    load_key_valid(sKV, a.tmask + (long long)b * a.Tp, a.Tp, tid);
     __syncthreads();
+    ASTAMP(1);
     const int nqb = (a.Tp + 15) / 16;
     for (int qb = wave; qb < nqb; qb += (int)(blockDim.x >> 6)) {
         const int query = 16 * qb + i16;
@@ -157,7 +204,9 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
         f32x4 acc[AT_NB];
         score_block(sK, qf, acc, i16, g);
-        softmax_rows(acc, a, b, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
+        ASTAMP(2);
+        softmax_rows(acc, a, sKV, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
+        ASTAMP(3);
         if (a.p_thr) {
             const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
 #pragma unroll
@@ -169,6 +218,7 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
                 }
         }
         f32x4 o[8];
+        ASTAMP(4);
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -180,6 +230,7 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
                                                                 o[db], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        ASTAMP(5);
         if (query < a.Tp) {
             const long long obase = ((long long)b * a.Tp + query) * a.H + h * AT_HD;
 #pragma unroll
@@ -192,6 +243,7 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
             }
         }
     }
+    ASTAMP(6);
 }
 
 __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
@@ -205,8 +257,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnArgs a) {   // one
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
-    load_image(sK, base + a.H, ld, a.Tp, tid);
-    load_image(sV, base + 2 * a.H, ld, a.Tp, tid);
+    load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid);
     __syncthreads();
     const int nqb = (a.Tp + 15) / 16;
     const float inv_o_scale = 1.0f / a.o_scale;
@@ -257,6 +308,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnArgs a) {   // one
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * kb + 4 * g + r;
+                    // (the forward kernel's LDS key table does not pay here: the reads are hoisted and this kernel, at its 168-VGPR limit, spills)
                     const bool ok = key < a.Tp && ((key == qrow) || (ctx_ok(qrow, key, a.cf, a.cb) && a.tmask[b * a.Tp + key] != 0));
                     const float p = ok ? __expf(sc[j][r] * a.scale - lse) : 0.f;
                     float keep = (key < a.Tp) ? 1.f : 0.f;
@@ -399,7 +451,7 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse,
                     uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
     static bool once = false;
-    const int lds = 2 * AT_TPAD * 256;
+    const int lds = 2 * AT_TPAD * 256 + AT_TPAD * 4;
     if (!once) { int r = set_lds((const void*)attn_fwd_kernel, lds); if (r) return r; once = true; }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
@@ -436,3 +488,9 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const
 }
 
 }  // namespace nbci
+
+#ifdef NBCI_STAMPS
+extern "C" int nbci_debug_read_attn_stamps(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nbci::g_astamps), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif
