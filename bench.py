@@ -123,11 +123,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        tr.train_step(batch, seed=100 + i)
+        tr.train_step(batch, seed=100 + i + 100003 * rank)   # per-rank dropout / noise streams, as DDP ranks have
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tr.train_step(batch, seed=1000 + i)
+        tr.train_step(batch, seed=1000 + i + 100003 * rank)
     sync()
     el = time.perf_counter() - t0
     if world > 1:
@@ -145,7 +145,7 @@ def main():
             check(l.nbci_profile_enable(1), "profile_enable")
         nprof = 3
         for i in range(nprof):
-            tr.train_step(batch, seed=5000 + i)
+            tr.train_step(batch, seed=5000 + i + 100003 * rank)
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         out = (C.c_double * 24)()
