@@ -41,6 +41,7 @@ constexpr int F32_RM_STRIDE = 144;  // dwords per row, row-major f32 tile [16][1
 
 #ifdef NBCI_STAMPS   // measurement build only (tools/gemm_stamps.py): per-workgroup wall-clock stamps (100 MHz) of the kernel's phases
 static __device__ unsigned long long g_stamps[8192 * 8];
+static __device__ unsigned long long g_kstamps[1024 * 64];   // [workgroup][K tile 4..11][slot]
 #define STAMP(slot)                                                                                   \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (slot)] = wall_clock64(); \

@@ -164,7 +164,8 @@ __device__ __forceinline__ void tr_read_frags(bf16x8 (&f)[N], const unsigned (&b
 // ITS fragments have landed — a counted lgkmcnt: LDS reads return in order, and scalar loads that may also be
 // outstanding only make a counted wait conservative — while the second k-step's reads are still in flight.
 template <bool AK, bool BKM, int MI, int NI>
-__device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane) {
+__device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f32x4 (&acc)[MI][NI], int ar0, int bc0, int lane,
+                                               unsigned long long* kst = nullptr) {   // kst: measurement build only (K-loop stamps)
     const int i16 = lane & 15, g = lane >> 4;
     bf16x8 af[2][MI], bf[2][NI];
     unsigned ka[2] = {0u, 0u}, kb[2] = {0u, 0u}, ta[MI], tb[NI];
@@ -193,6 +194,9 @@ __device__ __forceinline__ void compute_tile_g(const char* sA, const char* sB, f
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#ifdef NBCI_STAMPS
+    if (kst) { kst[2] = clock64(); __builtin_amdgcn_sched_barrier(0); }   // (lgkmcnt is drained here anyway: s_memtime shares it with the LDS reads)
+#endif
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

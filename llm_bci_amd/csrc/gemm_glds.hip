@@ -105,6 +105,12 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
     __syncthreads();  // drains the LDS-DMA (hipcc emits vmcnt(0) ahead of the barrier)
     STAMP(1);
     for (int kt = kt_begin; kt < kt_full_end; ++kt) {
+#ifdef NBCI_STAMPS   // K-loop stamps (shader cycles) of wave 0, K tiles 4..11: 0 loop top, 1 LDS-DMA issued, 2 first k-step's MFMAs issued +
+                     // second k-step's fragments landed, 3 second k-step's MFMAs issued, 4 past the barrier
+        unsigned long long* kst = (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024 && kt >= 4 && kt < 12)
+                                      ? g_kstamps + ((size_t)blockIdx.x * 8 + (kt - 4)) * 8 : nullptr;
+        if (kst) kst[0] = clock64();
+#endif
 #if defined(NBCI_ABLATE) && NBCI_ABLATE == 2
         if (false) {
 #else
@@ -115,8 +121,16 @@ __device__ __forceinline__ void gemm_glds_body(const GemmK& d, const int block_x
             glds_stage<BKM, NPB, 4, VIEW>(gb, B, nx + A_BYTES, kt + 1, w);
         }
         const char* sA = smem + cur * STAGE;
+#ifdef NBCI_STAMPS
+        if (kst) kst[1] = clock64();
+        compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane, kst);
+        if (kst) kst[3] = clock64();
+        __syncthreads();
+        if (kst) kst[4] = clock64();
+#else
         compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
         __syncthreads();
+#endif
         cur ^= 1;
     }
     if constexpr (BM == 128) {
@@ -429,6 +443,9 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
 }  // namespace nbci
 
 #ifdef NBCI_STAMPS
+extern "C" int nbci_debug_read_kstamps(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nbci::g_kstamps), (size_t)nblocks * 64 * sizeof(unsigned long long));
+}
 extern "C" int nbci_debug_read_stamps(unsigned long long* host, int nblocks) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nbci::g_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long));
 }

@@ -72,3 +72,23 @@ one = ids[len(ids) // 2]
 print(f"timeline of CU {one}: (entry, K loop start, K loop end, stores issued, acknowledged)")
 for row in sorted(us[cu == one].tolist()):
     print("   " + "  ".join(f"{x:7.2f}" for x in row))
+
+# ---- K-loop stamps (shader cycles), wave 0 of each workgroup, K tiles 4..11
+try:
+    rk = lib().nbci_debug_read_kstamps
+except AttributeError:
+    rk = None
+if rk is not None:
+    rk.argtypes = [C.c_void_p, C.c_int]
+    nb = min(1024, nblk)
+    kb = np.zeros((nb, 8, 8), dtype=np.uint64)
+    assert rk(kb.ctypes.data, nb) == 0
+    k = kb[kb[:, :, 0].min(axis=1) > 0].astype(np.int64)
+    if len(k):
+        print(f"K loop, per K tile (shader cycles; wave 0 of {len(k)} workgroups x 8 tiles; MFMA work of the wave per tile = "
+              f"36 x 16 = 576 cycles at the 144-row tile):")
+        names = ("LDS-DMA issue (0->1)", "reads + first k-step issued, second landed (1->2)", "second k-step MFMAs issued (2->3)",
+                 "barrier incl. next tile's vmcnt (3->4)", "loop top -> loop top")
+        for i, nm in enumerate(names[:4]):
+            print(f"  {nm:52s}", q((k[:, :, i + 1] - k[:, :, i]).ravel()))
+        print(f"  {names[4]:52s}", q((k[:, 1:, 0] - k[:, :-1, 0]).ravel()))
