@@ -21,6 +21,7 @@ from . import ops
 from ._lib import ACT, NBCI_BF16, NBCI_F32, check, lib
 from .config import DictConfig, update_config
 from .model_output import ModelOutput
+from .flat import bridge_begin, bridge_check
 from .ndt1 import NDT1, _ptr, _stream
 
 
@@ -46,14 +47,16 @@ class _EncodeFn(torch.autograd.Function):
         dt = torch.bfloat16 if model.compute_dtype == NBCI_BF16 else torch.float32
         hidden = torch.empty(B, Tp, model._ccfg.factors_size or model._ccfg.hidden, dtype=dt, device=batch["spikes"].device)
         tmask = torch.empty(B, Tp, dtype=torch.int32, device=hidden.device)
+        bridge_begin(model)   # torch.optim steps the f32 views in place: rebuild the bf16 shadow when they moved
         model._run_forward(batch, want_grad=True, hidden_out=hidden, token_mask_out=tmask)
-        ctx.model = model
+        ctx.model, ctx.fwd_id = model, model._fwd_id
         ctx.mark_non_differentiable(tmask)
         return hidden, tmask
 
     @staticmethod
     def backward(ctx, g_hidden, _g_mask):
         m = ctx.model
+        bridge_check(m, ctx.fwd_id, "_EncodeFn")
         grads = torch.zeros_like(m._flat)
         m._run_backward(grads, d_hidden=g_hidden.float().contiguous())
         out = [None, None]
@@ -210,7 +213,7 @@ class BCI(nn.Module):
                        block_idx=None, day_idx=None, targets=None):
         text_embeds = self.llm.get_input_embeddings()(input_ids)                      # stock HF embedding lookup
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_timestamp=spikes_timestamp, spikes_lengths=spikes_lengths,
-                     targets=None, targets_lengths=None)
+                     targets=None, targets_lengths=None, day_idx=day_idx, block_idx=block_idx)
         hidden, tmask = _EncodeFn.apply(self.ndt1, batch, *self.ndt1._param_list)     # (B,T',H), (B,T')
         B, T, H = hidden.shape
         s = self.stacking

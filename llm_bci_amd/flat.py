@@ -23,6 +23,30 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def bridge_begin(model):
+    """Top of every autograd-bridge forward. The bf16 shadow is only kept in sync by the fused AdamW of NativeTrainer; on the
+    registry-swap route (loss.backward() + torch.optim.* on model.parameters()) the optimizer writes the f32 views in place, so the
+    shadow is rebuilt whenever any parameter's version counter moved since it was taken."""
+    if model.compute_dtype == NBCI_BF16:
+        ver = sum(p._version for p in model._param_list)
+        if model._flat_lp is None or getattr(model, "_lp_version", None) != ver:
+            model.refresh_lp()
+            model._lp_version = ver
+
+
+def bridge_stamp(model):
+    """Every forward gets a number; a bridge backward refuses to run on another forward's saved activations (the workspace and
+    the borrowed io tensors are single-slot state of the most recent forward)."""
+    model._fwd_id = getattr(model, "_fwd_id", 0) + 1
+    return model._fwd_id
+
+
+def bridge_check(model, fwd_id, what):
+    if getattr(model, "_fwd_id", None) != fwd_id:
+        raise RuntimeError(f"{what}: backward of forward #{fwd_id} requested, but the model has since run forward "
+                           f"#{getattr(model, '_fwd_id', None)}; its saved activations are gone (one grad-enabled forward per backward)")
+
+
 class LayoutBuilder:
     """Same placement rule as the C++ plans: tensors in canonical order, each aligned to 8 elements, segments too."""
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import ACT, LOSS_KIND, MASK_MODE, NBCI_BF16, NBCI_F32, ItrConfig, ItrIO, MaskerDesc, check, lib
 from .config import DictConfig, itransformer_config, update_config
-from .flat import FlatParamModule, LayoutBuilder, _ptr, _stream
+from .flat import FlatParamModule, LayoutBuilder, bridge_begin, bridge_check, bridge_stamp, _ptr, _stream
 from .model_output import ModelOutput
 
 SITE_MASKER = 64   # + 8 * masker index: +0 mask, +1 zero, +2 random-select, +3 random values, +4 timespan
@@ -136,13 +136,14 @@ class _ItrFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, *params):
         loss, preds = model._run_forward(batch, want_grad=True)
-        ctx.model = model
+        ctx.model, ctx.fwd_id = model, model._fwd_id
         ctx.mark_non_differentiable(preds)
         return loss.sum(), preds
 
     @staticmethod
     def backward(ctx, g_loss, _g_preds):
         m = ctx.model
+        bridge_check(m, ctx.fwd_id, "_ItrFunction")
         grads = torch.zeros_like(m._flat)
         m._run_backward(grads)
         grads.mul_(g_loss.to(grads.dtype))
@@ -302,6 +303,7 @@ class iTransformer(FlatParamModule):
         if not spikes.is_cuda:
             raise _lib.NbciUnavailable("iTransformer (HIP path) needs tensors on a ROCm device; there is no CPU fallback")
         self._ensure_plan()
+        bridge_stamp(self)
         if self.compute_dtype == NBCI_BF16 and self._flat_lp is None:
             self.refresh_lp()
         dev = spikes.device
@@ -355,6 +357,7 @@ class iTransformer(FlatParamModule):
     def forward(self, spikes, spikes_mask, spikes_timestamp, spikes_spacestamp=None, spikes_lengths=None, targets=None,
                 targets_lengths=None, neuron_regions=None, neuron_depths=None):
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_spacestamp=spikes_spacestamp, neuron_regions=neuron_regions)
+        bridge_begin(self)   # an external optimizer may have stepped the f32 views since the bf16 shadow was taken
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list):
             loss, preds = _ItrFunction.apply(self, batch, *self._param_list)
         else:

@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import ACT, NBCI_BF16, NBCI_F32, NDT1IO, NDT1Config, check, lib
 from .config import DictConfig, ndt1_config, update_config
+from .flat import bridge_begin, bridge_check, bridge_stamp
 from .model_output import NDT1Output
 
 
@@ -44,13 +45,14 @@ class _NDT1Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, *params):
         loss_vec, preds = model._run_forward(batch, want_grad=True)
-        ctx.model = model
+        ctx.model, ctx.fwd_id = model, model._fwd_id
         ctx.mark_non_differentiable(preds)
         return loss_vec.sum(), preds
 
     @staticmethod
     def backward(ctx, g_loss, _g_preds):
         m = ctx.model
+        bridge_check(m, ctx.fwd_id, "_NDT1Function")
         grads = torch.zeros_like(m._flat)
         m._run_backward(grads)
         grads.mul_(g_loss.to(grads.dtype))
@@ -347,6 +349,7 @@ class NDT1(nn.Module):
         if not spikes.is_cuda:
             raise _lib.NbciUnavailable("NDT1 (HIP path) needs tensors on a ROCm device; there is no CPU fallback")
         self._ensure_plan()
+        bridge_stamp(self)
         if self.compute_dtype == NBCI_BF16 and self._flat_lp is None:
             self.refresh_lp()
         dev = spikes.device
@@ -430,6 +433,7 @@ class NDT1(nn.Module):
                 block_idx=None, day_idx=None):
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_timestamp=spikes_timestamp,
                      spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths, day_idx=day_idx, block_idx=block_idx)
+        bridge_begin(self)   # an external optimizer may have stepped the f32 views since the bf16 shadow was taken
         if torch.is_grad_enabled() and targets is not None and any(p.requires_grad for p in self._param_list):
             loss, preds = _NDT1Function.apply(self, batch, *self._param_list)
         else:

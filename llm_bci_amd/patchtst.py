@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import ACT, LOSS_KIND, NBCI_BF16, NBCI_F32, PtstConfig, PtstIO, check, lib
 from .config import DictConfig, patchtst_config, update_config
-from .flat import FlatParamModule, LayoutBuilder, _Box, _ptr, _stream
+from .flat import FlatParamModule, LayoutBuilder, bridge_begin, bridge_check, bridge_stamp, _Box, _ptr, _stream
 from .model_output import ModelOutput
 from .patchtst_init import reference_order_init
 
@@ -72,13 +72,14 @@ class _PtstFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, *params):
         loss, preds = model._run_forward(batch, want_grad=True)
-        ctx.model = model
+        ctx.model, ctx.fwd_id = model, model._fwd_id
         ctx.mark_non_differentiable(preds)
         return loss.sum(), preds
 
     @staticmethod
     def backward(ctx, g_loss, _g_preds):
         m = ctx.model
+        bridge_check(m, ctx.fwd_id, "_PtstFunction")
         grads = torch.zeros_like(m._flat)
         m._run_backward(grads)
         grads.mul_(g_loss.to(grads.dtype))
@@ -280,6 +281,7 @@ class PatchTSTForSpikingActivity(FlatParamModule):
         if not spikes.is_cuda:
             raise _lib.NbciUnavailable("PatchTST (HIP path) needs tensors on a ROCm device; there is no CPU fallback")
         self._ensure_plan()
+        bridge_stamp(self)
         if self.compute_dtype == NBCI_BF16 and self._flat_lp is None:
             self.refresh_lp()
         c = self._ccfg
@@ -355,6 +357,7 @@ class PatchTSTForSpikingActivity(FlatParamModule):
     def forward(self, spikes, spikes_mask, spikes_lengths=None, targets=None, targets_lengths=None):
         batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_lengths=spikes_lengths, targets=targets, targets_lengths=targets_lengths)
         has_loss = self.method == "mlm" or targets is not None
+        bridge_begin(self)   # an external optimizer may have stepped the f32 views since the bf16 shadow was taken
         if torch.is_grad_enabled() and has_loss and any(p.requires_grad for p in self._param_list):
             loss, preds = _PtstFunction.apply(self, batch, *self._param_list)
         else:

@@ -177,6 +177,8 @@ class NativeTrainer:
         """Reference Trainer.evaluate (trainer.py:273-309): eval mode, sum-loss / sum-examples and the
         mean of per-batch PER ratios over `batches` (an iterable of device batches)."""
         m = self.model
+        if self._mstream is not None:   # the last train_step's side-stream metric still reads loss / argmax / targets and _per_bufs
+            torch.cuda.current_stream().wait_stream(self._mstream)
         was_training = m.training
         m.eval()
         acc = torch.zeros(4, dtype=torch.float64, device=m._flat.device)
@@ -199,6 +201,8 @@ class NativeTrainer:
         import os
         if rank != 0:
             return
+        if self._mstream is not None:
+            torch.cuda.current_stream().wait_stream(self._mstream)
         self.model.save_checkpoint(save_dir)
         m = self.model
         state = {"layout": [(n, o, k) for (n, o, k, _s, _g) in m._layout], "m": self.m.cpu(), "v": self.v.cpu(),

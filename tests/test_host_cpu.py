@@ -124,3 +124,71 @@ def test_product_collate_matches_reference_fixture_and_oracle():
         a = PC.padded_array(arrs, dim=0, **kw).numpy()
         b = OC.padded_array(arrs, dim=0, **kw)
         assert np.array_equal(a, b), kw
+
+
+def test_linear_step_and_onecycle_schedules_match_torch_and_hf_over_a_whole_run():
+    """trainer.py:233-253: "linear" = transformers.get_linear_schedule_with_warmup, "step" = StepLR(step_size=1, gamma) stepped per
+    epoch (trainer.py:418-419), "cosine" = OneCycleLR (also with a warm-up leg, pct_start 0.15 as trainer_ssl_itransformer.yaml).
+    The values each optimizer.step() uses, for every step of a run, from the libraries themselves."""
+    import torch
+    from torch.optim.lr_scheduler import OneCycleLR, StepLR
+    from transformers import get_linear_schedule_with_warmup
+    from llm_bci_amd.schedule import LinearWarmup, OneCycle, StepDecay
+
+    def opt():
+        return torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=2e-3)
+
+    total, warm_pct = 57, 0.15
+    o = opt(); sch = get_linear_schedule_with_warmup(o, num_warmup_steps=round(warm_pct * total), num_training_steps=total)
+    mine = LinearWarmup(total, 2e-3, round(warm_pct * total))
+    for s in range(total):
+        lr, b1 = mine.at(s)
+        assert abs(lr - o.param_groups[0]["lr"]) < 1e-15 and b1 == 0.9, s
+        o.step(); sch.step()
+    o = opt(); sch = OneCycleLR(o, total_steps=total, max_lr=2e-3, pct_start=warm_pct, div_factor=25.0)
+    mine = OneCycle(total, 2e-3, warm_pct, 25.0)
+    for s in range(total):
+        lr, b1 = mine.at(s)
+        assert abs(lr - o.param_groups[0]["lr"]) < 1e-15 and abs(b1 - o.param_groups[0]["betas"][0]) < 1e-12, s
+        o.step(); sch.step()
+    o = opt(); sch = StepLR(o, step_size=1, gamma=0.95)
+    mine = StepDecay(2e-3, 0.95)
+    for epoch in range(6):
+        for s in range(5):
+            lr, b1 = mine.at(epoch * 5 + s)
+            assert abs(lr - o.param_groups[0]["lr"]) < 1e-15 and b1 == 0.9
+            o.step()
+        sch.step(); mine.end_epoch()
+
+
+def test_bridge_shadow_and_forward_stamp_logic():
+    """flat.bridge_begin rebuilds the bf16 shadow exactly when a parameter's version counter moved (an external optimizer's
+    in-place step), bridge_check refuses a backward whose forward is no longer the model's most recent one."""
+    import torch
+    from llm_bci_amd._lib import NBCI_BF16
+    from llm_bci_amd.flat import bridge_begin, bridge_check, bridge_stamp
+
+    class Fake:
+        compute_dtype = NBCI_BF16
+        def __init__(self):
+            self._flat = torch.arange(8, dtype=torch.float32)
+            self._param_list = [torch.nn.Parameter(self._flat[0:4]), torch.nn.Parameter(self._flat[4:8])]
+            for p, (a, b) in zip(self._param_list, ((0, 4), (4, 8))):
+                p.data = self._flat[a:b]
+            self._flat_lp, self.n_refresh = None, 0
+        def refresh_lp(self):
+            self._flat_lp = self._flat.to(torch.bfloat16); self.n_refresh += 1
+
+    m = Fake()
+    bridge_begin(m); bridge_begin(m)
+    assert m.n_refresh == 1
+    opt = torch.optim.SGD(m._param_list, lr=1.0)
+    for p in m._param_list:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    bridge_begin(m)
+    assert m.n_refresh == 2 and torch.equal(m._flat_lp.float(), m._flat)
+    a = bridge_stamp(m); bridge_check(m, a, "t")
+    bridge_stamp(m)
+    with pytest.raises(RuntimeError):
+        bridge_check(m, a, "t")

@@ -390,3 +390,92 @@ def test_embedder_backward_in_two_parts(variant):
     assert torch.equal(after1[split:e0], g2[split:e0])          # part 2 writes nothing on part 1's side
     assert float(g2[b0:split].abs().sum()) > 0
     assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-5 * float(g1.abs().max()))
+
+
+def test_c2_bf16_per_parity(capsys):
+    """PER parity of the bf16 path at C2 (the dtype bench.py times) against the reference's fp32 run recorded in g_c2.npz.
+    (a) the device decode + edit distance on the bf16 greedy path is bit-exact against the oracle's format_ctc / word_error_count
+        on the same path; (b) token counts equal the fixture's exactly and the error count differs from the fixture's by no more
+        than the number of frames whose argmax flipped (each flipped frame changes the collapsed sequence by at most one edit);
+    (c) every flipped frame has an fp32 top-2 margin below 0.1 nats. The measured flip rate is printed."""
+    from llm_bci_amd.trainer import NativeTrainer
+    fx = load("g_c2")
+    m = _model(_det_over("{}"), 41, dtype="bf16").to(DEV)
+    batch = _to_dev(batch_of(fx))
+    m.eval()
+    tr = NativeTrainer(m, total_steps=4)
+    with torch.no_grad():
+        m._run_forward(batch, want_grad=False)
+        err = tr._per(batch).cpu().numpy()
+    torch.cuda.synchronize()
+    am = m.last_argmax.cpu().numpy()
+    flips = am != fx["argmax"]
+    tg, tl = fx["in_targets"], fx["in_targets_lengths"].reshape(-1)
+    errs = toks = 0
+    for b in range(am.shape[0]):
+        dec = OM.format_ctc(am[b], 0)
+        tt = list(tg[b, :tl[b]])
+        e = OM.edit_distance(dec if dec else [""], tt if tt else [""])
+        assert (e, max(1, len(tt))) == tuple(err[b]), b          # (a) device metric == oracle metric on the bf16 path
+        errs += e; toks += max(1, len(tt))
+    assert toks == int(fx["per_tokens"])
+    assert abs(errs - int(fx["per_errors"])) <= int(flips.sum())
+    assert fx["margin"][flips].max(initial=0.0) < 0.1
+    with capsys.disabled():
+        print(f"\n[bf16 PER parity @C2] argmax flips {int(flips.sum())}/{flips.size} = {100.0 * flips.mean():.2f} % "
+              f"(largest fp32 margin among them {fx['margin'][flips].max(initial=0.0):.4f}); "
+              f"PER bf16 {errs}/{toks} vs reference fp32 {int(fx['per_errors'])}/{int(fx['per_tokens'])}")
+
+
+def _tiny_over():
+    return {"encoder": {"smooth_and_noise": {"noise": False},
+                        "embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}, "dropout": 0.0},
+                        "transformer": {"n_layers": 2, "hidden_size": 64, "n_heads": 2, "inter_size": 64, "dropout": 0.0}}}
+
+
+def test_bf16_registry_swap_route_trains_every_weight():
+    """The documented drop-in route: model(**batch).loss.backward() + torch.optim.AdamW(model.parameters()).
+    The optimizer steps the f32 views in place; the bf16 shadow the GEMMs read must follow (it did not in round 1: weight
+    matrices stayed frozen). Three steps in bf16 track the same three steps in fp32, and the eval forward after them (no_grad
+    route) sees the updated weights too."""
+    batch = _to_dev(_rand_batch(4, 40, 16, 5, 11, [40, 40, 36, 30], [5, 4, 3, 5]))
+    runs = {}
+    for dt in ("fp32", "bf16"):
+        m = _model(_tiny_over(), 11, dtype=dt).to(DEV)
+        w0 = dict(m.named_parameters())["encoder.layers.0.attn.query.weight"].detach().clone()
+        opt = torch.optim.AdamW(m.parameters(), lr=3e-3, weight_decay=0.0)
+        losses = []
+        m.train()
+        for _ in range(3):
+            out = m(**batch)
+            out.loss.backward()
+            opt.step(); opt.zero_grad()
+            losses.append(out.loss.item())
+        m.eval()
+        with torch.no_grad():
+            ev = m(**batch)
+        torch.cuda.synchronize()
+        w1 = dict(m.named_parameters())["encoder.layers.0.attn.query.weight"].detach()
+        assert (w1 - w0).abs().max() > 1e-4                      # the f32 weight moved ...
+        if dt == "bf16":                                         # ... and the shadow the kernels read equals its rounding
+            assert torch.equal(m._flat_lp, m._flat.to(torch.bfloat16))
+        runs[dt] = (losses, ev.loss.item(), ev.preds.cpu().numpy())
+    lf, lb = runs["fp32"][0], runs["bf16"][0]
+    assert lf[2] < lf[0] and lb[2] < lb[0]                       # training moves the loss
+    for a, b in zip(lf, lb):
+        assert abs(a - b) / abs(a) < 0.02, (lf, lb)              # bf16 tracks fp32 step by step (a frozen shadow does not)
+    assert abs(runs["fp32"][1] - runs["bf16"][1]) / abs(runs["fp32"][1]) < 0.02
+    assert np.abs(runs["fp32"][2] - runs["bf16"][2]).max() < 0.08
+
+
+def test_bridge_backward_refuses_another_forwards_activations():
+    """Two grad-enabled forwards before a backward: the first loss's backward would read the second forward's workspace."""
+    m = _model(_tiny_over(), 11).to(DEV)
+    b1 = _to_dev(_rand_batch(2, 40, 16, 4, 11, [40, 40], [4, 4], seed=1))
+    b2 = _to_dev(_rand_batch(2, 40, 16, 4, 11, [40, 40], [4, 4], seed=2))
+    m.train()
+    l1 = m(**b1).loss
+    l2 = m(**b2).loss
+    with pytest.raises(RuntimeError, match="saved activations are gone"):
+        l1.backward()
+    l2.backward()                                                # the most recent forward's backward is fine
