@@ -187,6 +187,11 @@ int nbci_coupler_splice_fwd(const void* text, const void* spikes, void* out, int
 int nbci_coupler_splice_bwd(const void* d_out, void* d_text, void* d_spikes, int32_t dtype, const int64_t* split, int32_t B,
                             int32_t Lt, int32_t Ts, int32_t H, nbci_stream_t stream);
 
+/* out[n] += sum_m in[m][n] (f32 accumulate; `in` is (M, ld) in in_dtype): the bias gradient of a Linear whose output gradient
+ * does not come out of one of this library's GEMMs (the BCI projector's last Linear, models/bci.py:88-96, whose output gradient
+ * arrives from the LLM's autograd through the splice backward). */
+int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t N, float* out, nbci_stream_t stream);
+
 /* nn.LogSoftmax(-1) of the decoder (ndt1.py:499) + argmax path (main.py:69) */
 int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V,
                     nbci_stream_t stream);

@@ -89,6 +89,10 @@ int nbci_coupler_splice_bwd(const void* d_out, void* d_text, void* d_spikes, int
                             int32_t Ts, int32_t H, nbci_stream_t stream) {
     return nbci::splice_bwd_launch(d_out, d_text, d_spikes, dtype, split, B, Lt, Ts, H, (hipStream_t)stream);
 }
+int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t N, float* out, nbci_stream_t stream) {
+    if (!in || !out || M <= 0 || N <= 0 || ld < N) return nbci::fail(NBCI_EINVAL, "colsum: bad arguments");
+    return nbci::colsum_launch(in, in_dtype, ld, M, N, out, (hipStream_t)stream);
+}
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");

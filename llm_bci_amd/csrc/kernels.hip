@@ -1188,7 +1188,14 @@ __global__ __launch_bounds__(256) void splice_fwd_kernel(const T* __restrict__ t
     const int src = is_spike ? pos - d : (pos < d ? pos : pos - Ts);
     const T* s = is_spike ? spikes + ((long long)b * Ts + src) * H : (text ? text + ((long long)b * Lt + src) * H : nullptr);
     T* o = out + (long long)row * H;
-    for (int c = threadIdx.x; c < H; c += 256) o[c] = s ? s[c] : (T)0.0f;
+    constexpr int E = 16 / (int)sizeof(T);   // 16-byte copies when the rows allow it (H_llm = 4096: one row = 8 KB bf16)
+    if (H % E == 0 && ((uintptr_t)o % 16 == 0) && (!s || (uintptr_t)s % 16 == 0)) {
+        const uint4* s4 = (const uint4*)s;
+        uint4* o4 = (uint4*)o;
+        for (int c = threadIdx.x; c < H / E; c += 256) o4[c] = s ? s4[c] : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int c = threadIdx.x; c < H; c += 256) o[c] = s ? s[c] : (T)0.0f;
+    }
     if (threadIdx.x == 0) {
         if (mask_out) mask_out[row] = is_spike ? (svalid ? svalid[b * Ts + src] : 1) : (tmask ? tmask[b * Lt + src] : 1);
         if (targets_out) targets_out[row] = is_spike ? -100 : (targets ? targets[b * Lt + src] : -100);
@@ -1208,7 +1215,14 @@ __global__ __launch_bounds__(256) void splice_bwd_kernel(const T* __restrict__ d
     T* dst = is_spike ? dspikes + ((long long)b * Ts + src) * H : (dtext ? dtext + ((long long)b * Lt + src) * H : nullptr);
     if (!dst) return;
     const T* g = dout + (long long)row * H;
-    for (int c = threadIdx.x; c < H; c += 256) dst[c] = g[c];
+    constexpr int E = 16 / (int)sizeof(T);
+    if (H % E == 0 && ((uintptr_t)g % 16 == 0) && ((uintptr_t)dst % 16 == 0)) {
+        const uint4* g4 = (const uint4*)g;
+        uint4* d4 = (uint4*)dst;
+        for (int c = threadIdx.x; c < H / E; c += 256) d4[c] = g4[c];
+    } else {
+        for (int c = threadIdx.x; c < H; c += 256) dst[c] = g[c];
+    }
 }
 
 int splice_fwd_launch(const void* text, const void* spikes, void* out, int dtype, const int64_t* tmask, const int64_t* svalid,

@@ -91,6 +91,27 @@ class NativeTrainer:
         n = getattr(self.model, "last_n_examples", None)
         return loss_vec.numel() if n is None else n.sum().double()
 
+    def _backward_and_reduce(self, sync):
+        """Backward of the last forward into self.grads, segment by segment from the top of the flat layout down, handing every
+        finished range to the reducer so its all-reduce overlaps the rest of the backward (trainer.py:339 under DDP; skipped on
+        accumulation micro-steps as `no_sync` does, trainer.py:345). Models: NDT1 / iTransformer / PatchTST (segments = head,
+        layers, embedder) and BCI (trainable LLM tensors, projector, then the encoder's segments)."""
+        m = self.model
+        nseg = len(m._segments)
+        if self.reducer.world == 1 or not sync:   # nothing to overlap with: the whole backward is one call (one fold of the small-vector gradients)
+            m._run_backward(self.grads, nseg - 1, 0)
+            return
+        split = getattr(m, "_embed_split", None)
+        for seg in range(nseg - 1, 0 if split is not None else -1, -1):
+            m._run_backward(self.grads, seg, seg)
+            self.reducer.segment_done(self.grads, seg)
+        if split is not None:   # the embedder in two parts: its big stack-projection bucket is on the wire during part 2
+            b0, e0 = m._segments[0]
+            m._run_backward(self.grads, 0, 0, embed_part=1)
+            self.reducer.range_done(self.grads, split, e0)
+            m._run_backward(self.grads, 0, 0, embed_part=2)
+            self.reducer.range_done(self.grads, b0, split)
+
     def train_step(self, batch, seed=None):
         """One micro-batch: forward, backward (+ overlapped all-reduce), and — on the steps the
         reference synchronises on (trainer.py:335) — AdamW + scheduler + zero_grad."""
@@ -119,20 +140,7 @@ class NativeTrainer:
                 if err is not None:
                     self.stats[2] += self._per_ratio(err)
                     self.stats[3] += 1
-        nseg = len(m._segments)
-        if self.reducer.world == 1 or not sync:   # nothing to overlap with: the whole backward is one call (one fold of the small-vector gradients)
-            m._run_backward(self.grads, nseg - 1, 0)
-        else:
-            split = getattr(m, "_embed_split", None)
-            for seg in range(nseg - 1, 0 if split is not None else -1, -1):
-                m._run_backward(self.grads, seg, seg)
-                self.reducer.segment_done(self.grads, seg)
-            if split is not None:   # the embedder in two parts: its big stack-projection bucket is on the wire during part 2
-                b0, e0 = m._segments[0]
-                m._run_backward(self.grads, 0, 0, embed_part=1)
-                self.reducer.range_done(self.grads, split, e0)
-                m._run_backward(self.grads, 0, 0, embed_part=2)
-                self.reducer.range_done(self.grads, b0, split)
+        self._backward_and_reduce(sync)
         if sync:
             lr, beta1 = self.sched.at(self.opt_step)
             t = self.opt_step + 1
@@ -150,6 +158,8 @@ class NativeTrainer:
                 done += e - b
             if done != m._total:
                 raise RuntimeError("gradient buckets do not cover the flat parameter buffer")
+            if hasattr(m, "_after_optimizer_step"):   # BCI: f32 masters of the LLM's trainable tensors -> the tensors it computes with
+                m._after_optimizer_step()
             self.grads.zero_()
             self.opt_step += 1
         self.global_step += 1

@@ -330,20 +330,27 @@ def forward(cfg, p, batch, train=False, seed=0, dtype=np.float32, keep_cache=Tru
 
 
 # ----------------------------------------------------------------------------- backward
-def backward(c, grad_scale=1.0):
+def backward(c, grad_scale=1.0, d_enc_out=None):
     """d(sum-loss)/d(params), hand-derived; keys = state-dict names. grad_scale multiplies the
-    loss (trainer.py:339 divides by gradient_accumulation_steps)."""
+    loss (trainer.py:339 divides by gradient_accumulation_steps).
+    d_enc_out (B,T',H or factors size): start from a gradient of the ENCODER OUTPUT instead of the CTC head (the encoder as BCI's
+    feature extractor, models/bci.py:125); the decoder then gets no gradient."""
     cfg, P, B, T, Tp, f = c["cfg"], c["P"], c["B"], c["T"], c["Tp"], c["f"]
     D, S, st, H, L, nh = (cfg[k] for k in ("input_dim", "stack_size", "stack_stride", "hidden", "n_layers", "n_heads"))
     hd = H // nh
     scale = f(1.0 / math.sqrt(hd))
     g = {}
-    dlogits = c["dlogits"] * f(grad_scale)                          # (B,Tp,V)
     Fs = cfg.get("factors_size", 0)
-    dec_in = c["fo"] if Fs else c["xo"]
-    g["decoder.0.weight"] = dlogits.reshape(-1, dlogits.shape[-1]).T @ dec_in.reshape(-1, dec_in.shape[-1])
-    g["decoder.0.bias"] = dlogits.reshape(-1, dlogits.shape[-1]).sum(0)
-    dxo = dlogits @ P["decoder.0.weight"]
+    if d_enc_out is not None:
+        dxo = np.asarray(d_enc_out, f) * f(grad_scale)
+        g["decoder.0.weight"] = np.zeros_like(P["decoder.0.weight"])
+        g["decoder.0.bias"] = np.zeros_like(P["decoder.0.bias"])
+    else:
+        dlogits = c["dlogits"] * f(grad_scale)                          # (B,Tp,V)
+        dec_in = c["fo"] if Fs else c["xo"]
+        g["decoder.0.weight"] = dlogits.reshape(-1, dlogits.shape[-1]).T @ dec_in.reshape(-1, dec_in.shape[-1])
+        g["decoder.0.bias"] = dlogits.reshape(-1, dlogits.shape[-1]).sum(0)
+        dxo = dlogits @ P["decoder.0.weight"]
     if Fs:
         dfu = dxo * act_bwd(cfg["factors_act"], c["fu"])
         g["encoder.out_proj.proj.0.weight"] = dfu.reshape(-1, Fs).T @ c["xo"].reshape(-1, H)

@@ -327,8 +327,75 @@ def bci_case():
     print("g_bci", emb.shape, mask.tolist(), tg.tolist()[0])
 
 
+def bci_forward_case():
+    """BCI.forward (models/bci.py:173-219) end to end through the reference's own `llm=` constructor argument (bci.py:48-49) with
+    a 2-layer random Llama small enough to store whole: loss (shifted CE sum), n_examples, logits, and d loss / d parameters of
+    the projector, the encoder and the LLM; once with the LLM in fp32 (tight parity of the coupler) and once exactly as the
+    reference runs it (llm.to(float16), bci.py:71,190)."""
+    import types
+    peft = types.ModuleType("peft"); peft.LoraConfig = None; peft.get_peft_model = None
+    sys.modules["peft"] = peft
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from models.bci import BCI
+    enc = json.loads(json.dumps(tiny()["encoder"]))
+    enc.setdefault("smooth_and_noise", {})["noise"] = False
+    enc["embedder"]["dropout"] = 0.0; enc["transformer"]["dropout"] = 0.0
+    cfg = {"projector": {"stacking": 2, "inter_size": 48, "bias": True, "act": "relu"}, "ndt1": {"encoder": enc}}
+    llm_cfg = dict(vocab_size=128, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=4, max_position_embeddings=64)
+    torch.manual_seed(5)
+    llm = AutoModelForCausalLM.from_config(LlamaConfig(**llm_cfg))
+    m = BCI(cfg, llm_path=None, llm=llm, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    g = np.random.default_rng(6)
+    B, T, Lt = 3, 32, 7
+    lens = [32, 27, 18]
+    spikes = g.standard_normal((B, T, 16)).astype(np.float32)
+    smask = np.zeros((B, T), np.int64); ts = np.zeros((B, T), np.int64)
+    for b, L in enumerate(lens):
+        spikes[b, L:] = 0; smask[b, :L] = 1; ts[b, :L] = np.arange(L)
+    input_ids = g.integers(0, 128, (B, Lt)).astype(np.int64)
+    amask = np.ones((B, Lt), np.int64); amask[1, 5:] = 0
+    split = np.array([2, 3, 1], np.int64)
+    targets = g.integers(0, 128, (B, Lt)).astype(np.int64); targets[:, :3] = -100; targets[1, 5:] = -100
+    tt = lambda a: torch.from_numpy(a)
+    args = (tt(input_ids), tt(amask), tt(split), tt(spikes), tt(smask), tt(ts), tt(np.array(lens)), None, None, tt(targets))
+    fx = {"spikes": spikes, "spikes_mask": smask, "spikes_timestamp": ts, "spikes_lengths": np.array(lens), "input_ids": input_ids,
+          "attention_mask": amask, "input_split": split, "targets": targets, "config_json": np.array(json.dumps(cfg)),
+          "llm_config_json": np.array(json.dumps(llm_cfg))}
+    m.eval()
+    m.llm.float()
+    for k, v in m.ndt1.state_dict().items():
+        fx["w:ndt1." + k] = v.numpy().copy()
+    for k, v in m.projector.state_dict().items():
+        fx["w:projector." + k] = v.numpy().copy()
+    for k, v in m.llm.state_dict().items():
+        fx["w:llm." + k] = v.numpy().copy()
+    out = m(*args)
+    out.loss.backward()
+    fx.update(f32_loss=np.float64(out.loss.item()), n_examples=np.int64(out.n_examples.item()), f32_logits=out.preds.detach().numpy(),
+              out_targets=out.targets.numpy())
+    for k, p in m.projector.named_parameters():
+        fx["g32:projector." + k] = p.grad.numpy().copy()
+    for k, p in m.ndt1.named_parameters():
+        if p.grad is not None and any(s in k for s in ("out_norm", "layers.1.mlp.down_proj", "embed_spikes", "layers.0.attn.query", "stack_projection.bias")):
+            fx["g32:ndt1." + k] = p.grad.numpy().copy()
+    for k, p in m.llm.named_parameters():
+        if any(s in k for s in ("embed_tokens", "layers.1.self_attn.q_proj", "layers.0.mlp.down_proj", "lm_head", "norm.weight")):
+            fx["g32:llm." + k] = p.grad.numpy().copy()
+    m.zero_grad()
+    m.llm.to(torch.float16)          # the reference's own precision for the LLM (bci.py:71)
+    out16 = m(*args)
+    out16.loss.backward()
+    fx.update(f16_loss=np.float64(out16.loss.item()), f16_logits=out16.preds.detach().float().numpy())
+    for k, p in m.projector.named_parameters():
+        fx["g16:projector." + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g_bci_fwd.npz"), **fx)
+    print("g_bci_fwd", out.loss.item(), out16.loss.item(), int(out.n_examples), tuple(out.preds.shape))
+
+
 if __name__ == "__main__" and "--bci" in sys.argv:
     bci_case()
+    bci_forward_case()
 
 
 # ------------------------------------------------------------------------------------------------

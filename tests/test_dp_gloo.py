@@ -114,3 +114,60 @@ def test_segments_cover_flat_buffer_contiguously():
     assert q[0] + q[1] == k_[0] and k_[0] + k_[1] == v[0]
     qb, kb, vb = (lay[f"encoder.layers.0.attn.{n}.bias"] for n in ("query", "key", "value"))
     assert qb[0] + qb[1] == kb[0] and kb[0] + kb[1] == vb[0]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BCI (BASELINE configs[3]): encoder + coupler + LoRA gradients through the SAME reduce schedule NativeTrainer runs on the GPU
+# ------------------------------------------------------------------------------------------------------------------------
+def _bci_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from llm_bci_amd.bci import BCI
+    from llm_bci_amd.trainer import NativeTrainer
+    torch.manual_seed(1)
+    llm = AutoModelForCausalLM.from_config(LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                                                       num_attention_heads=4, num_key_value_heads=4))
+    llm = BCI._add_lora(llm, dict(r=4, alpha=8, dropout=0.0, target_modules=["q_proj", "v_proj"], modules_to_save=[]))
+    m = BCI({"projector": {"stacking": 1, "inter_size": 48}, "ndt1": OVER}, llm=llm, compute_dtype="fp32")
+    calls = []
+    segs = m._segments
+
+    def fake_backward(grads, seg_hi, seg_lo, embed_part=0):
+        """stands in for the HIP/LLM backward (no GPU here): writes rank- and position-dependent values into exactly the range the
+        real call would finish, and records the call order."""
+        calls.append((seg_hi, seg_lo, embed_part))
+        for seg in range(seg_hi, seg_lo - 1, -1):
+            b, e = segs[seg]
+            if seg == 0 and embed_part == 1:
+                b = m._embed_split
+            elif seg == 0 and embed_part == 2:
+                e = m._embed_split
+            grads[b:e] += (rank + 1) * torch.arange(b, e, dtype=torch.float32) * 1e-3
+
+    m._run_backward = fake_backward
+    tr = NativeTrainer(m, total_steps=4, compute_per=False)
+    tr.reducer.min_bucket = 2048               # small buckets: several all-reduces in flight
+    tr._backward_and_reduce(sync=True)
+    covered = torch.zeros(m._total, dtype=torch.int32)
+    for b, e in tr.reducer.drain(tr.grads):
+        covered[b:e] += 1
+    n = len(segs)
+    assert calls == [(s, s, 0) for s in range(n - 1, 0, -1)] + [(0, 0, 1), (0, 0, 2)], calls   # LLM adapters, projector, head..layer 0, embedder in 2 parts
+    assert bool((covered == 1).all())                                                           # every element reduced exactly once
+    want = sum(r + 1 for r in range(world)) * torch.arange(m._total, dtype=torch.float32) * 1e-3
+    assert torch.allclose(tr.grads, want, rtol=1e-6)
+    # an accumulation micro-step (no_sync, trainer.py:345): one backward call, nothing on the wire
+    calls.clear()
+    tr.grads.zero_()
+    tr._backward_and_reduce(sync=False)
+    assert calls == [(n - 1, 0, 0)] and not tr.reducer._works
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write(str(m._total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bci_two_rank_reduce_schedule_covers_encoder_coupler_and_adapters(tmp_path):
+    mp.spawn(_bci_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok"))

@@ -192,3 +192,61 @@ def test_bridge_shadow_and_forward_stamp_logic():
     bridge_stamp(m)
     with pytest.raises(RuntimeError):
         bridge_check(m, a, "t")
+
+
+def test_lora_fallback_is_lora_by_its_published_definition():
+    """llm_bci_amd/lora.py stands in for peft (absent from the image; models/bci.py:10,56-62): y = base(x) + (alpha/r) B A x,
+    B = 0 at init (the wrapped model starts out identical), only adapter tensors trainable, peft's parameter names."""
+    import torch
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from llm_bci_amd.lora import LoRALinear, inject_lora
+    torch.manual_seed(0)
+    base = torch.nn.Linear(12, 7)
+    l = LoRALinear(base, r=3, alpha=6, dropout=0.0)
+    x = torch.randn(5, 12)
+    assert torch.equal(l(x), base(x))                                  # B = 0
+    l.lora_B["default"].weight.data.normal_()
+    A, B = l.lora_A["default"].weight, l.lora_B["default"].weight
+    assert torch.allclose(l(x), base(x) + 2.0 * (x @ A.T @ B.T), atol=1e-6)
+    llm = AutoModelForCausalLM.from_config(LlamaConfig(vocab_size=64, hidden_size=16, intermediate_size=32, num_hidden_layers=2,
+                                                       num_attention_heads=2, num_key_value_heads=2))
+    n_base = sum(p.numel() for p in llm.parameters())
+    inject_lora(llm, 4, 8, 0.1, ["q_proj", "v_proj"])
+    tr = {n for n, p in llm.named_parameters() if p.requires_grad}
+    assert len(tr) == 2 * 2 * 2 and all(n.endswith(("lora_A.default.weight", "lora_B.default.weight")) for n in tr)
+    assert sum(p.numel() for n, p in llm.named_parameters() if not p.requires_grad) == n_base
+    with pytest.raises(ValueError):
+        inject_lora(llm, 4, 8, 0.0, ["no_such_module"])
+
+
+def test_bci_joint_flat_layout_on_cpu():
+    """BCI's native layout [ndt1 | projector | trainable LLM tensors]: contiguous 8-aligned segments, ndt1 / projector parameters
+    re-homed as views, adapter masters copied in and written back in the adapters' dtype."""
+    import torch
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from llm_bci_amd.bci import BCI
+    over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                        "transformer": {"n_layers": 2, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}}
+    llm = AutoModelForCausalLM.from_config(LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                                                       num_attention_heads=4, num_key_value_heads=4))
+    llm = BCI._add_lora(llm, dict(r=4, alpha=8, dropout=0.0, target_modules=["q_proj", "v_proj"], modules_to_save=[]))
+    m = BCI({"projector": {"stacking": 2, "inter_size": 48}, "ndt1": over}, llm=llm, compute_dtype="bf16")
+    keys0 = set(m.state_dict())
+    w_before = m.projector.state_dict()["0.weight"].clone()
+    segs = m._segments
+    assert segs[0][0] == 0 and segs[-1][1] == m._total and all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))
+    assert len(segs) == len(m.ndt1._segments) + 2 and segs[:len(m.ndt1._segments)] == m.ndt1._segments
+    for (name, off, numel, shape, seg) in m._layout:
+        assert off % 8 == 0 and segs[seg][0] <= off and off + numel <= segs[seg][1], name
+    assert set(m.state_dict()) == keys0 and torch.equal(m.projector.state_dict()["0.weight"], w_before)
+    lo, hi = m._flat.data_ptr(), m._flat.data_ptr() + 4 * m._total
+    for p in list(m.ndt1.parameters()) + list(m.projector.parameters()):
+        assert lo <= p.data_ptr() < hi
+    ee = m._native["eentries"]
+    assert len(ee) == 8 and all(p.dtype == torch.float16 for _n, p, _o in ee)   # llm.to(float16) (bci.py:71) took the adapters along
+    n, p, off = ee[0]
+    assert torch.equal(m._flat[off:off + p.numel()].view(p.shape), p.detach().float())
+    m._flat[off:off + p.numel()] += 0.25
+    m._after_optimizer_step()
+    assert torch.equal(p.detach(), m._flat[off:off + p.numel()].view(p.shape).to(torch.float16))
+    assert m._flat_lp.dtype == torch.bfloat16 and m.ndt1._flat_lp.data_ptr() == m._flat_lp.data_ptr()
