@@ -150,7 +150,8 @@ def main():
     over = {"encoder": {"embedder": {"n_channels": args.channels}}}
     model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    total_steps = args.steps * args.repeats + args.warmup + 64   # OneCycle horizon covers warm-up + timed windows + profiling / extra points
+    # OneCycle horizon: warm-up + timed windows + the 3 profiling steps + the two extra points (2 warm-up + 3 windows each)
+    total_steps = args.warmup + args.steps * max(1, args.repeats) + 3 + 2 * (2 + 3 * args.steps) + 16
     tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=total_steps, warmup_pct=0.0,
                        div_factor=25)
     _, batch = make_batch(args.batch, args.bins, args.channels, args.target_len, 41, dev, seed=rank)

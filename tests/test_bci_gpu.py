@@ -212,16 +212,16 @@ def test_native_trainer_trains_bci_with_lora(dtype):
     a0 = {n: p.detach().clone() for n, p in m.llm.named_parameters() if "lora_" in n}
     base0 = m.llm.model.layers[0].self_attn.q_proj.base_layer.weight.detach().clone()
     w0 = dict(m.projector.named_parameters())["2.weight"].detach().clone()
-    tr = NativeTrainer(m, lr=2e-3, wd=0.0, total_steps=40, compute_per=False)
+    tr = NativeTrainer(m, lr=5e-3, wd=0.0, total_steps=80, compute_per=False)
     batch = _batch_dict(fx)
     losses = []
-    for s in range(12):
+    for s in range(30):
         loss, _ = tr.train_step(batch, seed=s)
         losses.append(float(loss.sum()))
     torch.cuda.synchronize()
     st = tr.read_stats()
-    assert st["n_examples"] == 12 * int(fx["n_examples"])
-    assert np.all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+    assert st["n_examples"] == 30 * int(fx["n_examples"])
+    assert np.all(np.isfinite(losses)) and losses[-1] < 0.93 * losses[0] and losses[-1] < losses[10] < losses[0], losses
     moved = [n for n, p in m.llm.named_parameters() if "lora_" in n and not torch.equal(p, a0[n])]
     assert len(moved) == len(a0)                                            # every adapter tensor was stepped ...
     assert torch.equal(m.llm.model.layers[0].self_attn.q_proj.base_layer.weight, base0)   # ... the frozen base was not
