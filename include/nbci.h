@@ -231,6 +231,10 @@ int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_str
  * (bf16 ? 4 : 0) + (A.kmajor ? 2 : 0) + (B.kmajor ? 1 : 0). Host-synchronising; never call it in
  * a timed region. */
 int nbci_profile_enable(int32_t on);
+/* Measurement / test aid: which bf16 GEMM kernel family nbci_gemm picks for eligible shapes (k-major A, K % 64 == 0, N >= 256):
+ * 0 = the two-workgroup-per-CU kernels only, 1 = the producer / consumer kernel (144 x 256 tiles, gemm_pc.hip) where the tile
+ * cost model prefers it (default), 2 = the producer / consumer kernel whenever eligible. Initial value: NBCI_GEMM_PC. */
+int nbci_debug_gemm_pc(int32_t mode);
 int nbci_profile_collect(double* out24);
 
 /* ------------------------------------------------------------------------------------

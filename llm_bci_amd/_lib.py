@@ -182,6 +182,7 @@ _SIGNATURES = {
     "nbci_coupler_splice_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "nbci_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nbci_profile_enable": (C.c_int, [C.c_int32]),
+    "nbci_debug_gemm_pc": (C.c_int, [C.c_int32]),
     "nbci_profile_collect": (C.c_int, [C.POINTER(C.c_double)]),
     "nbci_step_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "nbci_per": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

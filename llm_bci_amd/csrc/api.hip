@@ -93,6 +93,7 @@ int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t
     if (!in || !out || M <= 0 || N <= 0 || ld < N) return nbci::fail(NBCI_EINVAL, "colsum: bad arguments");
     return nbci::colsum_launch(in, in_dtype, ld, M, N, out, (hipStream_t)stream);
 }
+int nbci_debug_gemm_pc(int32_t mode) { nbci::gemm_pc_set_mode(mode); return NBCI_OK; }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");

@@ -496,45 +496,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[MI][N
 // rows: lane owns n = 4 * (t & 31) .. + 3 of row t / 32 (+ nthreads / 32 per pass): 512 B (f32) / 256 B (bf16)
 // contiguous per row for C, C2, the residual and the gate. The per-element work is epi_apply(), unchanged.
 constexpr int EPI_LD = 132;   // floats per LDS row: 16 B of padding spreads the 16 rows of a fragment over all banks
-// CH > 1: the tile goes through LDS in CH row chunks (tall tiles whose f32 image would not leave room for two
-// workgroups per CU); needs every wave to span all rows (mw_l = 0) and MI % CH == 0.
-template <int MI, int NI, int CH = 1>
-__device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[MI][NI], int mw_l, int nw_l, int m0, int n0, int bm,
-                                                   long long coff, int t, int nthreads, char* smem) {
-    static_assert(MI % CH == 0, "row chunks must split the wave's row blocks evenly");
-    constexpr int MC = MI / CH;
-    const int lane = t & 63, i16 = lane & 15, g = lane >> 4;
-    float* tile = (float*)smem;
-    if (d.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
-        float s = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) s += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
-        if (s == 1.2345e-30f) ((float*)d.C)[0] = s;
-        return;
-    }
+// The row loop over an f32 LDS tile [rows][EPI_LD] of 128 columns: thread t owns columns 4 * (t & 31) .. + 3 of rows t / 32
+// (+ nthreads / 32 per pass); m_first = global row of the tile's row 0, n0 = global column of its column 0.
+__device__ __forceinline__ void epi_tile_rows(const GemmK& d, const float* tile, int rows, int m_first, int n0, long long coff, int t,
+                                              int nthreads, float (&csum)[4]) {
     const int c4 = 4 * (t & 31), n = n0 + c4;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    const int rows = bm / CH;
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-        __syncthreads();   // every wave has left the K loop (the previous chunk): the LDS tile is free
-#pragma unroll
-        for (int mi = 0; mi < MC; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                *(float4*)(tile + (mw_l + mi * 16 + i16) * EPI_LD + nw_l + ni * 16 + 4 * g) =
-                    make_float4(acc[ch * MC + mi][ni][0] * d.alpha, acc[ch * MC + mi][ni][1] * d.alpha, acc[ch * MC + mi][ni][2] * d.alpha,
-                                acc[ch * MC + mi][ni][3] * d.alpha);
-        __syncthreads();
-        if (ch == 0) STAMP(6);
-        if (n < d.N) {
-            const int rstep = nthreads >> 5;
-            if ((n + 3 < d.N) && d.cvec) {   // (the thread's columns are fixed: one decision for all its rows)
+    if (n < d.N) {
+        const int rstep = nthreads >> 5;
+        if ((n + 3 < d.N) && d.cvec) {   // (the thread's columns are fixed: one decision for all its rows)
 #define NBCI_EPI_ROWS(MODE_)                                                         \
     for (int r = t >> 5; r < rows; r += rstep) {                                     \
-        const int m = m0 + ch * rows + r;                                            \
+        const int m = m_first + r;                                                   \
         if (m >= d.M) break;                                                         \
         const float4 a = *(const float4*)(tile + r * EPI_LD + c4);                   \
         float v[4] = {a.x, a.y, a.z, a.w};                                           \
@@ -570,16 +542,52 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[
                 }
 #undef NBCI_EPI_CASE
 #undef NBCI_EPI_ROWS
-            } else {
-                for (int r = t >> 5; r < rows; r += rstep) {
-                    const int m = m0 + ch * rows + r;
-                    if (m >= d.M) break;
-                    const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
-                    float v[4] = {a.x, a.y, a.z, a.w};
-                    epi_apply_t<false>(d, v, m, n, coff, csum);
-                }
+        } else {
+            for (int r = t >> 5; r < rows; r += rstep) {
+                const int m = m_first + r;
+                if (m >= d.M) break;
+                const float4 a = *(const float4*)(tile + r * EPI_LD + c4);
+                float v[4] = {a.x, a.y, a.z, a.w};
+                epi_apply_t<false>(d, v, m, n, coff, csum);
             }
         }
+    }
+}
+
+// CH > 1: the tile goes through LDS in CH row chunks (tall tiles whose f32 image would not leave room for two
+// workgroups per CU); needs every wave to span all rows (mw_l = 0) and MI % CH == 0.
+template <int MI, int NI, int CH = 1>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[MI][NI], int mw_l, int nw_l, int m0, int n0, int bm,
+                                                   long long coff, int t, int nthreads, char* smem) {
+    static_assert(MI % CH == 0, "row chunks must split the wave's row blocks evenly");
+    constexpr int MC = MI / CH;
+    const int lane = t & 63, i16 = lane & 15, g = lane >> 4;
+    float* tile = (float*)smem;
+    if (d.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
+        float s = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) s += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (s == 1.2345e-30f) ((float*)d.C)[0] = s;
+        return;
+    }
+    const int c4 = 4 * (t & 31), n = n0 + c4;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int rows = bm / CH;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        __syncthreads();   // every wave has left the K loop (the previous chunk): the LDS tile is free
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                *(float4*)(tile + (mw_l + mi * 16 + i16) * EPI_LD + nw_l + ni * 16 + 4 * g) =
+                    make_float4(acc[ch * MC + mi][ni][0] * d.alpha, acc[ch * MC + mi][ni][1] * d.alpha, acc[ch * MC + mi][ni][2] * d.alpha,
+                                acc[ch * MC + mi][ni][3] * d.alpha);
+        __syncthreads();
+        if (ch == 0) STAMP(6);
+        epi_tile_rows(d, tile, rows, m0 + ch * rows, n0, coff, t, nthreads, csum);
     }
     if (d.colsum) {   // bias gradient: the two half-waves hold the same columns; one atomic per column per wave
         const int cbase = (int)(coff % d.ldc);

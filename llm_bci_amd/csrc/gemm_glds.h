@@ -93,6 +93,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform; s_wa
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
         case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;

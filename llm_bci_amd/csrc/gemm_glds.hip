@@ -378,9 +378,21 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
     return NBCI_OK;
 }
 
+bool gemm_pc_eligible(const nbci_gemm_desc& d, const GemmK& k);
+int gemm_pc_mode();
+long gemm_pc_tiles(const nbci_gemm_desc& d);
+int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
+
 int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int batch = d.batch > 0 ? d.batch : 1;
     const int splitk = k.splitk;
+    // producer / consumer kernel (gemm_pc.hip): 144 x 256 tiles, one workgroup per CU. NBCI_GEMM_PC: 0 = off, 1 = when the grid
+    // fills at least 3/4 of a round of 256 workgroups, 2 = whenever eligible (measurement)
+    const int pc_mode = gemm_pc_mode();
+    if (pc_mode && gemm_pc_eligible(d, k)) {
+        const long tiles = gemm_pc_tiles(d);
+        if (pc_mode == 2 || tiles >= 192) return gemm_pc_launch(d, k, stream);
+    }
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.
     int bm = 128;

@@ -11,6 +11,7 @@ int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream);  // = gemm_l
 int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream);        // <= 6 problems, one launch
 int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream);
 void gemm_profile_enable(bool on);
+void gemm_pc_set_mode(int m);   // gemm_pc.hip: kernel-family switch (nbci_debug_gemm_pc)
 bool gemm_profile_on();
 int gemm_profile_collect(double* out24);
 
