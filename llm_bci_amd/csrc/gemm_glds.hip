@@ -386,12 +386,16 @@ int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
 int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int batch = d.batch > 0 ? d.batch : 1;
     const int splitk = k.splitk;
-    // producer / consumer kernel (gemm_pc.hip): 144 x 256 tiles, one workgroup per CU. NBCI_GEMM_PC: 0 = off, 1 = when the grid
-    // fills at least 3/4 of a round of 256 workgroups, 2 = whenever eligible (measurement)
+    // producer / consumer kernel (gemm_pc.hip): 144 x 256 tiles, ONE workgroup per CU. In-box A/B on the step's shapes
+    // (tools/time_gemm_pc.py, profiles/r02_gemm_pc_ab.txt): 3 - 7 % faster than the two-workgroup kernels from K = 3072 up (fewer
+    // staged and fragment bytes per FLOP), equal at K = 1024 with one round of tiles, 4 % slower at K = 1024 with 3 - 4 rounds (a
+    // single resident workgroup overlaps nothing with its fill and epilogue). Mode 1 (default) therefore takes it for K >= 2048
+    // when the last round of 256 workgroups is at least 3/4 full; mode 2 = whenever eligible (tests, measurement); 0 = never.
     const int pc_mode = gemm_pc_mode();
     if (pc_mode && gemm_pc_eligible(d, k)) {
         const long tiles = gemm_pc_tiles(d);
-        if (pc_mode == 2 || tiles >= 192) return gemm_pc_launch(d, k, stream);
+        const long last = tiles % 256;
+        if (pc_mode == 2 || (d.K >= 2048 && tiles >= 192 && (last == 0 || last >= 192))) return gemm_pc_launch(d, k, stream);
     }
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.

@@ -17,10 +17,15 @@
 // no split-K, no window views (those stay on gemm_glds.hip). LDS images and swizzles are the ones of gemm_glds.h; the 256-column
 // B tile is two 128-column images side by side.
 //
-// Synchronisation protocol (tile k lives in stage k % 3; B_k = the k-th workgroup barrier):
-//   producers : issue(0), issue(1); vmcnt -> tile 0 landed; B_0; for k = 1 .. nt-1 { vmcnt(0): tile k landed; B_k; issue(k+1) }
-//   consumers : B_0; read step (0,0); for i = 0 .. nt-1 { step (i,0) prefetching (i,1); B_{i+1}; step (i,1) prefetching (i+1,0) }
-// issue(k+1) goes to stage (k-2) % 3, whose last fragment reads were consumed by MFMAs issued before the consumers reached B_k.
+// Synchronisation protocol (tile k lives in stage k % 3; B_k = the k-th workgroup barrier; FREE_c = an LDS word per consumer wave):
+//   producers : issue(0), issue(1); for k = 0 .. nt-1 { vmcnt(pieces of tile k+1): tile k landed; B_k; poll FREE >= k; issue(k+2) }
+//   consumers : B_0; read step (0,0); for i = 0 .. nt-1 { step (i,0) prefetching (i,1); FREE_c = i + 1; B_{i+1};
+//                                                          step (i,1) prefetching (i+1,0) }
+// TWO tiles are in flight (k+1 landing while k+2 is issued): with one, a K tile cost issue (740 cycles: 50 KB through the CU's
+// 64 B/clk L2 -> LDS path) + landing (880) + barrier = 1 770 cycles against 1 152 cycles of MFMA work (in-kernel stamps,
+// profiles/r02_gemm_pc_stamps_*.txt). issue(k+2) overwrites stage (k-1) % 3: at B_k every consumer has ISSUED its last read of
+// tile k-1 (they are the re-reads of step (k-1,0)) and then written FREE_c = k through the same in-order LDS queue, so a producer
+// that has read FREE_c >= k from LDS knows those reads have executed; the DMA it issues afterwards cannot overtake them.
 // Every wave executes exactly nt barriers in the loop (B_0 .. B_{nt-1}).
 #include <cstdlib>
 
@@ -30,17 +35,30 @@ namespace nbci {
 
 constexpr int PC_BM = 144, PC_BN = 256, PC_MI = 9, PC_NI = 4;
 constexpr int PC_A_BYTES = PC_BM * 128, PC_B_BYTES = 32768, PC_STAGE = PC_A_BYTES + PC_B_BYTES, PC_NS = 3;
-constexpr int PC_LDS = PC_NS * PC_STAGE;   // 153,600 B (the epilogue's two f32 images [144][132] x 2 = 152,064 B fit inside)
+constexpr int PC_FLAGS = PC_NS * PC_STAGE;   // FREE words: 4 consumers x 256 B (every lane writes its own word: no write conflict)
+constexpr int PC_LDS = PC_FLAGS + 1024;      // 154,624 B (the epilogue's two f32 images [144][132] x 2 = 152,064 B fit below the flags)
 constexpr int PC_THREADS = 512;
 
+#ifdef NBCI_STAMPS   // measurement build only (tools/gemm_pc_stamps.py): producer wave 4 of every workgroup, shader cycles per K tile:
+                     // [0] past B_k, [1] tile k+1 issued, [2] tile k+1 landed (vmcnt(0)); wall clock (100 MHz): entry, B_0, loop end, stores issued
+static __device__ unsigned long long g_pc_tile[1024 * 64 * 4];
+static __device__ unsigned long long g_pc_wall[1024 * 8];
+#define PC_TSTAMP(k, slot) do { if (pstamp && (k) < 64) g_pc_tile[((size_t)blockIdx.x * 64 + (k)) * 4 + (slot)] = clock64(); } while (0)
+#define PC_WSTAMP(slot) do { if (threadIdx.x == 256 && blockIdx.y == 0 && blockIdx.x < 1024) g_pc_wall[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PC_TSTAMP(k, slot) do { } while (0)
+#define PC_WSTAMP(slot) do { } while (0)
+#endif
+
 // rows R .. 8 of one k-step (compile-time recursion: the re-read's row offset is an instruction immediate)
-template <bool BKM, int R>
+template <bool BKM, int EXTRA, int R>
 __device__ __forceinline__ void pc_rows(f32x4 (&acc)[PC_MI][PC_NI], bf16x8 (&af)[PC_MI], const bf16x8 (&bc)[PC_NI], unsigned a_next) {
     if constexpr (R < PC_MI) {
-        // Outstanding reads when row R waits: A'(R+1..8) of the current set (8 - R), the 4 (k-major) or 8 (transposed) reads of
-        // the next B set, and the R re-reads issued in this step: 12 resp. 16 (the counter saturates at 15: one read early).
-        if constexpr (BKM) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        // Outstanding LDS operations when row R waits: A'(R+1..8) of the current set (8 - R), EXTRA (the FREE word written
+        // between the two steps of a tile), the 4 (k-major) or 8 (transposed) reads of the next B set, and the R re-reads issued
+        // in this step: 12 + EXTRA resp. 16 + EXTRA (the counter saturates at 15: the wait is then a read or two early).
+        constexpr int N = (BKM ? 12 : 16) + EXTRA;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
         __builtin_amdgcn_sched_barrier(0);   // MFMAs do not touch memory: without the fence hipcc may hoist them above the wait
 #pragma unroll
         for (int ni = 0; ni < PC_NI; ++ni)
@@ -48,18 +66,18 @@ __device__ __forceinline__ void pc_rows(f32x4 (&acc)[PC_MI][PC_NI], bf16x8 (&af)
         __builtin_amdgcn_sched_barrier(0);
         af[R] = ds_read_b128_asm<2048 * R>(a_next);   // the same row block for the NEXT k-step (the MFMAs above read af[R] at issue)
         __builtin_amdgcn_sched_barrier(0);
-        pc_rows<BKM, R + 1>(acc, af, bc, a_next);
+        pc_rows<BKM, EXTRA, R + 1>(acc, af, bc, a_next);
     }
 }
 
 // one k-step of a consumer wave: 36 MFMAs on (bc, af) while the fragments of the NEXT k-step are read into (bn, af)
-template <bool BKM, int KS_NEXT>
+template <bool BKM, int KS_NEXT, int EXTRA>
 __device__ __forceinline__ void pc_step(f32x4 (&acc)[PC_MI][PC_NI], bf16x8 (&af)[PC_MI], const bf16x8 (&bc)[PC_NI], bf16x8 (&bn)[PC_NI],
                                         unsigned a_next, unsigned b_next, const unsigned (&tb_next)[PC_NI]) {
     if constexpr (BKM) km_read_frags<PC_NI>(bn, b_next);
     else tr_read_frags<KS_NEXT, PC_NI>(bn, tb_next);
     __builtin_amdgcn_sched_barrier(0);
-    pc_rows<BKM, 0>(acc, af, bc, a_next);
+    pc_rows<BKM, EXTRA, 0>(acc, af, bc, a_next);
 }
 
 template <bool BKM>
@@ -91,9 +109,13 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
     const long long coff = z1 * d.czs1 + z2 * d.czs2;
     const int nt = d.K / 64;
 
+    PC_WSTAMP(0);
     if (w >= 4) {
         // ------------------------------------------------------------------------------------------------ producers
         const int pw = w - 4;
+#ifdef NBCI_STAMPS
+        const bool pstamp = threadIdx.x == 256 && blockIdx.y == 0 && blockIdx.x < 1024;
+#endif
         OperandK A = d.A, B = d.B;
         A.ptr = (const bf16_t*)A.ptr + z1 * d.azs1 + z2 * d.azs2;
         B.ptr = (const bf16_t*)B.ptr + z1 * d.bzs1 + z2 * d.bzs2;
@@ -109,20 +131,32 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
             glds_stage<BKM, 16, 4>(gb0, B, s + PC_A_BYTES, k, pw);
             glds_stage<BKM, 16, 4>(gb1, B, s + PC_A_BYTES + 16384, k, pw);
         };
+        const unsigned flag_addr = lds_addr(smem + PC_FLAGS) + (lane & 3) * 256;   // lane l polls consumer l & 3
         issue(0, 0);
         if (nt > 1) issue(1, 1);
-        wait_vmcnt(nt > 1 ? lw : 0);
-        __builtin_amdgcn_s_barrier();   // B_0
-        asm volatile("" ::: "memory");
         int stage = 2;
-        for (int k = 1; k < nt; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile k (the only one in flight) has landed
-            __builtin_amdgcn_s_barrier();                      // B_k: tile k visible; stage (k+1) % 3 is no longer read
+        for (int k = 0; k < nt; ++k) {
+            wait_vmcnt(k + 1 < nt ? lw : 0);                   // tile k has landed (tile k + 1 may still be in flight)
+            PC_TSTAMP(k, 2);
+            __builtin_amdgcn_s_barrier();                      // B_k: tile k visible to the consumers
             asm volatile("" ::: "memory");
-            if (k + 1 < nt) issue(k + 1, stage);
+            if (k == 0) PC_WSTAMP(1);
+            PC_TSTAMP(k, 0);
+            if (k + 2 < nt) {
+                // stage (k + 2) % 3 held tile k - 1: every consumer must have issued its last read of it (FREE_c >= k)
+                for (;;) {
+                    unsigned f;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag_addr) : "memory");
+                    if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64((int)f >= k) == ~0ull)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                issue(k + 2, stage);
+            }
+            PC_TSTAMP(k, 1);
             stage = stage == 2 ? 0 : stage + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PC_WSTAMP(2);
     } else {
         // ------------------------------------------------------------------------------------------------ consumers
         f32x4 acc[PC_MI][PC_NI];
@@ -141,6 +175,9 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
             for (int ni = 0; ni < PC_NI; ++ni) tb[ni] = tr_frag_base(sB, cb + ni * 16, i16, g);
         }
         bf16x8 af[PC_MI], bf0[PC_NI], bf1[PC_NI];
+        const unsigned flag_addr = lds_addr(smem + PC_FLAGS) + w * 256 + lane * 4;
+        // FREE_c = 0 before anybody polls it (LDS keeps the previous workgroup's bytes); completed before B_0 orders it for the producers
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(flag_addr), "v"(0) : "memory");
         __builtin_amdgcn_s_barrier();   // B_0: tile 0 is in stage 0
         asm volatile("" ::: "memory");
         // fragments of step (0, 0)
@@ -154,8 +191,11 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
                 unsigned tbn[PC_NI];
 #pragma unroll
                 for (int ni = 0; ni < PC_NI; ++ni) tbn[ni] = tb[ni] + so;
-                pc_step<BKM, 1>(acc, af, bf0, bf1, (a_base + so) ^ 64u, (b_base + so) ^ 64u, tbn);
+                pc_step<BKM, 1, 0>(acc, af, bf0, bf1, (a_base + so) ^ 64u, (b_base + so) ^ 64u, tbn);
             }
+            // every read of tile i's stage has been issued: FREE_c = i + 1 through the same in-order LDS queue
+            asm volatile("ds_write_b32 %0, %1" ::"v"(flag_addr), "v"(i + 1) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < nt) {
                 __builtin_amdgcn_s_barrier();   // B_{i+1}: tile i + 1 has landed in the next stage
                 asm volatile("" ::: "memory");
@@ -166,7 +206,7 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
                 unsigned tbn[PC_NI];
 #pragma unroll
                 for (int ni = 0; ni < PC_NI; ++ni) tbn[ni] = tb[ni] + so;
-                pc_step<BKM, 0>(acc, af, bf1, bf0, a_base + so, b_base + so, tbn);
+                pc_step<BKM, 0, 1>(acc, af, bf1, bf0, a_base + so, b_base + so, tbn);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the over-read of the last step has returned before LDS is reused
@@ -186,6 +226,7 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
         asm volatile("" ::: "memory");
     }
     __syncthreads();   // the two f32 images are complete
+    PC_WSTAMP(3);
     // row-contiguous epilogue by all 8 waves: image h = columns n0 + 128 h .. + 127
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
@@ -203,6 +244,7 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
             }
         }
     }
+    PC_WSTAMP(4);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
@@ -212,7 +254,7 @@ bool glds_view(const nbci_gemm_desc& d);
 // Initialised from NBCI_GEMM_PC; nbci_debug_gemm_pc() changes it at run time.
 static int g_pc_mode = -1;
 int gemm_pc_mode() {
-    if (g_pc_mode < 0) { const char* e = getenv("NBCI_GEMM_PC"); g_pc_mode = e ? atoi(e) : 0; }
+    if (g_pc_mode < 0) { const char* e = getenv("NBCI_GEMM_PC"); g_pc_mode = e ? atoi(e) : 1; }
     return g_pc_mode;
 }
 void gemm_pc_set_mode(int m) { g_pc_mode = m; }
@@ -248,3 +290,10 @@ int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
 }
 
 }  // namespace nbci
+
+#ifdef NBCI_STAMPS
+extern "C" int nbci_debug_read_pc_stamps(unsigned long long* tile, unsigned long long* wall, int nblocks) {
+    if (hipMemcpyFromSymbol(tile, HIP_SYMBOL(nbci::g_pc_tile), (size_t)nblocks * 64 * 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(wall, HIP_SYMBOL(nbci::g_pc_wall), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif

@@ -12,6 +12,9 @@ from llm_bci_amd._lib import lib  # noqa: E402
 
 dev = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 9152
+ZERO = os.environ.get("ZERO") == "1"   # zero-filled operands: the same instruction stream at the clock the chip holds without data toggling
+if ZERO:
+    torch.randn = lambda *a, **k: torch.zeros(*a, **k)
 l = lib()
 
 
