@@ -217,10 +217,20 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     return NBCI_OK;
 }
 
+// NBCI_GEMM_LOG=<file>: one line per GEMM kernel launch, in launch order ("M N K batch kind nproblems"; kind as in
+// nbci_profile_collect; grouped launches list every problem: "G n M N K M N K ..."). Measurement aid: tools/roofline_report.py joins
+// it with a rocprofv3 kernel trace of the same run (launch i of the trace = line i), so every launch's algorithmic FLOPs are known.
+static FILE* gemm_log_file() {
+    static FILE* f = [] { const char* e = getenv("NBCI_GEMM_LOG"); return (e && e[0]) ? fopen(e, "w") : (FILE*)nullptr; }();
+    return f;
+}
+static int kind_of(const nbci_gemm_desc& d) { return (d.in_dtype == NBCI_BF16 ? 4 : 0) + (d.A.kmajor ? 2 : 0) + (d.B.kmajor ? 1 : 0); }
+
 int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     GemmK k;
     int rc = build_gemmk(d, k);
     if (rc != NBCI_OK) return rc;
+    if (FILE* f = gemm_log_file()) { fprintf(f, "S %d %d %d %d %d\n", d.M, d.N, d.K, d.batch > 0 ? d.batch : 1, kind_of(d)); fflush(f); }
     const int batch = d.batch > 0 ? d.batch : 1;
     const int splitk = d.splitk > 1 ? d.splitk : 1;
     if (d.in_dtype == NBCI_BF16 && glds_eligible(d, k)) return gemm_glds_launch(d, k, stream);
@@ -241,7 +251,14 @@ int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream) 
         ok = descs[i].in_dtype == NBCI_BF16 && ks[i].splitk == 1 && descs[i].batch <= 1 && glds_eligible(descs[i], ks[i]) && !glds_view(descs[i]) &&
              (descs[i].A.kmajor != 0) == (descs[0].A.kmajor != 0) && (descs[i].B.kmajor != 0) == (descs[0].B.kmajor != 0);
     }
-    if (ok) return gemm_group_launch(descs, ks, n, stream);
+    if (ok) {
+        if (FILE* f = gemm_log_file()) {
+            fprintf(f, "G %d %d", n, kind_of(descs[0]));
+            for (int i = 0; i < n; ++i) fprintf(f, " %d %d %d", descs[i].M, descs[i].N, descs[i].K);
+            fprintf(f, "\n"); fflush(f);
+        }
+        return gemm_group_launch(descs, ks, n, stream);
+    }
     for (int i = 0; i < n; ++i) {
         int rc = gemm_launch(descs[i], stream);
         if (rc != NBCI_OK) return rc;
