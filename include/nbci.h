@@ -319,16 +319,19 @@ int nbci_ndt1_backward(nbci_ndt1_plan plan, const float* params, const void* par
                        float* grads, int32_t seg_hi, int32_t seg_lo, nbci_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Masker.forward (models/masker.py:44-104) on the device. The mask bit of an element comes from the counter RNG
- * (site), keyed by the index the mode makes it constant along: temporal = (b,t) (widened by `timespan`, the
- * reference's expand_timesteps :107-110), neuron = (b,n), random = (b,t,n); TABLE_BN / TABLE_N take the
- * Bernoulli probability from `probs` ((B,N): `region` mode, the host maps region names; (N): `co-smooth`);
- * GIVEN uses `ext_mask` as is (tests, replay). Then zero_ratio of the masked elements are zeroed (site+1) and
+ * Masker.forward (models/masker.py:44-104, and the three extra modes of "models/masker copy.py":81-104,117,133) on the device.
+ * The mask bit of an element comes from the counter RNG (site), keyed by the index the mode makes it constant along:
+ * temporal = (b,t) (widened by `timespan`, the reference's expand_timesteps :107-110), neuron = (b,n), random = (b,t,n);
+ * TABLE_BN / TABLE_N / TABLE_T take the Bernoulli probability from `probs` ((B,N): `region`, `inter-region`, `intra-region`
+ * - the host maps region names and draws the region sample; (N): `co-smooth`; (T): `forward-pred`);
+ * GIVEN uses `ext_mask` as is (tests, replay). `target_bn` ((B,N), optional): the RETURNED mask is the bit AND target_bn != 0
+ * while the corruption below uses the full bit (`intra-region`: every neuron outside the target regions is masked, the
+ * targets are the masked bins of the target regions). Then zero_ratio of the masked elements are zeroed (site+1) and
  * random_ratio of the remaining masked ones become U(0, max(out)) (site+2, site+3). `out` may alias `in` (the
  * reference mutates its input); `mask` is overwritten, or OR-ed into when `accumulate` (itransformer.py:324-326).
  * scratch: 4 bytes of device memory. */
 enum { NBCI_MASK_TEMPORAL = 0, NBCI_MASK_NEURON = 1, NBCI_MASK_RANDOM = 2, NBCI_MASK_TABLE_BN = 3, NBCI_MASK_TABLE_N = 4,
-       NBCI_MASK_GIVEN = 5 };
+       NBCI_MASK_GIVEN = 5, NBCI_MASK_TABLE_T = 6 };
 typedef struct nbci_masker_desc {
     int32_t B, T, N;
     int32_t mode;
@@ -343,6 +346,7 @@ typedef struct nbci_masker_desc {
     int64_t* mask;             /* (B,T,N) int64 0/1 */
     int32_t accumulate;
     void* scratch;
+    const float* target_bn;    /* optional (B,N): see above */
 } nbci_masker_desc;
 int nbci_masker(const nbci_masker_desc* desc, nbci_stream_t stream);
 

@@ -73,10 +73,10 @@ class MaskerDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("mode", C.c_int32), ("ratio", C.c_float),
                 ("timespan", C.c_int32), ("zero_ratio", C.c_float), ("random_ratio", C.c_float), ("probs", C.c_void_p),
                 ("ext_mask", C.c_void_p), ("seed", C.c_uint32), ("site", C.c_uint32), ("in_", C.c_void_p), ("out", C.c_void_p),
-                ("mask", C.c_void_p), ("accumulate", C.c_int32), ("scratch", C.c_void_p)]
+                ("mask", C.c_void_p), ("accumulate", C.c_int32), ("scratch", C.c_void_p), ("target_bn", C.c_void_p)]
 
 
-MASK_MODE = {"temporal": 0, "neuron": 1, "random": 2, "region": 3, "co-smooth": 4, "given": 5}
+MASK_MODE = {"temporal": 0, "neuron": 1, "random": 2, "region": 3, "co-smooth": 4, "given": 5, "table_t": 6}
 LOSS_KIND = {("poisson_nll", True): 0, ("poisson_nll", False): 1, ("mse", True): 2, ("mse", False): 2}
 
 

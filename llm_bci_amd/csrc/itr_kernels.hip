@@ -29,6 +29,27 @@ __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u &
 // ------------------------------------------------------------------------------------------
 // Masker.forward (models/masker.py:44-104)
 // ------------------------------------------------------------------------------------------
+// the mask bit of element i = (b, t, c): constant along the axes the mode says (masker.py:54-93, masker copy.py:65-117)
+__device__ __forceinline__ bool masker_bit(const nbci_masker_desc& d, long long i, int b, int t, int c) {
+    switch (d.mode) {
+        case NBCI_MASK_TEMPORAL: {   // bernoulli over (B,T), optionally widened: conv1d(..., ones(span), 'same') >= 1
+            bool m = false;
+            const int left = (d.timespan - 1) / 2;
+            for (int j = 0; j < d.timespan; ++j) {
+                const int tt = t - left + j;
+                if (tt >= 0 && tt < d.T) m = m || (uni24(d.seed, d.site, (uint32_t)(b * d.T + tt)) < d.ratio);
+            }
+            return m;
+        }
+        case NBCI_MASK_NEURON: return uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.ratio;
+        case NBCI_MASK_RANDOM: return uni24(d.seed, d.site, (uint32_t)i) < d.ratio;
+        case NBCI_MASK_TABLE_BN: return uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.probs[b * d.N + c];
+        case NBCI_MASK_TABLE_N: return uni24(d.seed, d.site, (uint32_t)c) < d.probs[c];
+        case NBCI_MASK_TABLE_T: return uni24(d.seed, d.site, (uint32_t)t) < d.probs[t];   // forward-pred (masker copy.py:81-85)
+        default: return d.ext_mask[i] != 0;   // NBCI_MASK_GIVEN
+    }
+}
+
 // pass 1: mask bit per element (constant along the axes the mode says), zero `zero_ratio` of the masked
 // elements, tensor maximum of the result (needed by the random replacement, masker.py:101).
 __global__ __launch_bounds__(256) void masker_zero_kernel(nbci_masker_desc d, unsigned* __restrict__ maxbits) {
@@ -38,26 +59,12 @@ __global__ __launch_bounds__(256) void masker_zero_kernel(nbci_masker_desc d, un
         const int c = (int)(i % d.N);
         const long long bt = i / d.N;
         const int t = (int)(bt % d.T), b = (int)(bt / d.T);
-        bool m = false;
-        switch (d.mode) {
-            case NBCI_MASK_TEMPORAL: {   // bernoulli over (B,T), optionally widened: conv1d(..., ones(span), 'same') >= 1
-                const int left = (d.timespan - 1) / 2;
-                for (int j = 0; j < d.timespan; ++j) {
-                    const int tt = t - left + j;
-                    if (tt >= 0 && tt < d.T) m = m || (uni24(d.seed, d.site, (uint32_t)(b * d.T + tt)) < d.ratio);
-                }
-                break;
-            }
-            case NBCI_MASK_NEURON: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.ratio; break;
-            case NBCI_MASK_RANDOM: m = uni24(d.seed, d.site, (uint32_t)i) < d.ratio; break;
-            case NBCI_MASK_TABLE_BN: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.probs[b * d.N + c]; break;
-            case NBCI_MASK_TABLE_N: m = uni24(d.seed, d.site, (uint32_t)c) < d.probs[c]; break;
-            default: m = d.ext_mask[i] != 0; break;   // NBCI_MASK_GIVEN
-        }
+        const bool m = masker_bit(d, i, b, t, c);
         float v = d.in[i];
         if (m && uni24(d.seed, d.site + 1, (uint32_t)i) < d.zero_ratio) v = 0.f;
         d.out[i] = v;
-        d.mask[i] = d.accumulate ? (d.mask[i] | (long long)m) : (long long)m;
+        const bool mt = m && (!d.target_bn || d.target_bn[b * d.N + c] != 0.f);   // intra-region: targets = masked bins of the target regions only (masker copy.py:133)
+        d.mask[i] = d.accumulate ? (d.mask[i] | (long long)mt) : (long long)mt;
         mx = fmaxf(mx, v);
     }
     mx = wave_max(mx);
@@ -72,22 +79,7 @@ __global__ __launch_bounds__(256) void masker_random_kernel(nbci_masker_desc d, 
         const int c = (int)(i % d.N);
         const long long bt = i / d.N;
         const int t = (int)(bt % d.T), b = (int)(bt / d.T);
-        bool m = false;
-        switch (d.mode) {
-            case NBCI_MASK_TEMPORAL: {
-                const int left = (d.timespan - 1) / 2;
-                for (int j = 0; j < d.timespan; ++j) {
-                    const int tt = t - left + j;
-                    if (tt >= 0 && tt < d.T) m = m || (uni24(d.seed, d.site, (uint32_t)(b * d.T + tt)) < d.ratio);
-                }
-                break;
-            }
-            case NBCI_MASK_NEURON: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.ratio; break;
-            case NBCI_MASK_RANDOM: m = uni24(d.seed, d.site, (uint32_t)i) < d.ratio; break;
-            case NBCI_MASK_TABLE_BN: m = uni24(d.seed, d.site, (uint32_t)(b * d.N + c)) < d.probs[b * d.N + c]; break;
-            case NBCI_MASK_TABLE_N: m = uni24(d.seed, d.site, (uint32_t)c) < d.probs[c]; break;
-            default: m = d.ext_mask[i] != 0; break;
-        }
+        const bool m = masker_bit(d, i, b, t, c);
         if (!m) continue;
         if (uni24(d.seed, d.site + 1, (uint32_t)i) < d.zero_ratio) continue;   // zeroed in pass 1
         if (uni24(d.seed, d.site + 2, (uint32_t)i) < d.random_ratio) d.out[i] = mx * uni24(d.seed, d.site + 3, (uint32_t)i);
@@ -97,8 +89,9 @@ __global__ __launch_bounds__(256) void masker_random_kernel(nbci_masker_desc d, 
 int masker_launch(const nbci_masker_desc& d, hipStream_t s) {
     NBCI_REQUIRE(d.B > 0 && d.T > 0 && d.N > 0, NBCI_ESHAPE, "masker: B, T, N must be positive");
     NBCI_REQUIRE(d.in && d.out && d.mask && d.scratch, NBCI_EINVAL, "masker: in, out, mask and scratch are required");
-    NBCI_REQUIRE(d.mode >= NBCI_MASK_TEMPORAL && d.mode <= NBCI_MASK_GIVEN, NBCI_EINVAL, "masker: unknown mode");
-    NBCI_REQUIRE(!((d.mode == NBCI_MASK_TABLE_BN || d.mode == NBCI_MASK_TABLE_N) && !d.probs), NBCI_EINVAL, "masker: probs table required");
+    NBCI_REQUIRE(d.mode >= NBCI_MASK_TEMPORAL && d.mode <= NBCI_MASK_TABLE_T, NBCI_EINVAL, "masker: unknown mode");
+    NBCI_REQUIRE(!((d.mode == NBCI_MASK_TABLE_BN || d.mode == NBCI_MASK_TABLE_N || d.mode == NBCI_MASK_TABLE_T) && !d.probs), NBCI_EINVAL,
+                 "masker: probs table required");
     NBCI_REQUIRE(!(d.mode == NBCI_MASK_GIVEN && !d.ext_mask), NBCI_EINVAL, "masker: ext_mask required");
     NBCI_REQUIRE(d.mode != NBCI_MASK_TEMPORAL || (d.timespan >= 1 && d.timespan <= 64), NBCI_EINVAL, "masker: timespan must be in 1..64");
     NBCI_REQUIRE((long long)d.B * d.T * d.N < (1ll << 32), NBCI_ESHAPE, "masker: tensor too large for the 32-bit RNG counter");

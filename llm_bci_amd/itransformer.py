@@ -57,6 +57,19 @@ def masker_timespan(seed, site, expand_prob, max_timespan):
     return 1
 
 
+def region_sample(seed, site, regions, n):
+    """`random.sample(regions, n)` of "masker copy.py":91,99 with the counter RNG (site + 5): a partial Fisher-Yates shuffle, so the
+    choice is a function of (seed, site) like every other draw (the reference uses Python's global `random`)."""
+    pool = list(regions)
+    n = int(n)
+    if n > len(pool):
+        raise ValueError("Sample larger than population or is negative")   # what random.sample raises
+    for j in range(n):
+        k = j + _rng_u32(seed, site + 5, j) % (len(pool) - j)
+        pool[j], pool[k] = pool[k], pool[j]
+    return pool[:n]
+
+
 def layout_of(T, H, L, C_, R, use_cls, mlp_decoder):
     b = LayoutBuilder()
     b.add("encoder.embed.0.0.weight", (H, T), 0); b.add("encoder.embed.0.0.bias", (H,), 0)
@@ -283,6 +296,31 @@ class iTransformer(FlatParamModule):
                 probs = torch.from_numpy(pr).to(dev)
                 d.mode, d.probs = MASK_MODE["co-smooth"], _ptr(probs)
                 keep.append(probs)
+            elif mode == "forward-pred":          # "masker copy.py":81-85: a fixed set of time steps
+                assert mc.get("timesteps") is not None, "No time steps to mask"
+                pr = np.zeros(T, np.float32)
+                pr[list(mc["timesteps"])] = 1
+                probs = torch.from_numpy(pr).to(dev)
+                d.mode, d.probs = MASK_MODE["table_t"], _ptr(probs)
+                keep.append(probs)
+            elif mode == "inter-region":          # :86-94: `ratio` of the neurons of n_mask_regions sampled regions; targets = the mask
+                assert neuron_regions is not None, "Can't mask region without brain region information"
+                assert mc.get("mask_regions") is not None, "No regions to mask"
+                chosen = region_sample(seed, d.site, mc["mask_regions"], mc.get("n_mask_regions", 1))
+                pr = np.isin(np.asarray(neuron_regions), chosen).astype(np.float32) * np.float32(mc["ratio"])
+                probs = torch.from_numpy(pr).to(dev).contiguous()
+                d.mode, d.probs = MASK_MODE["region"], _ptr(probs)
+                keep.append(probs)
+            elif mode == "intra-region":          # :95-104,133: everything outside the sampled target regions is masked, `ratio` inside;
+                assert neuron_regions is not None, "Can't mask region without brain region information"   # targets = masked bins inside
+                assert mc.get("target_regions") is not None, "No target regions"
+                chosen = region_sample(seed, d.site, mc["target_regions"], mc.get("n_mask_regions", 1))
+                tgt = np.isin(np.asarray(neuron_regions), chosen)
+                pr = np.where(tgt, np.float32(mc["ratio"]), np.float32(1.0)).astype(np.float32)
+                probs = torch.from_numpy(pr).to(dev).contiguous()
+                target = torch.from_numpy(tgt.astype(np.float32)).to(dev).contiguous()
+                d.mode, d.probs, d.target_bn = MASK_MODE["region"], _ptr(probs), _ptr(target)
+                keep += [probs, target]
             else:
                 raise Exception(f"Masking mode {mode} not implemented")
             if first:

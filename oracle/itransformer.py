@@ -65,10 +65,22 @@ def masker_timespan(seed, site, expand_prob, max_timespan):
     return 1
 
 
-def masker(mc, spikes, training, seed, site, probs=None):
-    """Masker.forward (masker.py:44-104). mc: dict(active, force_active, mode, ratio, zero_ratio, random_ratio, expand_prob,
-    max_timespan, channels). `probs`: (B,N) 0/1 table for `region` mode (the reference builds it from region names on
-    the host). Returns (masked copy, int64 mask); the reference mutates `spikes` in place, this does not."""
+def region_sample(seed, site, regions, n):
+    """random.sample(regions, n) ("masker copy.py":91,99) drawn from the counter RNG at site + 5 (partial Fisher-Yates), as the
+    host side of the HIP path draws it."""
+    pool = list(regions)
+    for j in range(int(n)):
+        k = j + int(R.rng_u32(seed, site + 5, np.array([j], np.uint32))[0] % np.uint32(len(pool) - j))
+        pool[j], pool[k] = pool[k], pool[j]
+    return pool[:int(n)]
+
+
+def masker(mc, spikes, training, seed, site, probs=None, neuron_regions=None):
+    """Masker.forward (masker.py:44-104) plus the modes of "models/masker copy.py":81-104,117,133 (forward-pred, inter-region,
+    intra-region). mc: dict(active, force_active, mode, ratio, zero_ratio, random_ratio, expand_prob, max_timespan, channels,
+    timesteps, mask_regions, target_regions, n_mask_regions). `probs`: (B,N) 0/1 table for `region` mode (the reference builds it
+    from region names on the host); `neuron_regions`: (B,N) region names for the inter- / intra-region modes.
+    Returns (masked copy, int64 mask); the reference mutates `spikes` in place, this does not."""
     B, T, N = spikes.shape
     if not mc.get("active", True) or (not training and not mc.get("force_active", False)):
         return spikes.copy(), np.zeros((B, T, N), np.int64)
@@ -89,6 +101,21 @@ def masker(mc, spikes, training, seed, site, probs=None):
         pr = np.zeros(N, np.float32)
         pr[list(mc["channels"])] = 1
         mask = np.broadcast_to((uniform(seed, site, N) < pr)[None, None, :], (B, T, N))
+    elif mode == "forward-pred":
+        pr = np.zeros(T, np.float32)
+        pr[list(mc["timesteps"])] = 1
+        mask = np.broadcast_to((uniform(seed, site, T) < pr)[None, :, None], (B, T, N))
+    elif mode == "inter-region":
+        chosen = region_sample(seed, site, mc["mask_regions"], mc.get("n_mask_regions", 1))
+        pr = np.isin(np.asarray(neuron_regions), chosen).astype(np.float32) * np.float32(ratio)
+        mask = np.broadcast_to((uniform(seed, site, B * N).reshape(B, N) < pr)[:, None, :], (B, T, N))
+    elif mode == "intra-region":
+        chosen = region_sample(seed, site, mc["target_regions"], mc.get("n_mask_regions", 1))
+        tgt = np.isin(np.asarray(neuron_regions), chosen)
+        pr = np.where(tgt, np.float32(ratio), np.float32(1.0)).astype(np.float32)
+        mask = np.broadcast_to((uniform(seed, site, B * N).reshape(B, N) < pr)[:, None, :], (B, T, N))
+        out, full = apply_mask(mc, spikes, mask, seed, site)
+        return out, full * tgt[:, None, :].astype(np.int64)      # targets: the masked bins of the target regions only (:133)
     else:
         raise Exception(f"Masking mode {mode} not implemented")
     return apply_mask(mc, spikes, mask, seed, site)

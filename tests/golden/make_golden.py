@@ -266,7 +266,7 @@ if __name__ == "__main__" and "--factors" in sys.argv:
                                                  "init_range": 0.1}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     sys.exit(0)
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst", "--masker-copy")):
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
@@ -531,12 +531,49 @@ def masker_cases():
     print("masker_cases", {k: v.shape for k, v in fx.items() if k.endswith("_mask")})
 
 
+def masker_copy_cases():
+    """The three extra modes of the reference's "models/masker copy.py" (forward-pred :81-85, inter-region :86-94, intra-region
+    :95-104 + :133). The file name has a space, so it is loaded by path; Python's `random` (its region sample) and torch are seeded.
+    As for masker_cases the draws are not reproducible elsewhere: the fixture pins the STRUCTURE (which bins are masked / returned
+    as targets / corrupted) in cases where it is deterministic (ratio 1, every listed region sampled) and the invariants elsewhere."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location("masker_copy", os.path.join(REF, "models", "masker copy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from utils.config_utils import DictConfig
+    fx = {}
+    g = np.random.default_rng(6)
+    B, T, N = 4, 10, 12
+    spikes = g.poisson(2.0, (B, T, N)).astype(np.float32) + 1.0      # strictly positive: a zeroed bin is recognisable
+    regions = np.array([["CA1", "DG", "PO", "VIS"][(i * 7 + i // 5) % 4] for i in range(B * N)]).reshape(B, N)
+    base = dict(force_active=True, mode="neuron", ratio=1.0, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1,
+                channels=None, timesteps=None, mask_regions=None, target_regions=None, n_mask_regions=1)
+    cases = {"forward_pred": dict(mode="forward-pred", timesteps=[2, 5, 6]),
+             "inter_all": dict(mode="inter-region", mask_regions=["CA1", "PO"], n_mask_regions=2, ratio=1.0),
+             "inter_half": dict(mode="inter-region", mask_regions=["CA1", "PO", "DG"], n_mask_regions=1, ratio=0.5),
+             "intra_all": dict(mode="intra-region", target_regions=["DG"], n_mask_regions=1, ratio=1.0),
+             "intra_some": dict(mode="intra-region", target_regions=["DG", "VIS"], n_mask_regions=2, ratio=0.4)}
+    for name, extra in cases.items():
+        c = dict(base); c.update(extra)
+        torch.manual_seed(7); random.seed(7)
+        mk = mod.Masker(DictConfig(c)); mk.train()
+        out, mask = mk(torch.from_numpy(spikes.copy()), regions)
+        fx[name + "_out"] = out.numpy(); fx[name + "_mask"] = mask.numpy(); fx[name + "_cfg"] = np.array(json.dumps(c))
+    fx["spikes"] = spikes; fx["regions"] = regions.astype("U8")
+    np.savez_compressed(os.path.join(OUT, "masker_copy_cases.npz"), **fx)
+    print("masker_copy_cases", {k: int(v.sum()) for k, v in fx.items() if k.endswith("_mask")})
+
+
 def itr_tiny(**enc_extra):
     enc = {"embedder": {"max_n_bins": 12, "dropout": 0.0}, "hidden_size": 32, "n_heads": 2, "n_layers": 2, "dropout": 0.0,
            "max_n_channels": 16, "embed_region": False}
     enc.update(enc_extra)
     return {"encoder": enc, "masker": {"main": {"active": True, "regions": None, "ratio": 0.3}}}
 
+
+if __name__ == "__main__" and "--masker-copy" in sys.argv:
+    masker_copy_cases()
 
 if __name__ == "__main__" and "--itr" in sys.argv:
     _install_torchvision_mlp()

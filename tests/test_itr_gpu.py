@@ -74,6 +74,33 @@ def test_masker_matches_oracle_bit_exact(mode, extra):
     assert mask.sum().item() == 0 and np.array_equal(masked.cpu().numpy(), spikes)   # masker.py:50-51
 
 
+@pytest.mark.parametrize("case", ["forward_pred", "inter_all", "inter_half", "intra_all", "intra_some"])
+def test_masker_copy_modes_bit_exact_vs_oracle_and_reference_structure(case):
+    """the three extra modes of the reference's "models/masker copy.py" on the device: bit-exact against the oracle (same counter
+    RNG, same region sample), and in the deterministic cases equal to what the reference's own Masker returned."""
+    from llm_bci_amd.itransformer import SITE_MASKER, region_sample
+    fx = load("masker_copy_cases")
+    sp, regions = fx["spikes"], fx["regions"]
+    B, T, N = sp.shape
+    mc = json.loads(str(fx[case + "_cfg"]))
+    mc["active"] = True
+    over = {"encoder": {"embedder": {"max_n_bins": T, "dropout": 0.0}, "hidden_size": 32, "n_heads": 2, "n_layers": 1, "dropout": 0.0,
+                        "max_n_channels": 16, "embed_region": False}, "masker": {"main": mc}}
+    m = _model(over).to(DEV)
+    m.train()
+    for seed in (21, 987654321):
+        d = torch.from_numpy(sp).to(DEV)
+        masked, mask, _keep = m._apply_maskers(d, regions, seed)
+        torch.cuda.synchronize()
+        ref_out, ref_mask = OI.masker(mc, sp, True, seed, SITE_MASKER, neuron_regions=regions)
+        assert np.array_equal(mask.cpu().numpy(), ref_mask)
+        np.testing.assert_allclose(masked.cpu().numpy(), ref_out, rtol=1e-6, atol=0)
+        assert np.array_equal(d.cpu().numpy(), sp)                    # the caller's tensor is left alone
+        if case in ("forward_pred", "inter_all", "intra_all"):        # deterministic: the reference's own output
+            assert np.array_equal(mask.cpu().numpy(), fx[case + "_mask"]) and np.array_equal(masked.cpu().numpy(), fx[case + "_out"])
+    assert region_sample(5, SITE_MASKER, ["a", "b", "c", "d"], 3) == OI.region_sample(5, SITE_MASKER, ["a", "b", "c", "d"], 3)
+
+
 def test_masker_two_maskers_accumulate():
     from llm_bci_amd.itransformer import SITE_MASKER
     g = np.random.default_rng(4)

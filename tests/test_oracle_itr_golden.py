@@ -142,3 +142,48 @@ def test_masker_rules_match_reference_structure():
     assert np.array_equal(out, sp) and mask.sum() == 0
     out, mask = OI.masker(dict(base, mode="temporal", expand_prob=1.0, max_timespan=3), sp, True, 5, OI.SITE_MASKER)
     assert (mask == mask[:, :, :1]).all()
+
+
+def test_masker_copy_modes_match_reference_structure():
+    """forward-pred / inter-region / intra-region of the reference's "models/masker copy.py" (:81-104,117,133), recorded by
+    make_golden.py --masker-copy. Deterministic cases (ratio 1, every listed region sampled) must match bit for bit; in the
+    others the draws differ (torch / Python RNG vs the counter RNG), so the same structural invariants are checked on both."""
+    fx = load("masker_copy_cases")
+    sp, regions = fx["spikes"], fx["regions"]
+    B, T, N = sp.shape
+
+    def run(name):
+        mc = json.loads(str(fx[name + "_cfg"]))
+        mc["active"] = True
+        return mc, OI.masker(mc, sp, True, seed=21, site=OI.SITE_MASKER, neuron_regions=regions)
+
+    for name in ("forward_pred", "inter_all", "intra_all"):          # deterministic: exact
+        mc, (out, mask) = run(name)
+        assert np.array_equal(mask, fx[name + "_mask"]), name
+        assert np.array_equal(out, fx[name + "_out"]), name
+    assert set(np.nonzero(fx["forward_pred_mask"][0, :, 0])[0]) == {2, 5, 6}
+    assert np.array_equal(fx["inter_all_mask"][:, 0, :].astype(bool), np.isin(regions, ["CA1", "PO"]))
+    assert (fx["intra_all_out"] == 0).all() and np.array_equal(fx["intra_all_mask"][:, 0, :].astype(bool), regions == "DG")
+
+    mc, (out, mask) = run("inter_half")                              # one of three regions, half of its neurons
+    for mm, oo in ((mask, out), (fx["inter_half_mask"], fx["inter_half_out"])):
+        mb = mm.astype(bool)
+        assert (mm == mm[:, :1, :]).all()                            # constant along time
+        hit = set(regions[mb[:, 0, :]])
+        assert len(hit) <= 1 and hit <= {"CA1", "PO", "DG"}          # a single sampled region
+        assert (oo[mb] == 0).all() and np.array_equal(oo[~mb], sp[~mb])
+    assert 0 < mask.sum() < np.isin(regions, ["CA1", "PO", "DG"]).sum() * T
+
+    mc, (out, mask) = run("intra_some")                              # targets inside DG + VIS; everything outside is masked too
+    tgt = np.isin(regions, ["DG", "VIS"])
+    for mm, oo in ((mask, out), (fx["intra_some_mask"], fx["intra_some_out"])):
+        mb = mm.astype(bool)
+        assert (mm == mm[:, :1, :]).all() and not mb[:, 0, :][~tgt].any()         # returned targets lie inside the target regions
+        assert (oo[:, :, :][np.broadcast_to(~tgt[:, None, :], oo.shape)] == 0).all()   # every neuron outside them is corrupted
+        inside = np.broadcast_to(tgt[:, None, :], oo.shape)
+        assert np.array_equal((oo == 0) & inside, mb)                              # inside: corrupted exactly where returned
+    assert 0 < mask.sum() < tgt.sum() * T
+    # the region sample: distinct members of the list, a function of (seed, site)
+    s1 = OI.region_sample(5, OI.SITE_MASKER, ["a", "b", "c", "d"], 3)
+    assert len(set(s1)) == 3 and set(s1) <= {"a", "b", "c", "d"} and s1 == OI.region_sample(5, OI.SITE_MASKER, ["a", "b", "c", "d"], 3)
+    assert {tuple(OI.region_sample(s, OI.SITE_MASKER, ["a", "b", "c", "d"], 1)) for s in range(40)} == {("a",), ("b",), ("c",), ("d",)}
