@@ -108,6 +108,44 @@ def cpu_baseline(budget_s=12.0, T=600, N=256, S=60):
             "reference_eager_8vcpu_build_container": 5.2}
 
 
+def feed_from_host(tr, args, dev, n_rows=256, windows=3):
+    """K train steps per window, every batch collated on the host and uploaded while the previous step runs."""
+    from llm_bci_amd.collate import DeviceFeeder, HostCollator, PinnedPool, item_from_row
+    g = np.random.default_rng(11)
+    T, N, S, B = args.bins, args.channels, args.target_len, args.batch
+    lens = g.integers(T // 2, T + 1, n_rows)
+    items = [item_from_row({"spikes": g.standard_normal((int(L), N)).astype(np.float32),
+                            "targets": g.integers(1, 41, (max(1, int(S * L / T)),)).astype(np.int64)}) for L in lens]
+    full = item_from_row({"spikes": g.standard_normal((T, N)).astype(np.float32), "targets": g.integers(1, 41, (S,)).astype(np.int64)})
+    pad = {k: dict(dim=0, side="right", value=0, truncate=None, min_length=None)      # trainer_ctc_ndt1.yaml pad_dict
+           for k in ("spikes", "spikes_mask", "spikes_timestamp", "targets", "targets_mask")}
+    names = ["spikes", "spikes_mask", "spikes_timestamp", "spikes_lengths", "targets", "targets_lengths"]
+    n_batches = 2 + windows * args.steps
+
+    def sampler():
+        for _ in range(n_batches):
+            idx = g.integers(0, n_rows, B - 1)
+            yield [full] + [items[i] for i in idx]      # one full-length row: the padded shape equals the resident point's
+
+    pool = PinnedPool()
+    feeder = DeviceFeeder(HostCollator(sampler(), names, pad, workers=4, depth=4, pool=pool), dev, pool=pool)
+    for _ in range(2):
+        b, _u = next(feeder)
+        tr.train_step(b, seed=1)
+    ws = []
+    for w in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            b, _u = next(feeder)
+            tr.train_step(b, seed=7000 + 100 * w + i)
+        torch.cuda.synchronize()
+        ws.append(time.perf_counter() - t0)
+    w = sorted(ws)[len(ws) // 2]
+    return {"ms_per_step": round(1e3 * w / args.steps, 3), "samples_per_s": round(B * args.steps / w, 1),
+            "h2d_mbytes_per_step": round(B * T * N * 4 / 1e6, 1), "pinned_buffers_allocated": pool.allocated}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +189,7 @@ def main():
     model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
     # OneCycle horizon: warm-up + timed windows + the 3 profiling steps + the two extra points (2 warm-up + 3 windows each)
-    total_steps = args.warmup + args.steps * max(1, args.repeats) + 3 + 2 * (2 + 3 * args.steps) + 16
+    total_steps = args.warmup + args.steps * max(1, args.repeats) + 3 + 3 * (2 + 3 * args.steps) + 16
     tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=total_steps, warmup_pct=0.0,
                        div_factor=25)
     _, batch = make_batch(args.batch, args.bins, args.channels, args.target_len, 41, dev, seed=rank)
@@ -229,6 +267,13 @@ def main():
             extra[name] = {"ms_per_step": round(1e3 * w / args.steps, 3), "samples_per_s": round(B2 * args.steps / w, 1)}
             if rg:
                 extra[name]["mean_valid_fraction"] = round(float(b2["spikes_lengths"].float().mean().item()) / args.bins, 3)
+        # the same ragged workload FED FROM THE HOST every step: a pool of rows in host memory -> background
+        # collation into recycled pinned buffers (llm_bci_amd.collate.HostCollator) -> asynchronous H2D on a copy stream
+        # (DeviceFeeder) -> train step; a fresh batch of the recipe's size each step, nothing resident.
+        fed = feed_from_host(tr, args, dev)
+        rs = extra[f"B{args.batch}_ragged"]["ms_per_step"]
+        fed["vs_resident_ragged"] = round(fed["ms_per_step"] / rs, 3)
+        extra[f"B{args.batch}_ragged_fed_from_host"] = fed
         tr.read_stats()
     if world > 1:
         dist.barrier()

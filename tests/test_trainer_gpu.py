@@ -103,3 +103,43 @@ def test_resume_reproduces_training(tmp_path):
     assert (d > 2e-5).float().mean() < 0.01 and d.max() < 4.1e-3, (d.max(), (d > 2e-5).float().mean())
     ev = tr2.evaluate([bd])
     assert ev["loss"] > 0 and ev["PER"] is not None
+
+
+def test_host_fed_batches_equal_reference_collate_and_survive_buffer_recycling():
+    """rows -> HostCollator (background threads, recycled pinned buffers) -> DeviceFeeder (copy stream) -> device
+    batches. (a) the fed batch of the fixture's rows equals the reference's pad_collate_fn output stored in g_tiny.npz bit for bit;
+    (b) 24 distinct batches through a pool that ends up with a handful of buffers arrive intact and in order (a buffer handed back
+    before its copy finished, or a device tensor recycled under a running kernel, would corrupt some of them)."""
+    from llm_bci_amd.collate import DeviceFeeder, HostCollator, PinnedPool, item_from_row, pad_collate_fn
+    from test_oracle_golden import load
+    fx = load("g_tiny")
+    g = np.random.default_rng(0)
+    rows = []
+    for L, S in zip([30, 22, 17], [5, 4, 2]):     # the rows make_golden.py fed the reference's collate (same generator order)
+        rows.append(item_from_row({"spikes": g.standard_normal((L, 16)).astype(np.float32), "targets": g.integers(1, 11, (S,)).astype(np.int64)}))
+    pad = {k: dict(dim=0, side="right", value=0, truncate=None, min_length=None)
+           for k in ("spikes", "spikes_mask", "spikes_timestamp", "targets", "targets_mask")}
+    names = ["spikes", "spikes_mask", "spikes_timestamp", "spikes_lengths", "targets", "targets_lengths"]
+    pool = PinnedPool()
+    dev_batch, unused = next(DeviceFeeder(HostCollator([rows], names, pad, pool=pool), DEV, pool=pool))
+    torch.cuda.synchronize()
+    for k in names:
+        assert np.array_equal(dev_batch[k].cpu().numpy(), fx["in_" + k]), k
+    assert "targets_mask" in unused
+    g = np.random.default_rng(1)
+    items = [item_from_row({"spikes": g.standard_normal((int(L), 64)).astype(np.float32), "targets": g.integers(1, 11, (4,)).astype(np.int64)})
+             for L in g.integers(40, 101, 48)]
+    batches = [[items[(5 * i + j) % 48] for j in range(8)] for i in range(24)]
+    pool = PinnedPool()
+    feeder = DeviceFeeder(HostCollator(batches, names, pad, workers=3, depth=3, pool=pool), DEV, pool=pool)
+    burn = torch.randn(2048, 2048, device=DEV)
+    n = 0
+    for (b, _u), rb in zip(feeder, batches):
+        burn = burn @ burn * 1e-3                       # keep the consumer stream busy while the next upload runs
+        ref, _ = pad_collate_fn(rb, names, pad)
+        got = {k: b[k].clone() for k in names}          # (on the consumer stream, ordered after the upload)
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(got[k].cpu(), ref[k]), (n, k)
+        n += 1
+    assert n == 24 and pool.allocated <= 5 * 6          # buffers are recycled: a handful per key, not one per batch
