@@ -225,6 +225,27 @@ int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t
 
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Data-parallel exchange for a host that is not PyTorch (the Python host uses torch.distributed, backend "nccl" = RCCL):
+ * replaces accelerate -> DDP's bucketed gradient all-reduce (models/trainer.py:260-262,339). One communicator per process /
+ * GPU over the node's xGMI mesh. Rank 0 calls nbci_comm_unique_id, ships the 128 bytes to the other ranks by any host channel,
+ * then every rank calls nbci_comm_create. nbci_allreduce_bucket all-reduces (SUM, in place) one contiguous gradient range of
+ * the flat buffer (nbci_ndt1_segment_range) on `stream` - call it right after nbci_ndt1_backward of that segment so the exchange
+ * overlaps the rest of the backward - and DDP's mean is nbci_adamw's grad_scale = 1 / world_size. dtype NBCI_F32 or NBCI_BF16.
+ * librccl.so is opened on first use (dlopen): libnbci.so itself does not depend on it. */
+typedef void* nbci_comm;
+int nbci_comm_unique_id(void* id128);
+int nbci_comm_create(nbci_comm* comm, int32_t world_size, int32_t rank, const void* id128);
+void nbci_comm_destroy(nbci_comm comm);
+int nbci_allreduce_bucket(nbci_comm comm, void* buf, int64_t n, int32_t dtype, nbci_stream_t stream);
+
+/* How many CUs the GEMM tile cost model may count on (default 256). An overlapped RCCL all-reduce parks its channels' workgroups
+ * on some CUs; grids sized for exactly one or two rounds of 256 CUs then spill into an extra, nearly empty round. With the
+ * number lowered the model prefers tile heights whose rounds fit the CUs that are left (tools/dp_cu_footprint.py measures it). */
+int nbci_set_available_cus(int32_t cus);
+/* Measurement aid: park n_workgroups workgroups (256 threads, lds_bytes of LDS each) for `microseconds` on `stream`. */
+int nbci_debug_occupy_cus(int32_t n_workgroups, int32_t lds_bytes, double microseconds, nbci_stream_t stream);
+
 /* Measurement aid (no reference counterpart): when enabled, every GEMM launched by
  * nbci_ndt1_forward/backward is bracketed by HIP events on its own stream. collect() waits for
  * them and fills out24[kind*3 + {0,1,2}] = {total ms, total FLOPs, launches}, kind =

@@ -183,6 +183,12 @@ _SIGNATURES = {
     "nbci_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nbci_profile_enable": (C.c_int, [C.c_int32]),
     "nbci_debug_gemm_pc": (C.c_int, [C.c_int32]),
+    "nbci_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "nbci_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "nbci_comm_destroy": (None, [C.c_void_p]),
+    "nbci_allreduce_bucket": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "nbci_set_available_cus": (C.c_int, [C.c_int32]),
+    "nbci_debug_occupy_cus": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
     "nbci_profile_collect": (C.c_int, [C.POINTER(C.c_double)]),
     "nbci_step_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "nbci_per": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

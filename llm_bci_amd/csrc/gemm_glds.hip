@@ -380,6 +380,11 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
 
 bool gemm_pc_eligible(const nbci_gemm_desc& d, const GemmK& k);
 int gemm_pc_mode();
+
+// CUs the tile cost model counts on (nbci_set_available_cus): fewer than 256 while an overlapped all-reduce occupies some
+static int g_avail_cus = 256;
+void set_available_cus(int cus) { g_avail_cus = cus; }
+int available_cus() { return g_avail_cus; }
 long gemm_pc_tiles(const nbci_gemm_desc& d);
 int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
 
@@ -394,8 +399,8 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int pc_mode = gemm_pc_mode();
     if (pc_mode && gemm_pc_eligible(d, k)) {
         const long tiles = gemm_pc_tiles(d);
-        const long last = tiles % 256;
-        if (pc_mode == 2 || (d.K >= 2048 && tiles >= 192 && (last == 0 || last >= 192))) return gemm_pc_launch(d, k, stream);
+        const long cus = g_avail_cus, last = tiles % cus;
+        if (pc_mode == 2 || (d.K >= 2048 && tiles >= 3 * cus / 4 && (last == 0 || last >= 3 * cus / 4))) return gemm_pc_launch(d, k, stream);
     }
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.
@@ -411,7 +416,8 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
             if (c == 160 && glds_view(d)) continue;   // (view launches pick their own 160-row case below)
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
             if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
-            const double cost = c == 288 ? (double)((tiles + 255) / 256) * c / 2.0 / 1.5 : (double)((tiles + 511) / 512) * c;
+            const long s1 = g_avail_cus, s2 = 2 * g_avail_cus;   // workgroup slots per round (one / two workgroups per CU)
+            const double cost = c == 288 ? (double)((tiles + s1 - 1) / s1) * c / 2.0 / 1.5 : (double)((tiles + s2 - 1) / s2) * c;
             if (best < 0 || cost < best) { best = cost; bm = c; }
         }
     }
@@ -424,7 +430,8 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         // where 128- / 144-row tiles need a second, mostly empty one)
         if (d.K % 64 == 0 && splitk == 1) {
             const long t160 = (long)((d.M + 159) / 160) * k.tiles_n * batch;
-            const double c160 = (double)((t160 + 511) / 512) * 160, ccur = (double)(((long)grid.x * grid.y + 511) / 512) * bm;
+            const long s2 = 2 * g_avail_cus;
+            const double c160 = (double)((t160 + s2 - 1) / s2) * 160, ccur = (double)(((long)grid.x * grid.y + s2 - 1) / s2) * bm;
             if (c160 < ccur) {
                 k.tiles_m = (d.M + 159) / 160;
                 return launch_glds<true, false, 1, 4, 10, 2, true>(k, dim3(k.tiles_m * k.tiles_n, batch), stream);

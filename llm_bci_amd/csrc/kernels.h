@@ -11,7 +11,9 @@ int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream);  // = gemm_l
 int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream);        // <= 6 problems, one launch
 int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream);
 void gemm_profile_enable(bool on);
-void gemm_pc_set_mode(int m);   // gemm_pc.hip: kernel-family switch (nbci_debug_gemm_pc)
+void gemm_pc_set_mode(int m);
+void set_available_cus(int cus);   // gemm_glds.hip: CUs the tile cost model may count on (nbci_set_available_cus)
+int available_cus();   // gemm_pc.hip: kernel-family switch (nbci_debug_gemm_pc)
 bool gemm_profile_on();
 int gemm_profile_collect(double* out24);
 

@@ -31,12 +31,18 @@ def shard_batch(batch, rank, world):
 
 
 class GradReducer:
-    """Bucketed async all-reduce over contiguous segments of a flat gradient buffer."""
+    """Bucketed async all-reduce over contiguous segments of a flat gradient buffer.
+    comm_dtype="bf16": every bucket is rounded to bf16, summed on the wire in bf16 and widened back (half the xGMI bytes: 82 MB
+    instead of 164 MB per NDT1 step; SURVEY §8e allows it, f32 stays the default and the parity setting). The sum of W bf16 values
+    is exact in f32 terms up to bf16 rounding of the result: a relative error of 2^-9 per element, independent of the bucket size."""
 
-    def __init__(self, segments, group=None, min_bucket_elems=1 << 20):
+    def __init__(self, segments, group=None, min_bucket_elems=1 << 20, comm_dtype="fp32"):
         self.segments = list(segments)           # [(begin, end)] ascending by offset
         self.group = group
         self.min_bucket = min_bucket_elems
+        if comm_dtype not in ("fp32", "bf16"):
+            raise ValueError("comm_dtype must be 'fp32' or 'bf16'")
+        self.comm_bf16 = comm_dtype == "bf16"
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._pending = None                     # [begin, end) accumulated but not yet launched
@@ -67,7 +73,11 @@ class GradReducer:
     def _launch(self, flat):
         b, e = self._pending
         self._pending = None
-        self._works.append((b, e, dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        if self.comm_bf16:
+            lp = flat[b:e].to(torch.bfloat16)    # (on the backward's stream, before the collective is queued behind it)
+            self._works.append((b, e, dist.all_reduce(lp, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lp))
+        else:
+            self._works.append((b, e, dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
 
     def finish(self, flat=None):
         for _ in self.drain(flat):
@@ -79,8 +89,12 @@ class GradReducer:
         if self._pending is not None and flat is not None:
             self._launch(flat)
         works, self._works = self._works, []
-        for (b, e, w) in works:
+        for (b, e, w, lp) in works:
             w.wait()
+            if lp is not None:
+                if flat is None:
+                    raise ValueError("drain(flat) needs the gradient buffer in bf16 communication mode")
+                flat[b:e].copy_(lp)              # widen the reduced bf16 bucket back into the f32 gradient range
             yield (b, e)
 
 

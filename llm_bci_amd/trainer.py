@@ -34,7 +34,7 @@ def register_into(reference_trainer_module):
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
                  div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
-                 compute_per=True, blank_id=0):
+                 compute_per=True, blank_id=0, comm_dtype="fp32"):
         self.model = model
         self.ga = gradient_accumulation_steps
         self.wd, self.eps, self.beta2 = wd, eps, betas[1]
@@ -51,7 +51,7 @@ class NativeTrainer:
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.reducer = GradReducer(model._segments, group=group)
+        self.reducer = GradReducer(model._segments, group=group, comm_dtype=comm_dtype)   # "bf16": half the bytes on the wire
         self.world = self.reducer.world
         self.group = group
         self.global_step = 1          # counts micro-batches like trainer.py:321

@@ -171,3 +171,39 @@ def _bci_worker(rank, world, port, out_dir):
 def test_bci_two_rank_reduce_schedule_covers_encoder_coupler_and_adapters(tmp_path):
     mp.spawn(_bci_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(tmp_path, "ok"))
+
+
+def _bf16_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from llm_bci_amd.dp import GradReducer
+    segs = [(0, 5000), (5000, 9000), (9000, 16000)]
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(16000, generator=g)
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        flat = mine.clone()
+        red = GradReducer(segs, min_bucket_elems=4000, comm_dtype=mode)
+        for seg in (2, 1, 0):
+            red.segment_done(flat, seg)
+        covered = torch.zeros(16000, dtype=torch.int32)
+        for b, e in red.drain(flat):
+            covered[b:e] += 1
+        assert bool((covered == 1).all())
+        outs[mode] = flat
+    # reference: the exact f32 sum over ranks
+    ref = sum(torch.randn(16000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    assert torch.allclose(outs["fp32"], ref, rtol=1e-6, atol=1e-6)
+    err = (outs["bf16"] - ref).abs()
+    bound = 2.0 ** -8 * (sum(torch.randn(16000, generator=torch.Generator().manual_seed(100 + r)).abs() for r in range(world)) + ref.abs())
+    assert bool((err <= bound + 1e-6).all()), float((err - bound).max())     # bf16 rounding of each addend and of the sum, no more
+    assert float(err.mean()) > 0.0                                             # (it really went through bf16)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_allreduce_option_is_within_bf16_rounding_of_the_f32_sum(tmp_path):
+    mp.spawn(_bf16_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok"))
