@@ -35,7 +35,24 @@ struct FAArgs {
     int NS, nh, S, H;
     float scale;
     unsigned thr; float dscale; uint32_t key;
+    // MASK kernels (NDT1: models/ndt1.py:30-41,435-437): key j is visible to query i iff j == i, or the context span allows
+    // (i, j) AND token j is valid. tmask (NS, S) int32; cf / cb = context.forward / backward (-2 = unbounded).
+    const int32_t* tmask; int cf, cb;
+    // dropout of the attention OUTPUT (ndt1.py:292) fused into the forward's store: index = element offset in (NS*S, H)
+    unsigned thr_out; float oscale; uint32_t key_out;
 };
+
+__device__ __forceinline__ bool fa_ctx(int i, int j, int f, int bk) {   // create_context_mask (ndt1.py:30-41), as kernels.hip ctx_allowed
+    if (f >= -1 && j - i > f) return false;
+    if (bk >= -1 && i - j > bk) return false;
+    return true;
+}
+// validity bits of keys k0 .. k0+31 of sequence `sq` (bit b = key k0 + b valid and inside the sequence)
+__device__ __forceinline__ unsigned fa_valid_bits(const FAArgs& a, int sq, int k0, int lane) {
+    bool v = false;
+    if (lane < 32 && k0 + lane < a.S) v = a.tmask[(long long)sq * a.S + k0 + lane] != 0;
+    return (unsigned)__builtin_amdgcn_ballot_w64(v);
+}
 
 constexpr int FA_IMG = 32 * 256;   // bytes of one wave-private image (32 rows x 256 B)
 
@@ -105,11 +122,14 @@ __device__ __forceinline__ void fa_to_image(char* img, const bf16x8 (&f)[2][HD /
 #endif
 constexpr int NQ = FA_NQ;
 
-template <int HD, bool TAIL>
+template <int HD, bool TAIL, bool MASK>
 __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
-                                            f32x4 (&o)[NQ][HD / 16], float (&m)[NQ], float (&l)[NQ], const unsigned (&rbase)[NQ], int lane) {
+                                            f32x4 (&o)[NQ][HD / 16], float (&m)[NQ], float (&l)[NQ], const unsigned (&rbase)[NQ],
+                                            const int (&qidx)[NQ], int sq, int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
+    unsigned vb = 0u;
+    if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
     f32x4 sc[NQ][2];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi)
@@ -130,6 +150,11 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
             for (int r = 0; r < 4; ++r) {
                 float s = sc[qi][t][r] * a.scale;
                 if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) s = -INFINITY;
+                if constexpr (MASK) {
+                    const int key = k0 + 16 * t + 4 * g + r;
+                    const bool ok = key == qidx[qi] || (fa_ctx(qidx[qi], key, a.cf, a.cb) && ((vb >> (16 * t + 4 * g + r)) & 1u));
+                    if (!ok) s = -INFINITY;
+                }
                 sc[qi][t][r] = s;
                 cm = fmaxf(cm, s);
             }
@@ -152,7 +177,8 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
             if (a.thr) fa_keep4(a.key, a.thr, rbase[qi] + (unsigned)(k0 + 16 * t + 4 * g), a.dscale, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[qi][t][r] - m[qi]);       // exp(-inf) = 0 for keys past the end
+                // exp(-inf) = 0 for keys past the end; MASK: a row may not have met a visible key yet (m = -inf): (-inf) - (-inf) is NaN
+                const float p = (MASK && sc[qi][t][r] == -INFINITY) ? 0.f : __expf(sc[qi][t][r] - m[qi]);
                 ps += p;
                 sc[qi][t][r] = p * keep[r];
             }
@@ -203,7 +229,7 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
     }
 #endif
 
-template <int HD>
+template <int HD, bool MASK>
 __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
@@ -219,11 +245,12 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     f32x4 o[NQ][NDB];
     float m[NQ], l[NQ];
     unsigned rbase[NQ];
-    int query[NQ];
+    int query[NQ], qidx[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         query[qi] = 16 * (qb0 + qi) + i16;
         const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
+        qidx[qi] = qrow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
 #pragma unroll
@@ -234,7 +261,7 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     const bf16_t* kp = base + a.H + 8 * g;
     const bf16_t* vp = base + 2 * a.H + 8 * g;
 #define FWD_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
-#define FWD_STEP(T, B, R0) fa_fwd_step<HD, T>(a, img, B, R0, qf, o, m, l, rbase, lane)
+#define FWD_STEP(T, B, R0) fa_fwd_step<HD, T, MASK>(a, img, B, R0, qf, o, m, l, rbase, qidx, sq, lane)
     FA_PIPELINE(FWD_LOAD, FWD_STEP)
 #undef FWD_LOAD
 #undef FWD_STEP
@@ -248,7 +275,9 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
             const long long obase = ((long long)sq * a.S + query[qi]) * a.H + h * HD;
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                bf16x4 ov = {f2bf(o[qi][db][0] * inv), f2bf(o[qi][db][1] * inv), f2bf(o[qi][db][2] * inv), f2bf(o[qi][db][3] * inv)};
+                float v[4] = {o[qi][db][0] * inv, o[qi][db][1] * inv, o[qi][db][2] * inv, o[qi][db][3] * inv};
+                if (MASK && a.thr_out) drop4(a.key_out, a.thr_out, (unsigned)(obase + 16 * db + 4 * g), a.oscale, v);   // ndt1.py:292
+                bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 *(bf16x4*)(a.out + obase + 16 * db + 4 * g) = ov;
             }
             if (g == 0) a.L[(long long)unit * a.S + query[qi]] = m[qi] + __logf(lt);
@@ -256,12 +285,14 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     }
 }
 
-template <int HD, bool TAIL>
+template <int HD, bool TAIL, bool MASK>
 __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
                                              const bf16x8 (&df)[NQ][HD / 32], f32x4 (&dq)[NQ][HD / 16], const float (&Li)[NQ], const float (&D)[NQ],
-                                             const unsigned (&rbase)[NQ], int lane) {
+                                             const unsigned (&rbase)[NQ], const int (&qidx)[NQ], int sq, int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
+    unsigned vb = 0u;
+    if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
     f32x4 sc[NQ][2], dp[NQ][2];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi)
@@ -287,6 +318,10 @@ __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const F
             for (int r = 0; r < 4; ++r) {
                 float p = __expf(sc[qi][t][r] * a.scale - Li[qi]);
                 if (TAIL && k0 + 16 * t + 4 * g + r >= a.S) p = 0.f;
+                if constexpr (MASK) {
+                    const int key = k0 + 16 * t + 4 * g + r;
+                    if (!(key == qidx[qi] || (fa_ctx(qidx[qi], key, a.cf, a.cb) && ((vb >> (16 * t + 4 * g + r)) & 1u)))) p = 0.f;
+                }
                 sc[qi][t][r] = p * (dp[qi][t][r] * keep[r] - D[qi]) * a.scale;   // dS, scaled
             }
         }
@@ -302,7 +337,7 @@ __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const F
     asm volatile("" ::: "memory");
 }
 
-template <int HD>
+template <int HD, bool MASK>
 __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
@@ -318,11 +353,12 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     f32x4 dq[NQ][NDB];
     float D[NQ], Li[NQ];
     unsigned rbase[NQ];
-    int query[NQ];
+    int query[NQ], qidx[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         query[qi] = 16 * (qb0 + qi) + i16;
         const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
+        qidx[qi] = qrow;
         const bf16_t* dop = a.dout + ((long long)sq * a.S + qrow) * a.H + h * HD;
         const bf16_t* op = a.out + ((long long)sq * a.S + qrow) * a.H + h * HD;
         float d = 0.f;
@@ -336,6 +372,8 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
         }
         d += __shfl_xor(d, 16, 64);
         d += __shfl_xor(d, 32, 64);
+        // with the output dropout fused into the forward both factors carry keep * scale: dO . O_pre = (dO_masked . O_stored) / scale
+        if (MASK && a.thr_out) d *= 1.0f / a.oscale;
         D[qi] = d;
         Li[qi] = a.L[(long long)unit * a.S + qrow];
 #pragma unroll
@@ -345,7 +383,7 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
     const bf16_t* kp = base + a.H + 8 * g;
     const bf16_t* vp = base + 2 * a.H + 8 * g;
 #define BQ_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
-#define BQ_STEP(T, B, R0) fa_bwdq_step<HD, T>(a, img, B, R0, qf, df, dq, Li, D, rbase, lane)
+#define BQ_STEP(T, B, R0) fa_bwdq_step<HD, T, MASK>(a, img, B, R0, qf, df, dq, Li, D, rbase, qidx, sq, lane)
     FA_PIPELINE(BQ_LOAD, BQ_STEP)
 #undef BQ_LOAD
 #undef BQ_STEP
@@ -362,10 +400,10 @@ __global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
         }
 }
 
-template <int HD, bool TAIL>
+template <int HD, bool TAIL, bool MASK>
 __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[NQ][HD / 32],
                                               const bf16x8 (&vf)[NQ][HD / 32], f32x4 (&dk)[NQ][HD / 16], f32x4 (&dv)[NQ][HD / 16], const float* Lu,
-                                              const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], int lane) {
+                                              const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], const bool (&key_valid)[NQ], int lane) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     f32x4 st[NQ][2], dpt[NQ][2];
@@ -403,6 +441,9 @@ __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char*
                 const int q = q0 + 16 * t + 4 * g + r;
                 float p = __expf(st[ki][t][r] * a.scale - Lq[t][r]);
                 if ((TAIL && q >= a.S) || !key_ok[ki]) p = 0.f;
+                if constexpr (MASK) {
+                    if (!(q == krow[ki] || (fa_ctx(q, krow[ki], a.cf, a.cb) && key_valid[ki]))) p = 0.f;
+                }
                 float keep = 1.f;
                 if (a.thr) {
                     const int qc = (TAIL && q >= a.S) ? a.S - 1 : q;
@@ -428,7 +469,7 @@ __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char*
     asm volatile("" ::: "memory");
 }
 
-template <int HD>
+template <int HD, bool MASK>
 __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
@@ -445,12 +486,13 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     bf16x8 kf[NQ][KS], vf[NQ][KS];
     f32x4 dk[NQ][NDB], dv[NQ][NDB];
     int key[NQ], krow[NQ];
-    bool key_ok[NQ];
+    bool key_ok[NQ], key_valid[NQ];
 #pragma unroll
     for (int ki = 0; ki < NQ; ++ki) {
         key[ki] = 16 * (kb0 + ki) + i16;
         key_ok[ki] = key[ki] < a.S;
         krow[ki] = key_ok[ki] ? key[ki] : a.S - 1;
+        key_valid[ki] = MASK ? a.tmask[(long long)sq * a.S + krow[ki]] != 0 : true;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[ki][ks] = *(const bf16x8*)(base + a.H + (long long)krow[ki] * ld + 32 * ks + 8 * g);
@@ -465,7 +507,7 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     const bf16_t* qp = base + 8 * g;
     const bf16_t* dp_ = dob + 8 * g;
 #define BK_LOAD(B, R0) fa_load<HD>(B, qp, ld, dp_, (long long)a.H, R0, a.S, i16)
-#define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, lane)
+#define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T, MASK>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, key_valid, lane)
     FA_PIPELINE(BK_LOAD, BK_STEP)
 #undef BK_LOAD
 #undef BK_STEP
@@ -484,7 +526,8 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
 }
 
 bool fattn_eligible(int dtype, int S, int H, int nh) {
-    static const bool off = [] { const char* e = getenv("NBCI_FLASH_ATTN"); return e && e[0] == '0'; }();
+    const char* e = getenv("NBCI_FLASH_ATTN");   // (read per call, not cached: tests switch it per model)
+    const bool off = e && e[0] == '0';
     if (off || dtype != NBCI_BF16 || nh <= 0 || H % nh) return false;
     const int hd = H / nh;
     return (hd == 32 || hd == 64 || hd == 96 || hd == 128) && S >= 1 && H % 8 == 0;
@@ -500,21 +543,29 @@ static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32
     return NBCI_OK;
 }
 
-template <int HD>
+template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
-    if (which == 0) hipLaunchKernelGGL((fattn_fwd_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
-    else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD>), g, dim3(256), 4 * FA_IMG, s, a);
-    else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD>), g, dim3(256), 8 * FA_IMG, s, a);
+    if (which == 0) hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
+    else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
+    else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK>), g, dim3(256), 8 * FA_IMG, s, a);
     return check_launch("flash attention");
 }
 
 static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
+    if (a.tmask) {
+        switch (a.H / a.nh) {
+            case 32: return fa_launch<32, true>(which, a, s);
+            case 64: return fa_launch<64, true>(which, a, s);
+            case 96: return fa_launch<96, true>(which, a, s);
+            default: return fa_launch<128, true>(which, a, s);
+        }
+    }
     switch (a.H / a.nh) {
-        case 32: return fa_launch<32>(which, a, s);
-        case 64: return fa_launch<64>(which, a, s);
-        case 96: return fa_launch<96>(which, a, s);
-        default: return fa_launch<128>(which, a, s);
+        case 32: return fa_launch<32, false>(which, a, s);
+        case 64: return fa_launch<64, false>(which, a, s);
+        case 96: return fa_launch<96, false>(which, a, s);
+        default: return fa_launch<128, false>(which, a, s);
     }
 }
 
@@ -533,6 +584,40 @@ int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
     FAArgs a{};
     int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
     if (rc != NBCI_OK) return rc;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.dout = (const bf16_t*)dout; a.L = (float*)L; a.Dsum = Dsum; a.dqkv = (bf16_t*)dqkv;
+    rc = fa_dispatch(1, a, s);
+    if (rc != NBCI_OK) return rc;
+    return fa_dispatch(2, a, s);
+}
+
+// ---- masked variants for NDT1 (any length; the fused one-workgroup kernel of attention.hip covers T' <= 160 at head 128) ----
+static void fa_mask_args(FAArgs& a, const int32_t* tmask, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_out) {
+    a.tmask = tmask; a.cf = cf; a.cb = cb;
+    a.thr_out = drop_threshold(drop_p);
+    a.oscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    a.key_out = drop_key(seed, site_out);
+}
+
+int fattn_masked_fwd_launch(const void* qkv, const int32_t* tmask, void* out, float* L, int NS, int nh, int S, int H, int cf, int cb,
+                            float drop_p, uint32_t seed, uint32_t site_prob, uint32_t site_out, hipStream_t s) {
+    NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh) && tmask, NBCI_ESHAPE, "masked flash attention: bf16, head size 32 / 64 / 96 / 128, token mask");
+    NBCI_REQUIRE((long long)NS * S * H < (1ll << 32), NBCI_ESHAPE, "masked flash attention: output too large for the 32-bit dropout counter");
+    FAArgs a{};
+    int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site_prob);
+    if (rc != NBCI_OK) return rc;
+    fa_mask_args(a, tmask, cf, cb, drop_p, seed, site_out);
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.L = L;
+    return fa_dispatch(0, a, s);
+}
+
+// dout = the gradient of the DROPPED output already multiplied by its keep mask (the caller's out-proj data-gradient GEMM does it)
+int fattn_masked_bwd_launch(const void* qkv, const int32_t* tmask, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv,
+                            int NS, int nh, int S, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_prob, hipStream_t s) {
+    NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh) && tmask, NBCI_ESHAPE, "masked flash attention: bf16, head size 32 / 64 / 96 / 128, token mask");
+    FAArgs a{};
+    int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site_prob);
+    if (rc != NBCI_OK) return rc;
+    fa_mask_args(a, tmask, cf, cb, drop_p, seed, 0);
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.dout = (const bf16_t*)dout; a.L = (float*)L; a.Dsum = Dsum; a.dqkv = (bf16_t*)dqkv;
     rc = fa_dispatch(1, a, s);
     if (rc != NBCI_OK) return rc;

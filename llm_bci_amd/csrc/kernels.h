@@ -145,6 +145,12 @@ int sattn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
 
 // streaming MFMA attention (attn_flash.hip): bf16, head 32 / 64 / 96 / 128, any length, no mask
 bool fattn_eligible(int dtype, int S, int H, int nh);
+// NDT1's masked attention (key validity + context span + self, ndt1.py:30-41,435-437) on the streaming kernels, any length;
+// the output dropout of ndt1.py:292 is fused into the forward's store (site_out)
+int fattn_masked_fwd_launch(const void* qkv, const int32_t* tmask, void* out, float* L, int NS, int nh, int S, int H, int cf, int cb,
+                            float drop_p, uint32_t seed, uint32_t site_prob, uint32_t site_out, hipStream_t s);
+int fattn_masked_bwd_launch(const void* qkv, const int32_t* tmask, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv,
+                            int NS, int nh, int S, int H, int cf, int cb, float drop_p, uint32_t seed, uint32_t site_prob, hipStream_t s);
 int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int NS, int nh, int S, int H,
                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s);

@@ -36,6 +36,7 @@ struct Plan {
     float* d_taps;
     int ntaps;
     bool fused_attn;  // use attention.hip when the shape allows (NBCI_FUSED_ATTN=0 disables)
+    bool flash_attn;  // otherwise the masked streaming kernels of attn_flash.hip (bf16, head 32 / 64 / 96 / 128; NBCI_FLASH_ATTN=0 disables)
     // replicated accumulators for the 1-D parameters' gradients (biases, LayerNorm): compact index space
     std::vector<int> flat_of;               // compact index -> flat gradient offset (-1 = padding)
     std::vector<std::pair<int, int>> cseg;  // compact [begin,end) per segment
@@ -349,6 +350,9 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
             TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H, c.context_forward,
                                 c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
+        } else if (p.flash_attn && fattn_eligible(dt, Tp, H, nh)) {   // longer than the one-workgroup kernel holds (T' > 160), or another head size
+            TRY(fattn_masked_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H,
+                                        c.context_forward, c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
         } else {
             {   // scores = q k^T / sqrt(hd), batched over (b, head)
                 nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd),
@@ -576,6 +580,10 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
                                     nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
+            } else if (p.flash_attn && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
+                TRY(fattn_masked_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, ws + w.dB2, (const float*)(ws + lw.lse),
+                                            (float*)(ws + w.scores), ws + w.dqkv, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
+                                            io->seed, 16 + 4 * l, s));
             } else {
                 {   // dPd = da v^T   (f32, reuses the score buffer)
                     nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + w.dB2, es, 0, H, 1, 0, 0, az1, hd),
@@ -607,7 +615,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                     TRY(gemm_launch_timed(d, s));
                 }
             }
-            const bool fused_bwd = p.fused_attn && attn_fused_eligible(dt, Tp, H, nh);
+            const bool fused_bwd = (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) || (p.flash_attn && fattn_eligible(dt, Tp, H, nh));
             if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
             if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
                 TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
@@ -737,6 +745,8 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
     {
         const char* e = getenv("NBCI_FUSED_ATTN");
         p->fused_attn = !(e && e[0] == '0');
+        const char* e2 = getenv("NBCI_FLASH_ATTN");
+        p->flash_attn = !(e2 && e2[0] == '0');
     }
     if (c.smooth_sd > 0.f) {
         // scipy.signal.gaussian(1 + 6*sd, sd) normalised, built in float64 (ndt1.py:87-88)

@@ -266,7 +266,14 @@ if __name__ == "__main__" and "--factors" in sys.argv:
                                                  "init_range": 0.1}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     sys.exit(0)
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst", "--masker-copy")):
+if __name__ == "__main__" and "--long" in sys.argv:
+    # sequences beyond the one-workgroup attention kernel (T' > 160): 1200 bins -> 293 tokens, ragged, 2 layers x 1024 (head 128)
+    c1 = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
+    run_case("g_long", c1, [1200, 900], [80, 60], 64)
+    c1c = json.loads(json.dumps(c1)); c1c["encoder"]["context"] = {"forward": 5, "backward": 40}
+    run_case("g_long_ctx", c1c, [1200, 900], [80, 60], 64)
+
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst", "--masker-copy", "--long")):
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)

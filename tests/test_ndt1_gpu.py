@@ -80,9 +80,14 @@ def test_tiny_golden_fp32(name):
         np.testing.assert_allclose(gv, ref, atol=5e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
 
 
+LONG = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
+LONG_CTX = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}, "context": {"forward": 5, "backward": 40}}}
+
+
 @pytest.mark.parametrize("name,over", [
     ("g_c1", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}),
     ("g_c2", {}),
+    ("g_long", LONG), ("g_long_ctx", LONG_CTX),       # 1200 bins -> 293 tokens, ragged (make_golden.py --long)
 ])
 def test_c1_c2_golden_fp32(name, over):
     fx = load(name)
@@ -125,6 +130,34 @@ def test_c2_golden_bf16():
     _, _, g = _grads(m, batch, train=True)
     for k, gv in g.items():
         s, a = fx["gsum:" + k]
+        if a > 1e-3:
+            assert abs(np.abs(gv.astype(np.float64)).sum() - a) <= 0.05 * a, (k, np.abs(gv).sum(), a)
+
+
+@pytest.mark.parametrize("name,over", [("g_long", LONG), ("g_long_ctx", LONG_CTX)])
+def test_long_sequence_golden_bf16_streaming_attention(name, over):
+    """293 tokens (> the 160 of the one-workgroup attention kernel): the bf16 path runs the MASKED streaming kernels of
+    attn_flash.hip (key validity + context span + self). Against the reference's fp32 run: log-probs within 0.08, argmax equal
+    wherever the fp32 top-2 margin exceeds 0.1, gradient L1 within 5 %."""
+    fx = load(name)
+    m = _model(_det_over(json.dumps(over)), 41, dtype="bf16").to(DEV)
+    batch = _to_dev(batch_of(fx))
+    m.eval()
+    with torch.no_grad():
+        out = m(**batch)
+    torch.cuda.synchronize()
+    preds = out.preds.cpu().numpy()
+    lens = fx["token_lens"]
+    for b, L in enumerate(lens):                       # frames beyond a sample's tokens never reach the loss (their keys are padding)
+        assert np.abs(preds[b, :L] - fx["eval_preds"][b, :L]).max() < 0.08
+    assert abs(out.loss.item() - float(fx["eval_loss"])) / float(fx["eval_loss"]) < 5e-3
+    am = m.last_argmax.cpu().numpy()
+    safe = fx["margin"] > 0.1
+    for b, L in enumerate(lens):
+        assert np.array_equal(am[b, :L][safe[b, :L]], fx["argmax"][b, :L][safe[b, :L]])
+    _, _, g = _grads(m, batch, train=True)
+    for k, gv in g.items():
+        s_, a = fx["gsum:" + k]
         if a > 1e-3:
             assert abs(np.abs(gv.astype(np.float64)).sum() - a) <= 0.05 * a, (k, np.abs(gv).sum(), a)
 
@@ -311,18 +344,24 @@ def test_checkpoint_roundtrip_and_reference_key_layout(tmp_path):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("T,lens,ctx", [(600, [600, 450], (-2, -2)), (100, [100, 70], (3, 2)), (664, [664, 664], (-2, -2))])
-def test_fused_attention_matches_batched_gemm_path(T, lens, ctx, monkeypatch):
-    """bf16: attention.hip (fused, T' <= 160) vs the batched-GEMM + softmax kernels on the same
-    weights, inputs and dropout streams (train mode, recipe dropout). Both are bf16 pipelines that
-    round at different points, so the bound is bf16-level: 0.03 on log-probs, 3 % of each
-    gradient's max-abs."""
+@pytest.mark.parametrize("T,lens,ctx,which", [
+    (600, [600, 450], (-2, -2), "fused"), (100, [100, 70], (3, 2), "fused"), (664, [664, 664], (-2, -2), "fused"),
+    # the masked streaming kernels (attn_flash.hip): what NDT1 runs beyond 160 tokens, and at shorter lengths when asked to
+    (1200, [1200, 900], (-2, -2), "flash"), (1200, [1200, 731], (5, 40), "flash"), (600, [600, 450], (-2, -2), "flash"),
+    (2048, [2048, 1500, 33], (-1, 64), "flash"), (100, [100, 70], (3, 2), "flash")])
+def test_fused_attention_matches_batched_gemm_path(T, lens, ctx, which, monkeypatch):
+    """bf16: attention.hip (fused, T' <= 160) resp. the masked streaming kernels of attn_flash.hip (any length) vs the
+    batched-GEMM + softmax kernels on the same weights, inputs and dropout streams (train mode, recipe dropout, ragged lengths,
+    context spans). All are bf16 pipelines that round at different points, so the bound is bf16-level: 0.03 on log-probs, 3 % of
+    each gradient's max-abs."""
     over = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2},
                         "context": {"forward": ctx[0], "backward": ctx[1]}}}
-    batch = _to_dev(_rand_batch(2, T, 64, 12, 41, lens, [12, 7]))
+    B = len(lens)
+    batch = _to_dev(_rand_batch(B, T, 64, 12, 41, lens, [12, 7, 3][:B]))
     outs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("NBCI_FUSED_ATTN", fused)
+    for new in (True, False):
+        monkeypatch.setenv("NBCI_FUSED_ATTN", "1" if (new and which == "fused") else "0")
+        monkeypatch.setenv("NBCI_FLASH_ATTN", "1" if (new and which == "flash") else "0")
         m = _model(over, 41, dtype="bf16").to(DEV)
         outs.append(_grads(m, batch, train=True, seed=77))
     (l1, p1, g1), (l0, p0, g0) = outs

@@ -165,6 +165,8 @@ def _regen(over, vocab=41):
 @pytest.mark.parametrize("name,over", [
     ("g_c1", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}),
     ("g_c2", {}),
+    ("g_long", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}),
+    ("g_long_ctx", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}, "context": {"forward": 5, "backward": 40}}}),
 ])
 def test_c1_c2_init_and_oracle(name, over):
     fx = load(name)
