@@ -164,7 +164,7 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
         // the first few steps it rarely does, and the rescale would drag all HD/16 accumulator tiles through the VALU
         if (__builtin_amdgcn_ballot_w64(cm > m[qi]) != 0ull) {
             const float mn = fmaxf(m[qi], cm);
-            const float corr = __expf(m[qi] - mn);
+            const float corr = (m[qi] == mn) ? 1.0f : __expf(m[qi] - mn);   // (MASK: a row that has met no visible key yet keeps m = mn = -inf)
             m[qi] = mn;
             l[qi] *= corr;
 #pragma unroll

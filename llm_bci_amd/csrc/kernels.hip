@@ -818,14 +818,14 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
                                                   const int32_t* __restrict__ in_lens, const int64_t* __restrict__ tgt_lens,
                                                   int Tp, int V, int S, int blank, int zero_inf, float* __restrict__ loss,
                                                   float* __restrict__ ws, TD* __restrict__ dlogits, int ldd,
-                                                  float grad_scale, int Bn) {
+                                                  float grad_scale, int Bn, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Lmax = 2 * S + 1;
     float* rowA = sm;                       // [2][Lmax] alpha double buffer
     float* rowB = sm + 2 * Lmax;            // [2][Lmax] beta double buffer
     int* ext = (int*)(sm + 4 * Lmax);       // [Lmax]
-    float* occ = sm + 5 * Lmax;             // [Tp][V] (gradient pass)
-    float* lpl = occ + Tp * V;              // [Tp][V] staged log-probabilities (STAGED)
+    float* occ = sm + 5 * Lmax;             // [chunk][V] (gradient pass; chunk = Tp when the whole sample fits)
+    float* lpl = occ + chunk * V;           // [Tp][V] staged log-probabilities (STAGED)
     __shared__ float s_nll;
     const int b = blockIdx.x, tid = threadIdx.x;
     int Tb = in_lens[b];
@@ -943,49 +943,57 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     const int tz = finite ? Tb : 0;
     for (long long i = tid + (long long)tz * ldd; i < (long long)Tp * ldd; i += 256) stf<TD>(dlogits, (long long)b * Tp * ldd + i, 0.f);
     if (!finite || Tb == 0) return;
-    // ---- occupancy: occ[t][c] = sum_{s: ext[s] = c} exp(alpha + beta - lp + nll), all (t, s) in parallel
-    for (int i = tid; i < Tb * V; i += 256) occ[i] = 0.f;
-    __syncthreads();   // also makes this block's alpha/beta global writes visible to its own threads
-    // wave w takes frames w, w + 4, ...; lanes run along the states. Four frames' lattice rows are loaded together:
-    // they were just written by this block and come back from L2 (~1 us each if taken one by one).
-    for (int t0 = tid >> 6; t0 < Tb; t0 += 16) {
-        for (int s = tid & 63; s < L; s += 64) {
-            float ab[4];
+    // ---- occupancy: occ[t][c] = sum_{s: ext[s] = c} exp(alpha + beta - lp + nll), all (t, s) in parallel; `chunk` frames per pass
+    // (one pass unless the sample has more frames than fit the LDS: the reference allows up to max_F = 1024 tokens)
+    for (int c0 = 0; c0 < Tb; c0 += chunk) {
+        const int c1 = min(Tb, c0 + chunk);
+        __syncthreads();   // the previous chunk's occ has been read; (first pass) this block's alpha / beta global writes are visible to its threads
+        for (int i = tid; i < (c1 - c0) * V; i += 256) occ[i] = 0.f;
+        __syncthreads();
+        // wave w takes frames c0 + w, + 4, ...; lanes run along the states. Four frames' lattice rows are loaded together:
+        // they were just written by this block and come back from L2 (~1 us each if taken one by one).
+        for (int t0 = c0 + (tid >> 6); t0 < c1; t0 += 16) {
+            for (int s = tid & 63; s < L; s += 64) {
+                float ab[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int t = t0 + 4 * k;
-                ab[k] = t < Tb ? aw[(long long)t * Lmax + s] + bw[(long long)t * Lmax + s] : -INFINITY;
-            }
-            const int e = ext[s];
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + 4 * k;
+                    ab[k] = t < c1 ? aw[(long long)t * Lmax + s] + bw[(long long)t * Lmax + s] : -INFINITY;
+                }
+                const int e = ext[s];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int t = t0 + 4 * k;
-                if (ab[k] > -INFINITY) atomicAdd(&occ[t * V + e], expf(ab[k] - lp[(long long)t * V + e] + nll));
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + 4 * k;
+                    if (ab[k] > -INFINITY) atomicAdd(&occ[(t - c0) * V + e], expf(ab[k] - lp[(long long)t * V + e] + nll));
+                }
             }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < Tb * ldd; i += 256) {
-        const int t = i / ldd, c = i % ldd;
-        const float v = (c < V) ? (expf(lp[(long long)t * V + c]) - occ[t * V + c]) * grad_scale : 0.f;
-        stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
+        __syncthreads();
+        for (int i = tid + c0 * ldd; i < c1 * ldd; i += 256) {
+            const int t = i / ldd, c = i % ldd;
+            const float v = (c < V) ? (expf(lp[(long long)t * V + c]) - occ[(t - c0) * V + c]) * grad_scale : 0.f;
+            stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
+        }
     }
 }
 
 int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int B, int Tp,
                int V, int S, int blank, int zero_infinity, float* loss, float* alpha_ws, void* dlogits, int d_dtype,
                int ldd, float grad_scale, hipStream_t s) {
-    const size_t lds1 = (size_t)(5 * (2 * S + 1) + (size_t)Tp * V) * sizeof(float), lds2 = lds1 + (size_t)Tp * V * sizeof(float);
-    NBCI_REQUIRE(lds1 <= 64000, NBCI_ESHAPE, "ctc: frames x vocab + targets too large for the LDS-resident gradient pass");
+    const size_t fixed = (size_t)5 * (2 * S + 1) * sizeof(float), per_frame = (size_t)V * sizeof(float);
+    NBCI_REQUIRE(fixed + 16 * per_frame <= 64000, NBCI_ESHAPE, "ctc: targets x vocab too large for the LDS-resident lattice rows");
     NBCI_REQUIRE(blank >= 0 && blank < V, NBCI_EINVAL, "ctc: blank id out of range");
+    const size_t lds1 = fixed + (size_t)Tp * per_frame, lds2 = lds1 + (size_t)Tp * per_frame;
     if (lds2 <= 64000) {   // room to stage the log-probabilities as well
         DISPATCH_DTYPE(d_dtype, TD,
                        hipLaunchKernelGGL((ctc_kernel<TD, true>), dim3(B), dim3(256), lds2, s, preds, targets, in_lens, tgt_lens, Tp, V,
-                                          S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale, B));
-    } else {
+                                          S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale, B, Tp));
+    } else {   // occupancy pass in chunks of frames (multiples of 16: the waves' frame stride) that fit 64 KB
+        int chunk = Tp;
+        if (lds1 > 64000) chunk = (int)((64000 - fixed) / per_frame) / 16 * 16;
         DISPATCH_DTYPE(d_dtype, TD,
-                       hipLaunchKernelGGL((ctc_kernel<TD, false>), dim3(B), dim3(256), lds1, s, preds, targets, in_lens, tgt_lens, Tp, V,
-                                          S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale, B));
+                       hipLaunchKernelGGL((ctc_kernel<TD, false>), dim3(B), dim3(256), fixed + (size_t)chunk * per_frame, s, preds, targets, in_lens,
+                                          tgt_lens, Tp, V, S, blank, zero_infinity, loss, alpha_ws, (TD*)dlogits, ldd, grad_scale, B, chunk));
     }
     return check_launch("ctc");
 }

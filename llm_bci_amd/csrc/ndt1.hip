@@ -37,6 +37,7 @@ struct Plan {
     int ntaps;
     bool fused_attn;  // use attention.hip when the shape allows (NBCI_FUSED_ATTN=0 disables)
     bool flash_attn;  // otherwise the masked streaming kernels of attn_flash.hip (bf16, head 32 / 64 / 96 / 128; NBCI_FLASH_ATTN=0 disables)
+    int flash_min;    // ... from this many tokens on (NBCI_FLASH_MIN_TOKENS): below it the batched-GEMM + softmax path is as fast (measured)
     // replicated accumulators for the 1-D parameters' gradients (biases, LayerNorm): compact index space
     std::vector<int> flat_of;               // compact index -> flat gradient offset (-1 = padding)
     std::vector<std::pair<int, int>> cseg;  // compact [begin,end) per segment
@@ -350,7 +351,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
             TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H, c.context_forward,
                                 c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
-        } else if (p.flash_attn && fattn_eligible(dt, Tp, H, nh)) {   // longer than the one-workgroup kernel holds (T' > 160), or another head size
+        } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // longer than the one-workgroup kernel holds (T' > 160), or another head size
             TRY(fattn_masked_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H,
                                         c.context_forward, c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
         } else {
@@ -580,7 +581,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
                                     nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
-            } else if (p.flash_attn && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
+            } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
                 TRY(fattn_masked_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, ws + w.dB2, (const float*)(ws + lw.lse),
                                             (float*)(ws + w.scores), ws + w.dqkv, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                             io->seed, 16 + 4 * l, s));
@@ -615,7 +616,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                     TRY(gemm_launch_timed(d, s));
                 }
             }
-            const bool fused_bwd = (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) || (p.flash_attn && fattn_eligible(dt, Tp, H, nh));
+            const bool fused_bwd = (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) || (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh));
             if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
             if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
                 TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
@@ -747,6 +748,8 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
         p->fused_attn = !(e && e[0] == '0');
         const char* e2 = getenv("NBCI_FLASH_ATTN");
         p->flash_attn = !(e2 && e2[0] == '0');
+        const char* e3 = getenv("NBCI_FLASH_MIN_TOKENS");
+        p->flash_min = e3 ? atoi(e3) : 1;
     }
     if (c.smooth_sd > 0.f) {
         // scipy.signal.gaussian(1 + 6*sd, sd) normalised, built in float64 (ndt1.py:87-88)

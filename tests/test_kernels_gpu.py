@@ -56,6 +56,33 @@ def test_ctc_cases(nm):
     assert torch.all(dl[:, :, V:] == 0)
 
 
+@pytest.mark.parametrize("T,S,lens,tls", [(600, 100, [600, 377, 16], [100, 40, 9]), (1024, 150, [1024, 1000], [150, 120])])
+def test_ctc_long_sequences_chunked_gradient_pass(T, S, lens, tls):
+    """up to the reference's max_F = 1024 tokens (configs/ndt1.yaml:39): frames x vocab no longer fits the LDS of the gradient pass,
+    which then runs in chunks of frames; against the numpy oracle (itself pinned to torch.nn.CTCLoss by ctc_cases.npz)."""
+    from oracle.ctc import ctc_loss_and_grad
+    l, check = _l()
+    g = np.random.default_rng(8)
+    B, V = len(lens), 41
+    lp = torch.log_softmax(torch.from_numpy(g.standard_normal((B, T, V)).astype(np.float32)), -1).numpy()
+    tg = g.integers(1, V, (B, S)).astype(np.int64)
+    il, tl = np.array(lens, np.int32), np.array(tls, np.int64)
+    ref_loss, ref_grad = ctc_loss_and_grad(lp, tg, il.astype(np.int64), tl, blank=0, zero_infinity=True)
+    loss = torch.zeros(B, device=DEV)
+    ws = torch.zeros(int(l.nbci_ctc_workspace_floats(B, T, S)), device=DEV)
+    ldd = (V + 7) // 8 * 8
+    dl = torch.full((B, T, ldd), 7.0, device=DEV)
+    lpd, tgd, ild, tld = d(lp), d(tg), d(il), d(tl)
+    check(l.nbci_ctc(vp(lpd), vp(tgd), vp(ild), vp(tld), B, T, V, S, 0, 1, vp(loss), vp(ws), vp(dl), 0, ldd, C.c_float(1.0), st()), "nbci_ctc")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=2e-5, atol=1e-4)
+    # alpha + beta - lp + nll cancels numbers of magnitude nll ~ 2 000 - 3 800 down to O(1) in f32 (1.2e-4 - 2.4e-4 per ulp there):
+    # the posteriors carry a relative error of ~1e-3 at these lengths whatever the kernel does (a chunk-boundary slip would be O(1))
+    err = np.abs(dl[:, :, :V].cpu().numpy() - ref_grad)
+    assert err.max() < 4e-3 and err.mean() < 5e-5, (err.max(), err.mean())
+    assert torch.all(dl[:, :, V:] == 0)
+
+
 def test_adamw_matches_oracle_and_refreshes_bf16_shadow():
     l, check = _l()
     g0 = np.random.default_rng(0)
