@@ -192,6 +192,16 @@ int nbci_coupler_splice_bwd(const void* d_out, void* d_text, void* d_spikes, int
  * arrives from the LLM's autograd through the splice backward). */
 int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t N, float* out, nbci_stream_t stream);
 
+/* MX-scaled fp8 (OCP e4m3) projection, BASELINE configs[4] "fp8 MFMA QKV": replaces the q / k / v nn.Linear of the HF PatchTST
+ * attention the reference's encoder runs (models/patchtst.py:176,223-225) in the forward pass.
+ * nbci_mx_quantize: rows x K values (f32 or bf16, row stride ldx; K % 32 == 0) -> e4m3 codes (rows x K bytes) + one E8M0 scale byte
+ * per 32 consecutive k (rows x K/32 bytes): X = 2^(floor(log2 amax) - 8), codes = RNE(v / X) saturated at +-448.
+ * nbci_gemm_fp8: C[M][N] (c_dtype, row stride ldc) = dequant(A8, sA) . dequant(W8, sW)^T + bias on v_mfma_scale_f32_16x16x128_f8f6f4
+ * (f32 accumulate; K % 128 == 0; operands 16-byte aligned). */
+int nbci_mx_quantize(const void* x, int32_t dtype, int64_t ldx, void* codes, void* scales, int64_t rows, int32_t K, nbci_stream_t stream);
+int nbci_gemm_fp8(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int32_t c_dtype, int64_t M, int32_t N,
+                  int32_t K, int64_t ldc, nbci_stream_t stream);
+
 /* nn.LogSoftmax(-1) of the decoder (ndt1.py:499) + argmax path (main.py:69) */
 int nbci_logsoftmax(const float* logits, int32_t ldl, float* preds, int32_t* argmax, int32_t M, int32_t V,
                     nbci_stream_t stream);
@@ -452,6 +462,8 @@ typedef struct nbci_ptst_config { /* configs/patchtst.yaml, flattened */
     int32_t mlp_decoder, dec_act;
     int32_t loss;                      /* NBCI_LOSS_* (mlm) */
     int32_t dtype;
+    int32_t fp8_qkv;                   /* 1: the q / k / v projections of the FORWARD run on the block-scaled fp8 matrix instruction
+                                          (MX e4m3, see nbci_gemm_fp8); needs dtype = NBCI_BF16 and d_model % 128 == 0 */
 } nbci_ptst_config;
 
 typedef struct nbci_ptst_io {

@@ -100,7 +100,7 @@ class PtstConfig(C.Structure):
         (n, C.c_float) for n in ("norm_eps", "attention_dropout", "positional_dropout", "path_dropout", "ff_dropout")] + [
         ("act", C.c_int32), ("do_mask_input", C.c_int32), ("random_mask_ratio", C.c_double), ("channel_consistent_masking", C.c_int32),
         ("mask_value", C.c_float), ("method", C.c_int32), ("vocab", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32),
-        ("mlp_decoder", C.c_int32), ("dec_act", C.c_int32), ("loss", C.c_int32), ("dtype", C.c_int32)]
+        ("mlp_decoder", C.c_int32), ("dec_act", C.c_int32), ("loss", C.c_int32), ("dtype", C.c_int32), ("fp8_qkv", C.c_int32)]
 
 
 class PtstIO(C.Structure):
@@ -183,6 +183,8 @@ _SIGNATURES = {
     "nbci_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nbci_profile_enable": (C.c_int, [C.c_int32]),
     "nbci_debug_gemm_pc": (C.c_int, [C.c_int32]),
+    "nbci_mx_quantize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "nbci_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "nbci_comm_unique_id": (C.c_int, [C.c_void_p]),
     "nbci_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "nbci_comm_destroy": (None, [C.c_void_p]),

@@ -93,6 +93,13 @@ int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t
     if (!in || !out || M <= 0 || N <= 0 || ld < N) return nbci::fail(NBCI_EINVAL, "colsum: bad arguments");
     return nbci::colsum_launch(in, in_dtype, ld, M, N, out, (hipStream_t)stream);
 }
+int nbci_mx_quantize(const void* x, int32_t dtype, int64_t ldx, void* codes, void* scales, int64_t rows, int32_t K, nbci_stream_t stream) {
+    return nbci::mx_quantize_launch(x, dtype, ldx, codes, scales, rows, K, (hipStream_t)stream);
+}
+int nbci_gemm_fp8(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int32_t c_dtype, int64_t M, int32_t N,
+                  int32_t K, int64_t ldc, nbci_stream_t stream) {
+    return nbci::gemm_fp8_launch(A8, sA, W8, sW, bias, C, c_dtype, M, N, K, ldc, (hipStream_t)stream);
+}
 int nbci_debug_gemm_pc(int32_t mode) { nbci::gemm_pc_set_mode(mode); return NBCI_OK; }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {

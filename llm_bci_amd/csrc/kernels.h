@@ -125,7 +125,7 @@ int ptst_embed_launch(const float* xm, const float* W, const float* bias, const 
                       float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 size_t bn_partial_floats(long long M, int D);
 int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
-                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s);
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8 = nullptr, void* q8_scales = nullptr);
 int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
                          float* partials, float* sums, long long M, int D, int train, hipStream_t s);
 int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s);
@@ -144,6 +144,10 @@ int sattn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
                      int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 
 // streaming MFMA attention (attn_flash.hip): bf16, head 32 / 64 / 96 / 128, any length, no mask
+// fp8.hip: MX-scaled e4m3 (OCP) quantisation and the block-scaled-MFMA projection GEMM
+int mx_quantize_launch(const void* x, int dtype, long long ldx, void* q, void* scales, long long rows, int K, hipStream_t s);
+int gemm_fp8_launch(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int c_dtype, long long M, int N, int K,
+                    long long ldc, hipStream_t s);
 bool fattn_eligible(int dtype, int S, int H, int nh);
 // NDT1's masked attention (key validity + context span + self, ndt1.py:30-41,435-437) on the streaming kernels, any length;
 // the output dropout of ndt1.py:292 is fused into the forward's store (site_out)

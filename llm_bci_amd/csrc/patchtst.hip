@@ -120,6 +120,7 @@ struct PtWS {
     std::vector<PtLayerWS> L;
     size_t x_last, pooled, d1, logits, alpha, dlogits, argmax, tlens, pred, dpred, scores, bnpart, bnsums;
     size_t dx, dtmp, cA, cA2, dU, dAtt, dqkv, dS, dpool, dsum, rep;
+    size_t y1q, y1s, wq8, wq8s;   // fp8_qkv: MX e4m3 copy of the BatchNorm output (M x D bytes + M x D/32 scale bytes), quantised q/k/v weights
     size_t bytes;
     long long M;
     int Mh, ldS, ldP, vpad, ldp;
@@ -191,6 +192,11 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.dS = bump(cur, nP * es);
     w.dpool = bump(cur, Mh * D * 4);
     w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
+    if (c.fp8_qkv) {
+        NBCI_REQUIRE(c.dtype == NBCI_BF16 && D % 128 == 0, NBCI_ESHAPE, "patchtst: fp8_qkv needs the bf16 path and d_model in multiples of 128");
+        w.y1q = bump(cur, M * D); w.y1s = bump(cur, M * D / 32);
+        w.wq8 = bump(cur, 3 * D * D); w.wq8s = bump(cur, 3 * D * D / 32);
+    }
     w.bytes = (cur + 255) / 256 * 256;
     return NBCI_OK;
 }
@@ -264,8 +270,12 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
         float* x_mid = (float*)(ws + lw.x_mid);
         float* x_out = (float*)(ws + (l + 1 < L ? w.L[l + 1].x_in : w.x_last));
         TRY(batchnorm_fwd_launch(x_in, params + lo.n1w, params + lo.n1b, aux.rm1(l), aux.rv1(l), train, c.norm_eps, ws + lw.y1, dt,
-                                 (float*)(ws + lw.mean1), (float*)(ws + lw.rstd1), (float*)(ws + w.bnpart), M, D, s));
-        {
+                                 (float*)(ws + lw.mean1), (float*)(ws + lw.rstd1), (float*)(ws + w.bnpart), M, D, s,
+                                 c.fp8_qkv ? ws + w.y1q : nullptr, c.fp8_qkv ? ws + w.y1s : nullptr));
+        if (c.fp8_qkv) {   // q / k / v on the block-scaled fp8 matrix instruction (fp8.hip); y1 stays in bf16 for the weight gradient
+            TRY(mx_quantize_launch(params + lo.qw, NBCI_F32, D, ws + w.wq8, ws + w.wq8s, 3 * D, D, s));   // from the f32 master weights
+            TRY(gemm_fp8_launch(ws + w.y1q, ws + w.y1s, ws + w.wq8, ws + w.wq8s, params + lo.qb, ws + lw.qkv, dt, M, 3 * D, D, 3 * D, s));
+        } else {
             nbci_gemm_desc d = gd(Mi, 3 * D, D, dt, op(ws + lw.y1, es, 0, D, 1), op(W(lo.qw), es, 0, D, 1), ws + lw.qkv, 3 * D, dt);
             d.bias = params + lo.qb;
             TRY(gemm_launch_timed(d, s));

@@ -192,10 +192,43 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     stq<TO>(y, i * 4 + 3, (v.w - mu.w) * rs.w * ww.w + bb.w);
 }
 
+// bn_apply + MX fp8 copy of the result (fp8.hip): 8 consecutive threads hold one 32-element block of a row (D % 32 == 0)
+template <typename TO>
+__global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ w, const float* __restrict__ b, TO* __restrict__ y,
+                                                         uint8_t* __restrict__ q, uint8_t* __restrict__ sc, long long n4, int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        const int c = (int)((i * 4) % D);
+        const float4 v = *(const float4*)(x + i * 4);
+        const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c), ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
+        o[0] = (v.x - mu.x) * rs.x * ww.x + bb.x; o[1] = (v.y - mu.y) * rs.y * ww.y + bb.y;
+        o[2] = (v.z - mu.z) * rs.z * ww.z + bb.z; o[3] = (v.w - mu.w) * rs.w * ww.w + bb.w;
+        stq<TO>(y, i * 4 + 0, o[0]); stq<TO>(y, i * 4 + 1, o[1]); stq<TO>(y, i * 4 + 2, o[2]); stq<TO>(y, i * 4 + 3, o[3]);
+    }
+    float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    if (i >= n4) return;
+    const unsigned bits = __float_as_uint(amax);
+    const int ex = (int)((bits >> 23) & 0xFF);
+    int E = ex - 127 - 8;
+    if (E < -127) E = -127;
+    if (amax * __uint_as_float((unsigned)(127 - E) << 23) > 448.f && E < 127) ++E;   // (fp8.hip mx_scale_byte: nothing saturates)
+    const unsigned sb = ex == 0 ? 0u : (unsigned)(E + 127);
+    const float inv = __uint_as_float((unsigned)(254 - (int)sb) << 23);
+    float a0 = fminf(fmaxf(o[0] * inv, -448.f), 448.f), a1 = fminf(fmaxf(o[1] * inv, -448.f), 448.f);
+    float a2 = fminf(fmaxf(o[2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(o[3] * inv, -448.f), 448.f);
+    const unsigned lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false) & 0xFFFFu;
+    const unsigned hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, 0, false) & 0xFFFFu;
+    *(unsigned*)(q + i * 4) = lo | (hi << 16);
+    if ((i & 7) == 0) sc[i >> 3] = (uint8_t)sb;     // element index 4 i -> block (4 i) / 32
+}
+
 size_t bn_partial_floats(long long M, int D) { return (size_t)((M + BN_ROWS - 1) / BN_ROWS) * 2 * D; }
 
 int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
-                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s) {
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8, void* q8_scales) {
     NBCI_REQUIRE(D % 4 == 0, NBCI_ESHAPE, "batchnorm: features must be a multiple of 4");
     const int nchunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
     if (train) {
@@ -208,6 +241,12 @@ int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* 
     if (rc != NBCI_OK) return rc;
     const long long n4 = M * D / 4;
     dim3 g((unsigned)((n4 + 255) / 256));
+    if (q8) {   // also the MX fp8 copy the block-scaled QKV GEMM reads (blocks of 32 along the feature axis)
+        NBCI_REQUIRE(D % 32 == 0 && q8_scales, NBCI_ESHAPE, "batchnorm: the fp8 copy needs features in multiples of 32");
+        if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_q_kernel<bf16_t>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
+        else hipLaunchKernelGGL((bn_apply_q_kernel<float>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
+        return check_launch("bn_apply_q");
+    }
     if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, n4, D);
     else hipLaunchKernelGGL((bn_apply_kernel<float>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, n4, D);
     return check_launch("bn_apply");

@@ -91,7 +91,8 @@ class _PtstFunction(torch.autograd.Function):
 
 class PatchTSTForSpikingActivity(FlatParamModule):
     """kwargs: method_name ("ctc": vocab_size, blank_id, zero_infinity | "mlm": loss, log_input) (patchtst.py:190-208);
-    extra: compute_dtype ("bf16" | "fp32", default bf16)."""
+    extra: compute_dtype ("bf16" | "fp32" | "fp8", default bf16). "fp8" = the bf16 path with the q / k / v projections of the forward
+    pass on the block-scaled fp8 matrix instruction (MX e4m3 activations quantised by the BatchNorm pass; d_model % 128 == 0)."""
 
     def __init__(self, config, **kwargs):
         super().__init__()
@@ -128,7 +129,8 @@ class PatchTSTForSpikingActivity(FlatParamModule):
             if self.loss_name not in ("poisson_nll", "mse"):
                 raise Exception(f"Loss {self.loss_name} not implemented yet for mlm")
         dtype_name = kwargs.get("compute_dtype", "bf16")
-        self.compute_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[dtype_name]
+        self.compute_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32, "fp8": NBCI_BF16}[dtype_name]
+        self.fp8_qkv = dtype_name == "fp8"
         c = PtstConfig()
         c.num_input_channels, c.context_length = enc.num_input_channels, enc.context_length
         c.patch_length, c.patch_stride = enc.patch_length, enc.patch_stride
@@ -148,6 +150,7 @@ class PatchTSTForSpikingActivity(FlatParamModule):
         c.mlp_decoder, c.dec_act = (1 if dec.get("mlp_decoder", False) else 0), ACT[dec.get("mlp_activation", "gelu")]
         c.loss = LOSS_KIND[(self.loss_name, self.log_input)] if self.method == "mlm" else 0
         c.dtype = self.compute_dtype
+        c.fp8_qkv = 1 if self.fp8_qkv else 0
         self._ccfg = c
         self.config = config
         T, pl, st = c.context_length, c.patch_length, c.patch_stride

@@ -151,9 +151,12 @@ def forward(cfg, p, bufs, batch, mask=None, train=False, seed=0, dtype=np.float3
         n1 = lp + "norm_sublayer1.batchnorm."
         y1, lc["bn1"], (new_bufs[n1 + "running_mean"], new_bufs[n1 + "running_var"]) = bn_fwd(
             h, P_[n1 + "weight"], P_[n1 + "bias"], np.asarray(bufs[n1 + "running_mean"], f), np.asarray(bufs[n1 + "running_var"], f), train, cfg["norm_eps"])
-        q = heads(y1 @ P_[lp + "self_attn.q_proj.weight"].T + P_[lp + "self_attn.q_proj.bias"])
-        k = heads(y1 @ P_[lp + "self_attn.k_proj.weight"].T + P_[lp + "self_attn.k_proj.bias"])
-        v = heads(y1 @ P_[lp + "self_attn.v_proj.weight"].T + P_[lp + "self_attn.v_proj.bias"])
+        if cfg.get("fp8_qkv"):   # the HIP path's MX e4m3 projections (oracle/fp8.py): FORWARD values only, the backward is straight-through
+            from .fp8 import linear_fp8
+            lin = lambda nm: linear_fp8(y1, P_[lp + f"self_attn.{nm}.weight"], P_[lp + f"self_attn.{nm}.bias"]).astype(y1.dtype)
+        else:
+            lin = lambda nm: y1 @ P_[lp + f"self_attn.{nm}.weight"].T + P_[lp + f"self_attn.{nm}.bias"]
+        q, k, v = heads(lin("q_proj")), heads(lin("k_proj")), heads(lin("v_proj"))
         s = (q @ k.transpose(0, 1, 3, 2)) * scale
         s = s - s.max(-1, keepdims=True)
         e = np.exp(s)

@@ -250,3 +250,22 @@ def test_bci_joint_flat_layout_on_cpu():
     m._after_optimizer_step()
     assert torch.equal(p.detach(), m._flat[off:off + p.numel()].view(p.shape).to(torch.float16))
     assert m._flat_lp.dtype == torch.bfloat16 and m.ndt1._flat_lp.data_ptr() == m._flat_lp.data_ptr()
+
+
+def test_fp8_oracle_rounding_is_ocp_e4m3():
+    """oracle/fp8.py against torch's float8_e4m3fn (the OCP format gfx950 implements): values and codes, incl. subnormals and saturation"""
+    import torch
+    from oracle import fp8 as OF
+    g = np.random.default_rng(0)
+    v = np.concatenate([g.standard_normal(50000).astype(np.float32) * 40, g.standard_normal(20000).astype(np.float32) * 0.01,
+                        np.array([0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 464.0, 1000.0], np.float32)])
+    t = torch.from_numpy(np.clip(v, -448, 448)).to(torch.float8_e4m3fn)
+    assert np.array_equal(OF.e4m3_round(v), t.float().numpy())
+    assert np.array_equal(OF.e4m3_encode(OF.e4m3_round(v)) & 0x7F, t.view(torch.uint8).numpy() & 0x7F)
+    x = g.standard_normal((7, 96)).astype(np.float32)
+    d, codes, sb = OF.mx_quantize(x)
+    amax = np.abs(x.reshape(7, 3, 32)).max(-1)
+    E = sb.astype(np.int64) - 127
+    base = np.floor(np.log2(amax)).astype(np.int64) - 8
+    assert ((E == base) | (E == base + 1)).all() and (amax / np.exp2(E) <= 448.0).all() and (amax / np.exp2(E) > 224.0).all()
+    assert (np.abs(d - x) <= 2.0 ** -4 * np.abs(x) + 2.0 ** -9 * np.exp2(E).repeat(32, -1).reshape(x.shape) + 1e-12).all()   # 3 mantissa bits, no saturation
