@@ -12,9 +12,13 @@
 //     so the GEMM reads 1 byte per element instead of 2 and no extra pass over the activations exists;
 //   * weights: quantised per forward by mx_quantize_launch (768 x 256 elements: nothing).
 // The backward pass keeps bf16 operands (straight-through: gradients are those of the unquantised projection).
-// Fragment layout (verified with exact integer data, tools/probe_mfma_scale_fp8.hip): any assignment of the 128 k of a step to
-// (lane >> 4, byte j) works as long as A and B use the same one; the natural k = 32 (lane >> 4) + j makes a lane's 32 bytes one
-// contiguous MX block. With the B fragment FIRST the result lane (i16, g) owns row m = i16, columns n = 4g .. 4g + 3.
+// Fragment layout, measured (tools/probe_mfma_scale_fp8.hip: exact integer data; tools/probe_mfma_scale_lanes.hip: which lane's scale
+// multiplies which bytes): lane (i16 = lane & 15, g = lane >> 4) supplies row i16 and, of the 128 k of a step, bytes 0..15 =
+// k 16g .. 16g+15 and bytes 16..31 = k 64+16g .. 64+16g+15; the E8M0 byte in lane (i16, t) is applied to k-block t (k 32t .. 32t+31)
+// of row i16 - so a lane's own 32 bytes belong to TWO blocks (g >> 1 and 2 + (g >> 1)), scaled by the bytes lanes (i16, g >> 1) and
+// (i16, 2 + (g >> 1)) carry. With uniform scales any consistent k assignment gives the right sums (which is why a data-only probe
+// cannot see this); with per-block scales only this one does. With the B fragment FIRST the result lane (i16, g) owns row m = i16,
+// columns n = 4g .. 4g + 3.
 #include "kernels.h"
 
 namespace nbci {
@@ -88,7 +92,8 @@ int mx_quantize_launch(const void* x, int dtype, long long ldx, void* q, void* s
 }
 
 // C[M][N] (bf16 or f32) = dequant(A8, sA)[M][K] . dequant(W8, sW)[N][K]^T + bias.  128 x 128 tile, 4 waves of 64 x 64; K % 128 == 0.
-// Fragments come straight from global memory: a wave-instruction reads 16 rows x 128 contiguous bytes (whole lines); with K = 256
+// Fragments come straight from global memory: a wave's two load instructions per operand read the two 64-byte halves of 16 rows' 128-byte
+// lines back to back; the scale byte of lane (i16, g) is block 4 ks + g of its row. With K = 256
 // there are two k-steps, nothing to pipeline, and the launch is bound by the C stores (N = 768 columns of bf16 per 256 bytes of A).
 template <typename TC>
 __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ sA, const uint8_t* __restrict__ W,
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
         int sa[4], sb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint4* pa = (const uint4*)(A + arow[i] * K + 128 * ks + 32 * g);
-            const uint4 a0 = pa[0], a1 = pa[1];
+            const uint4* pa = (const uint4*)(A + arow[i] * K + 128 * ks + 16 * g);   // k 16g .. +15 and 64 + 16g .. +15 of this step
+            const uint4 a0 = pa[0], a1 = pa[4];
             af[i] = (v8i){(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
             sa[i] = sA[arow[i] * nb + 4 * ks + g];
-            const uint4* pb = (const uint4*)(W + (long long)brow[i] * K + 128 * ks + 32 * g);
-            const uint4 b0 = pb[0], b1 = pb[1];
+            const uint4* pb = (const uint4*)(W + (long long)brow[i] * K + 128 * ks + 16 * g);
+            const uint4 b0 = pb[0], b1 = pb[4];
             bf[i] = (v8i){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
             sb[i] = sW[(long long)brow[i] * nb + 4 * ks + g];
         }

@@ -21,7 +21,7 @@ def e4m3_round(v):
     step = np.exp2(e - 3.0)
     q = np.rint(a / step) * step                              # np.rint = round half to even
     q = np.minimum(q, 448.0)
-    return (np.sign(v) * q).astype(np.float32)
+    return np.copysign(q, v).astype(np.float32)               # (keeps the sign of a zero, as the hardware conversion does)
 
 
 def e4m3_encode(v):
