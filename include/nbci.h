@@ -197,7 +197,7 @@ int nbci_colsum(const void* in, int32_t in_dtype, int64_t ld, int32_t M, int32_t
  * nbci_mx_quantize: rows x K values (f32 or bf16, row stride ldx; K % 32 == 0) -> e4m3 codes (rows x K bytes) + one E8M0 scale byte
  * per 32 consecutive k (rows x K/32 bytes): X = 2^(floor(log2 amax) - 8), codes = RNE(v / X) saturated at +-448.
  * nbci_gemm_fp8: C[M][N] (c_dtype, row stride ldc) = dequant(A8, sA) . dequant(W8, sW)^T + bias on v_mfma_scale_f32_16x16x128_f8f6f4
- * (f32 accumulate; K % 128 == 0; operands 16-byte aligned). */
+ * (f32 accumulate; K = 128, 256, 384 or 512; operands 16-byte aligned). */
 int nbci_mx_quantize(const void* x, int32_t dtype, int64_t ldx, void* codes, void* scales, int64_t rows, int32_t K, nbci_stream_t stream);
 int nbci_gemm_fp8(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int32_t c_dtype, int64_t M, int32_t N,
                   int32_t K, int64_t ldc, nbci_stream_t stream);

@@ -91,91 +91,124 @@ int mx_quantize_launch(const void* x, int dtype, long long ldx, void* q, void* s
     return check_launch("mx_quantize");
 }
 
-// C[M][N] (bf16 or f32) = dequant(A8, sA)[M][K] . dequant(W8, sW)[N][K]^T + bias.  128 x 128 tile, 4 waves of 64 x 64; K % 128 == 0.
-// Fragments come straight from global memory: a wave's two load instructions per operand read the two 64-byte halves of 16 rows' 128-byte
-// lines back to back; the scale byte of lane (i16, g) is block 4 ks + g of its row. With K = 256
-// there are two k-steps, nothing to pipeline, and the launch is bound by the C stores (N = 768 columns of bf16 per 256 bytes of A).
-template <typename TC>
+// C[M][N] (bf16 or f32) = dequant(A8, sA)[M][K] . dequant(W8, sW)[N][K]^T + bias.  K = 128 NK (NK <= 4), f32 accumulate.
+// One workgroup = 128 rows x ALL N columns: the A fragments of its rows (NK x 4 x 32 bytes per lane) are loaded ONCE into registers
+// and stay there while the workgroup walks the column tiles (the projection weights, 768 x 256 bytes, come back from L2 every time:
+// they are tiny); 4 waves = 2 x 2 wave tiles of 64 x 64 per column tile of 128. Fragments come straight from global memory: a
+// wave's two load instructions per operand read the two 64-byte halves of 16 rows' 128-byte lines back to back; the scale byte of
+// lane (i16, g) is block 4 ks + g of its row. The launch is bound by the C stores (N = 768 bf16 columns per 256 bytes of A): each
+// wave tile goes through a padded LDS image once so that every store instruction writes whole 128-byte (bf16) rows.
+constexpr int F8_LDT = 72;   // floats per LDS row of a wave's 64 x 64 f32 image (64 + 8: the 16 rows of a fragment spread over the banks)
+
+template <typename TC, int NK>
 __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ sA, const uint8_t* __restrict__ W,
                                                        const uint8_t* __restrict__ sW, const float* __restrict__ bias, TC* __restrict__ C,
-                                                       long long M, int N, int K, long long ldc, int tiles_n) {
+                                                       long long M, int N, long long ldc) {
+    __shared__ __attribute__((aligned(16))) float simg[4 * 64 * F8_LDT];
+    constexpr int K = 128 * NK, nb = 4 * NK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const long long tm = blockIdx.x / tiles_n;
-    const int tn = blockIdx.x % tiles_n;
-    const long long m0 = tm * 128 + wm * 64;
-    const int n0 = tn * 128 + wn * 64;
-    const int nb = K / 32;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long arow[4];
-    int brow[4];
+    const long long m0 = (long long)blockIdx.x * 128 + wm * 64;
+    float* img = simg + w * 64 * F8_LDT;
+    v8i af[NK][4];
+    int sa[NK][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         long long r = m0 + 16 * i + i16;
-        arow[i] = r < M ? r : M - 1;                      // clamped rows only feed outputs that are never stored
-        int n = n0 + 16 * i + i16;
-        brow[i] = n < N ? n : N - 1;
-    }
-    for (int ks = 0; ks < K / 128; ++ks) {
-        v8i af[4], bf[4];
-        int sa[4], sb[4];
+        if (r > M - 1) r = M - 1;                        // clamped rows only feed outputs that are never stored
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4* pa = (const uint4*)(A + arow[i] * K + 128 * ks + 16 * g);   // k 16g .. +15 and 64 + 16g .. +15 of this step
+        for (int ks = 0; ks < NK; ++ks) {
+            const uint4* pa = (const uint4*)(A + r * K + 128 * ks + 16 * g);   // k 16g .. +15 and 64 + 16g .. +15 of this step
             const uint4 a0 = pa[0], a1 = pa[4];
-            af[i] = (v8i){(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-            sa[i] = sA[arow[i] * nb + 4 * ks + g];
-            const uint4* pb = (const uint4*)(W + (long long)brow[i] * K + 128 * ks + 16 * g);
-            const uint4 b0 = pb[0], b1 = pb[4];
-            bf[i] = (v8i){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-            sb[i] = sW[(long long)brow[i] * nb + 4 * ks + g];
+            af[ks][i] = (v8i){(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+            sa[ks][i] = sA[r * nb + 4 * ks + g];
         }
+    }
+    const int tiles_n = (N + 127) / 128;
+    for (int tn = 0; tn < tiles_n; ++tn) {
+        const int n0 = tn * 128 + wn * 64;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            v8i bf[4];
+            int sb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int n = n0 + 16 * i + i16;
+                if (n > N - 1) n = N - 1;
+                const uint4* pb = (const uint4*)(W + (long long)n * K + 128 * ks + 16 * g);
+                const uint4 b0 = pb[0], b1 = pb[4];
+                bf[i] = (v8i){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+                sb[i] = sW[(long long)n * nb + 4 * ks + g];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)   // B fragment first: lane (i16, g) of the result owns row m = i16, columns n = 4g .. 4g + 3
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ni], af[ks][mi], acc[mi][ni], 0, 0, 0, sb[ni], 0, sa[ks][mi]);
+        }
+        // wave-private LDS image (LDS executes a wave's operations in order: no barrier), then whole rows out
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)   // B fragment first: lane (i16, g) of the result owns row m = i16, columns n = 4g .. 4g + 3
-                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ni], af[mi], acc[mi][ni], 0, 0, 0, sb[ni], 0, sa[mi]);
-    }
+            for (int ni = 0; ni < 4; ++ni)
+                *(float4*)(img + (16 * mi + i16) * F8_LDT + 16 * ni + 4 * g) = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        const int c8 = 8 * (lane & 7);                   // this lane's 8 consecutive columns of the wave tile
+        const int n = n0 + c8;
+        float bv[8];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const long long m = m0 + 16 * mi + i16;
-        if (m >= M) continue;
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + 16 * ni + 4 * g;
-            if (n >= N) continue;
-            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            if (bias) {
+        for (int it = 0; it < 8; ++it) {
+            const int rl = 8 * it + (lane >> 3);
+            const long long m = m0 + rl;
+            const float4 x0 = *(const float4*)(img + rl * F8_LDT + c8), x1 = *(const float4*)(img + rl * F8_LDT + c8 + 4);
+            const float v[8] = {x0.x + bv[0], x0.y + bv[1], x0.z + bv[2], x0.w + bv[3], x1.x + bv[4], x1.y + bv[5], x1.z + bv[6], x1.w + bv[7]};
+            if (m >= M || n >= N) continue;
+            TC* cp = C + m * ldc + n;
+            if (n + 7 < N && (ldc & 7) == 0) {
+                if constexpr (sizeof(TC) == 2) {
+                    bf16x8 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
+                    *(bf16x8*)cp = o;
+                } else {
+                    *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += bias[n + e];
-            }
-            if (n + 3 < N && (ldc & 3) == 0) st4(C + m * ldc + n, v);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (n + e < N) stf8<TC>(C, m * ldc + n + e, v[e]);
+                for (int e = 0; e < 8; ++e) if (n + e < N) stf8<TC>(cp, e, v[e]);
             }
         }
+    }
+}
+
+template <typename TC>
+static void gemm_fp8_dispatch(int nk, dim3 grid, hipStream_t s, const uint8_t* A, const uint8_t* sA, const uint8_t* W, const uint8_t* sW, const float* bias,
+                              TC* C, long long M, int N, long long ldc) {
+    switch (nk) {
+        case 1: hipLaunchKernelGGL((gemm_fp8_kernel<TC, 1>), grid, dim3(256), 0, s, A, sA, W, sW, bias, C, M, N, ldc); break;
+        case 2: hipLaunchKernelGGL((gemm_fp8_kernel<TC, 2>), grid, dim3(256), 0, s, A, sA, W, sW, bias, C, M, N, ldc); break;
+        case 3: hipLaunchKernelGGL((gemm_fp8_kernel<TC, 3>), grid, dim3(256), 0, s, A, sA, W, sW, bias, C, M, N, ldc); break;
+        default: hipLaunchKernelGGL((gemm_fp8_kernel<TC, 4>), grid, dim3(256), 0, s, A, sA, W, sW, bias, C, M, N, ldc); break;
     }
 }
 
 int gemm_fp8_launch(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int c_dtype, long long M, int N, int K,
                     long long ldc, hipStream_t s) {
     NBCI_REQUIRE(A8 && sA && W8 && sW && C && M > 0 && N > 0 && K > 0, NBCI_EINVAL, "gemm_fp8: null operand / bad shape");
-    NBCI_REQUIRE(K % 128 == 0 && ldc >= N, NBCI_ESHAPE, "gemm_fp8: K must be a multiple of 128 (one instruction's depth)");
+    NBCI_REQUIRE(K % 128 == 0 && K <= 512 && ldc >= N, NBCI_ESHAPE, "gemm_fp8: K must be 128, 256, 384 or 512 (the A fragments of a row block stay in registers)");
     NBCI_REQUIRE(((uintptr_t)A8) % 16 == 0 && ((uintptr_t)W8) % 16 == 0, NBCI_EALIGN, "gemm_fp8: operands must be 16-byte aligned");
-    const int tiles_n = (N + 127) / 128;
-    const long long tiles = ((M + 127) / 128) * tiles_n;
-    NBCI_REQUIRE(tiles < (1ll << 31), NBCI_ESHAPE, "gemm_fp8: too many tiles");
+    const long long tiles = (M + 127) / 128;
+    NBCI_REQUIRE(tiles < (1ll << 31), NBCI_ESHAPE, "gemm_fp8: too many row tiles");
+    dim3 grid((unsigned)tiles);
     if (c_dtype == NBCI_BF16)
-        hipLaunchKernelGGL((gemm_fp8_kernel<bf16_t>), dim3((unsigned)tiles), dim3(256), 0, s, (const uint8_t*)A8, (const uint8_t*)sA, (const uint8_t*)W8,
-                           (const uint8_t*)sW, bias, (bf16_t*)C, M, N, K, ldc, tiles_n);
+        gemm_fp8_dispatch<bf16_t>(K / 128, grid, s, (const uint8_t*)A8, (const uint8_t*)sA, (const uint8_t*)W8, (const uint8_t*)sW, bias, (bf16_t*)C, M, N, ldc);
     else
-        hipLaunchKernelGGL((gemm_fp8_kernel<float>), dim3((unsigned)tiles), dim3(256), 0, s, (const uint8_t*)A8, (const uint8_t*)sA, (const uint8_t*)W8,
-                           (const uint8_t*)sW, bias, (float*)C, M, N, K, ldc, tiles_n);
+        gemm_fp8_dispatch<float>(K / 128, grid, s, (const uint8_t*)A8, (const uint8_t*)sA, (const uint8_t*)W8, (const uint8_t*)sW, bias, (float*)C, M, N, ldc);
     return check_launch("gemm_fp8");
 }
 

