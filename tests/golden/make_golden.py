@@ -628,7 +628,7 @@ def ptst_case(name, over, method, B, lens, tgt_lens=None, vocab=11, full=True, s
         hs.append(lyr.register_forward_hook(lambda m, inp, o, i=i: inter.__setitem__(f"layer{i}", o[0].detach())))
     if ec["do_mask_input"]:
         hs.append(enc.masking.register_forward_hook(lambda m, i, o: masks.append(o[1].numpy().copy())))
-    cut = (lambda a: a) if full else (lambda a: a[..., ::7, ::13])
+    cut = (lambda a: a) if full else (lambda a: a[:, ::max(1, a.shape[1] // 16), ::7, ::13])   # (B, C, P, D): every C/16-th channel too
 
     def record(tag, out):
         fx[tag + "_loss"] = out.loss.detach().numpy(); fx[tag + "_n_examples"] = out.n_examples.numpy()
@@ -694,5 +694,5 @@ if __name__ == "__main__" and "--ptst" in sys.argv:
     ptst_case("g_ptst_tiny_ov", {**ptst_tiny(patch_stride=5, context_length=48), "decoder": {"mlp_decoder": True}}, "ctc", 3, [48, 40, 29], [4, 3, 2])
     ptst_case("g_ptst_tiny_mlm", ptst_tiny(do_mask_input=True, random_mask_ratio=0.4), "mlm", 3, [45, 38, 30])
     ptst_case("g_ptst_tiny_mlm_rate", ptst_tiny(do_mask_input=True, random_mask_ratio=0.4), "mlm", 3, [45, 38, 30], log_input=False)
-    ptst_case("g_ptst_c5", {"encoder": {"num_input_channels": 16, "context_length": 2050, "attention_dropout": 0.0, "ff_dropout": 0.0,
+    ptst_case("g_ptst_c5", {"encoder": {"num_input_channels": 128, "context_length": 2050, "attention_dropout": 0.0, "ff_dropout": 0.0,
                                          "do_mask_input": False}}, "ctc", 2, [2050, 1500], [60, 40], vocab=41, full=False)
