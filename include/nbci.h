@@ -266,6 +266,15 @@ int nbci_profile_enable(int32_t on);
  * 0 = the two-workgroup-per-CU kernels only, 1 = the producer / consumer kernel (144 x 256 tiles, gemm_pc.hip) where the tile
  * cost model prefers it (default), 2 = the producer / consumer kernel whenever eligible. Initial value: NBCI_GEMM_PC. */
 int nbci_debug_gemm_pc(int32_t mode);
+/* Measurement / test aid: how nbci_gemm_grouped launches a group of direct-to-LDS problems (K % 64 == 0): 0 = one workgroup per
+ * 128 x 128 output tile, 1 = deal the K tiles of all output tiles out evenly over the chip's workgroup slots when one workgroup
+ * per tile would leave more than 12 % of the slot-rounds empty (default; gemm_streamk.hip: partial tiles go through a scratch buffer
+ * of 64 KB per slot that the library keeps per (device, stream); fixed summation order, no atomics), 2 = always. Initial value:
+ * NBCI_STREAMK. The reference has no counterpart (a layer's weight gradients are four cuBLAS calls inside loss.backward(),
+ * models/trainer.py:339). */
+int nbci_debug_gemm_streamk(int32_t mode);
+/* Frees the scratch buffers the library allocated on its own (the grouped GEMM's partial tiles). Call with the streams idle. */
+int nbci_release_scratch(void);
 int nbci_profile_collect(double* out24);
 
 /* ------------------------------------------------------------------------------------

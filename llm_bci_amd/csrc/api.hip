@@ -101,6 +101,12 @@ int nbci_gemm_fp8(const void* A8, const void* sA, const void* W8, const void* sW
     return nbci::gemm_fp8_launch(A8, sA, W8, sW, bias, C, c_dtype, M, N, K, ldc, (hipStream_t)stream);
 }
 int nbci_debug_gemm_pc(int32_t mode) { nbci::gemm_pc_set_mode(mode); return NBCI_OK; }
+int nbci_debug_gemm_streamk(int32_t mode) {
+    if (mode < 0 || mode > 2) return nbci::fail(NBCI_EINVAL, "stream-K mode must be 0, 1 or 2");
+    nbci::gemm_streamk_set_mode(mode);
+    return NBCI_OK;
+}
+int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");

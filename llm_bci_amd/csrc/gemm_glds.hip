@@ -343,6 +343,9 @@ static int launch_glds_layout(const GemmK& k, bool ak, bool bk, dim3 grid, hipSt
     }
 }
 
+bool gemm_streamk_wanted(const nbci_gemm_desc* descs, const GemmK* ks, int n);   // gemm_streamk.hip
+int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream);
+
 int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream) {
     NBCI_REQUIRE(n >= 1 && n <= GEMM_GROUP_MAX, NBCI_EINVAL, "gemm group: 1..6 problems");
     GemmGroup grp;
@@ -358,6 +361,7 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
         grp.start[i + 1] = grp.start[i] + grp.sub[i].tiles_m * grp.sub[i].tiles_n;
     }
     for (int i = n; i < GEMM_GROUP_MAX; ++i) grp.start[i + 1] = grp.start[n];
+    if (gemm_streamk_wanted(descs, ks, n)) return gemm_streamk_launch(descs, ks, n, stream);   // tile count leaves slots idle: deal out K tiles instead
     dim3 grid(grp.start[n]);
     constexpr int lds = 128 * EPI_LD * 4;   // the epilogue tile (67.6 KB) is a little larger than the two K-loop stages
     static bool attr_set = false;

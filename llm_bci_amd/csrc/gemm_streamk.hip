@@ -1,0 +1,332 @@
+// gemm_streamk.hip — balanced launch of a GEMM group whose tile count does not fill the chip's workgroup slots.
+//
+// A layer's four weight gradients are 384 full-K tiles of 128 x 128 (K = all tokens) on 512 workgroup slots (256 CUs x 2): with
+// one tile per workgroup a quarter of the slots idle for the whole launch, and tiles cannot be cut to fit (1024- and 3072-row
+// problems, 6.3 M outputs / 512 = 12 288 per tile has no 16-multiple factorisation that divides both). Splitting K with f32
+// atomics was measured slower than the imbalance it removes. Here the launch is S workgroups, one per slot, and
+// the K TILES of all output tiles — tile-major, I = sum(tiles_p x ktiles_p) of them — are dealt out in equal contiguous runs
+// ("stream-K"): every workgroup does I / S K tiles, whatever the tile count. A run that starts or ends inside an output tile
+// yields a partial accumulator:
+//   * the workgroup that holds a tile's LAST K tile is the tile's owner: it adds the others' partials to its accumulators and runs
+//     the normal epilogue (alpha, beta, ... — anything gemm_epilogue_tile does), so the result is stored once and the summation
+//     order is fixed (deterministic, unlike atomics);
+//   * every other workgroup touching the tile is a contributor: it writes its accumulators — registers as they are, 1 KB per
+//     wave instruction — to its own 64 KB slot of a scratch buffer and publishes a flag (release, agent scope).
+// A workgroup has at most one contributor run (the one that does not reach its tile's end) and does it FIRST, so by the time an
+// owner has finished its own share the partials it needs have usually been there for a while. The owner spins on the
+// contributors' flags; this cannot deadlock: runs are dealt out per XCD (workgroup b is on XCD b % 8 and takes run b / 8 of that
+// XCD's tiles, so partials also stay inside one L2), contributors of a tile always have a lower block index than its owner,
+// workgroups are dispatched in block-index order and a contributor run waits for nothing.
+// Flags carry the launch's epoch (a per-process counter), so they are never reset.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "gemm_glds.h"
+#include "kernels.h"
+
+namespace nbci {
+
+constexpr int SK_MAX = 6;
+struct StreamK {
+    int n;
+    int tile_start[SK_MAX + 1];    // prefix sums of output tiles per problem
+    int iter_start[SK_MAX + 1];    // prefix sums of K tiles (tile-major) per problem
+    int kt[SK_MAX];                // K tiles per output tile
+    int xcd_tile[9];               // XCD x works on tiles [xcd_tile[x], xcd_tile[x + 1])
+    int wpx;                       // workgroups per XCD (grid = 8 wpx)
+    float* partial;                // [grid][16][256] float4
+    int* flags;                    // [grid]
+    int epoch;
+    int dbg;                       // measurement only: 1 = no partial exchange at all (wrong results)
+    GemmK sub[SK_MAX];
+};
+
+struct SkPos { int p, tile, k; };   // problem, tile inside the problem, K tile inside the output tile
+
+__device__ __forceinline__ SkPos sk_locate(const StreamK& s, int it) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < SK_MAX; ++i)
+        if (i < s.n && it >= s.iter_start[i]) p = i;
+    const int r = it - s.iter_start[p];
+    SkPos o;
+    o.p = p; o.tile = r / s.kt[p]; o.k = r - o.tile * s.kt[p];
+    return o;
+}
+__device__ __forceinline__ int sk_iter_of_tile(const StreamK& s, int gtile) {   // first K tile of global output tile `gtile`
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < SK_MAX; ++i)
+        if (i < s.n && gtile >= s.tile_start[i]) p = i;
+    return s.iter_start[p] + (gtile - s.tile_start[p]) * s.kt[p];
+}
+// run j of an XCD whose K tiles are [i0, i0 + len): [i0 + j len / wpx, i0 + (j + 1) len / wpx)
+__device__ __forceinline__ int sk_run_begin(int i0, int len, int wpx, int j) { return i0 + (int)(((long long)j * len) / wpx); }
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_streamk_kernel(StreamK s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 4, NI = 4, BM = 128;
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 16384, NPA = A_BYTES / 1024, NPB = 16;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w / 2, wn = w % 2;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int i0 = sk_iter_of_tile(s, s.xcd_tile[xcd]);
+    const int len = (s.xcd_tile[xcd + 1] == s.tile_start[s.n] ? s.iter_start[s.n] : sk_iter_of_tile(s, s.xcd_tile[xcd + 1])) - i0;
+    if (len <= 0) return;
+    const int g_begin = sk_run_begin(i0, len, s.wpx, j);
+    int g_end = sk_run_begin(i0, len, s.wpx, j + 1);
+    if (g_begin >= g_end) return;   // (host guarantees len >= wpx; kept for safety: an empty run neither owns nor contributes)
+
+    // the run's last piece: a contributor piece if it stops short of its tile's last K tile
+    int first = -1, first_end = 0;   // [first, first_end): piece to do first (-1: none)
+    {
+        const SkPos e = sk_locate(s, g_end - 1);
+        if (e.k + 1 < s.kt[e.p]) {
+            first = max(g_begin, g_end - 1 - e.k);
+            first_end = g_end;
+            g_end = first;
+        }
+    }
+    int g = first >= 0 ? first : g_begin;
+    bool contrib = first >= 0;
+    while (true) {
+        if (!contrib && g >= g_end) break;
+        const SkPos ps = sk_locate(s, g);
+        const GemmK& d = s.sub[ps.p];
+        const int ktn = s.kt[ps.p];
+        const int piece_end = contrib ? first_end : g + (ktn - ps.k);   // an owner piece always runs to its tile's end
+        const int kt_begin = ps.k, kt_end = ps.k + (piece_end - g);
+        int tm, tn;
+        {
+            const int per_group = 8 * d.tiles_n;
+            const int grp = ps.tile / per_group, in_grp = ps.tile % per_group;
+            const int first_m = grp * 8;
+            const int gsize = min(8, d.tiles_m - first_m);
+            tm = first_m + in_grp % gsize;
+            tn = in_grp / gsize;
+        }
+        const int m0 = tm * BM, n0 = tn * 128;
+
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        GldsOperand<AK, NPA> ga;
+        GldsOperand<BKM, NPB> gb;
+        glds_setup<AK, NPA>(ga, d.A, m0, d.M, w, lane);
+        glds_setup<BKM, NPB>(gb, d.B, n0, d.N, w, lane);
+        int cur = 0;
+        glds_stage<AK, NPA, 4>(ga, d.A, smem, kt_begin, w);
+        glds_stage<BKM, NPB, 4>(gb, d.B, smem + A_BYTES, kt_begin, w);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) {
+                char* nx = smem + (cur ^ 1) * STAGE;
+                glds_stage<AK, NPA, 4>(ga, d.A, nx, kt + 1, w);
+                glds_stage<BKM, NPB, 4>(gb, d.B, nx + A_BYTES, kt + 1, w);
+            }
+            const char* sA = smem + cur * STAGE;
+            compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        if (contrib) {
+            float4* slot = (float4*)s.partial + (size_t)blockIdx.x * (MI * NI * GEMM_THREADS);
+            if (!(s.dbg & 1)) {
+                // (s_nop 4: the scalar base may have just been written by a VALU instruction — v_readlane of a spilled SGPR — and the
+                // hazard recogniser does not look inside inline asm: VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states)
+                // write-through stores (sc0 sc1: past every non-coherent cache level), acknowledged before the flag goes out: no
+                // cache-wide writeback / invalidate, which would also throw out the operand panels the other workgroups are reusing
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(t * 16), "v"(acc[a][b]), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) __hip_atomic_store(s.flags + blockIdx.x, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            contrib = false;
+            g = g_begin;
+            continue;
+        }
+        if (kt_begin > 0) {
+            // contributors: the runs of this XCD that cover [tile begin, g): run indices jc .. j - 1
+            const int tile_it = g - kt_begin;
+            int jc = (int)((((long long)(tile_it - i0)) * s.wpx) / len);
+            while (jc > 0 && sk_run_begin(i0, len, s.wpx, jc) > tile_it) --jc;
+            while (sk_run_begin(i0, len, s.wpx, jc + 1) <= tile_it) ++jc;
+            for (int c = jc; c < j && !(s.dbg & 1); ++c) {
+                const int cb = c * 8 + xcd;
+                const float4* slot = (const float4*)s.partial + (size_t)cb * (MI * NI * GEMM_THREADS);
+                {
+                    if (t == 0) {
+                        while (__hip_atomic_load(s.flags + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) __builtin_amdgcn_s_sleep(8);
+                    }
+                    __syncthreads();
+                    // the partial was never cached here (first touch) but may be on another XCD: read it past the caches as well
+#pragma unroll
+                    for (int a = 0; a < MI; ++a) {
+                        f32x4 v[NI];
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(v[b]) : "v"(t * 16), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) acc[a][b] += v[b];
+                    }
+                }
+            }
+        }
+        gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, 0, t, GEMM_THREADS, smem);
+        __syncthreads();   // the epilogue's LDS tile is read out before the next piece stages into it
+        g = piece_end;
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------
+struct SkScratch { float* partial; int* flags; int slots; };
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, SkScratch> g_sk_scratch;
+static std::atomic<int> g_sk_epoch{1};
+static int g_sk_mode = -1;   // -1: read NBCI_STREAMK on first use (default 1)
+
+int gemm_streamk_mode() {
+    if (g_sk_mode < 0) {
+        const char* e = getenv("NBCI_STREAMK");
+        g_sk_mode = e ? atoi(e) : 1;
+    }
+    return g_sk_mode;
+}
+void gemm_streamk_set_mode(int m) { g_sk_mode = m; }
+
+int gemm_streamk_release() {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    for (auto& kv : g_sk_scratch) {
+        (void)hipFree(kv.second.partial);
+        (void)hipFree(kv.second.flags);
+    }
+    g_sk_scratch.clear();
+    return NBCI_OK;
+}
+
+static int sk_scratch(hipStream_t stream, int slots, SkScratch& out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(NBCI_EHIP, "stream-K scratch: hipGetDevice");
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    auto key = std::make_pair(dev, stream);
+    auto it = g_sk_scratch.find(key);
+    if (it != g_sk_scratch.end() && it->second.slots >= slots) { out = it->second; return NBCI_OK; }
+    if (it != g_sk_scratch.end()) {
+        // an earlier launch on this stream may still be reading the old buffers
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail(NBCI_EHIP, "stream-K scratch: sync");
+        (void)hipFree(it->second.partial);
+        (void)hipFree(it->second.flags);
+        g_sk_scratch.erase(it);
+    }
+    SkScratch s;
+    s.slots = slots;
+    if (hipMalloc((void**)&s.partial, (size_t)slots * 16 * GEMM_THREADS * sizeof(float4)) != hipSuccess)
+        return fail(NBCI_EHIP, "stream-K scratch: hipMalloc (partials)");
+    if (hipMalloc((void**)&s.flags, (size_t)slots * sizeof(int)) != hipSuccess) {
+        (void)hipFree(s.partial);
+        return fail(NBCI_EHIP, "stream-K scratch: hipMalloc (flags)");
+    }
+    if (hipMemsetAsync(s.flags, 0, (size_t)slots * sizeof(int), stream) != hipSuccess) return fail(NBCI_EHIP, "stream-K scratch: memset");
+    g_sk_scratch[key] = s;
+    out = s;
+    return NBCI_OK;
+}
+
+// Fills the launch description; false when the group cannot be dealt out (a K that is not a multiple of 64, or an XCD's share of
+// the tiles with fewer K tiles than workgroups).
+static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK& s) {
+    if (n < 1 || n > SK_MAX) return false;
+    s.n = n;
+    s.tile_start[0] = 0;
+    s.iter_start[0] = 0;
+    long iters = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].K % 64 || descs[i].K < 64) return false;
+        s.sub[i] = ks[i];
+        s.sub[i].tiles_m = (descs[i].M + 127) / 128;
+        s.kt[i] = descs[i].K / 64;
+        const int tl = s.sub[i].tiles_m * s.sub[i].tiles_n;
+        iters += (long)tl * s.kt[i];
+        if (iters > (1L << 30)) return false;
+        s.tile_start[i + 1] = s.tile_start[i] + tl;
+        s.iter_start[i + 1] = s.iter_start[i] + tl * s.kt[i];
+    }
+    for (int i = n; i < SK_MAX; ++i) { s.tile_start[i + 1] = s.tile_start[n]; s.iter_start[i + 1] = s.iter_start[n]; s.kt[i] = 1; }
+    const int tiles = s.tile_start[n];
+    const int slots = 2 * (available_cus() & ~3);   // a multiple of 8
+    if (slots < 64) return false;
+    s.wpx = slots / 8;
+    for (int x = 0; x <= 8; ++x) s.xcd_tile[x] = (int)(((long)tiles * x) / 8);
+    for (int x = 0; x < 8; ++x) {   // every run needs at least one K tile (an XCD without tiles simply returns)
+        long it = 0;
+        for (int g = s.xcd_tile[x]; g < s.xcd_tile[x + 1]; ++g) {
+            int p = 0;
+            while (p + 1 < n && g >= s.tile_start[p + 1]) ++p;
+            it += s.kt[p];
+        }
+        if (it != 0 && it < s.wpx) return false;
+    }
+    return true;
+}
+
+// Worth it when one-tile-per-workgroup rounds would leave a good part of the last round's slots empty (`tiles` 128 x 128 tiles on
+// `slots` = 2 x available CUs). The caller has checked that every problem is a plain (non-view, unbatched, unsplit) direct-to-LDS one.
+bool gemm_streamk_wanted(const nbci_gemm_desc* descs, const GemmK* ks, int n) {
+    const int mode = gemm_streamk_mode();
+    StreamK s;
+    if (mode == 0 || !sk_plan(descs, ks, n, s)) return false;
+    if (mode == 2) return true;        // forced (tests)
+    const long tiles = s.tile_start[n], iters = s.iter_start[n], slots = 8L * s.wpx;
+    const long rounds = (tiles + slots - 1) / slots;
+    if (rounds > 3 || iters < slots * 16) return false;
+    return (double)tiles / (double)(rounds * slots) < 0.88;   // the classic launch would idle > 12 % of its slot-rounds
+}
+
+int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream) {
+    StreamK s;
+    NBCI_REQUIRE(sk_plan(descs, ks, n, s), NBCI_EINVAL, "gemm stream-K: group cannot be dealt out");
+    const bool ak = descs[0].A.kmajor != 0, bk = descs[0].B.kmajor != 0;
+    const int slots = 8 * s.wpx;
+    SkScratch sc;
+    int rc = sk_scratch(stream, slots, sc);
+    if (rc != NBCI_OK) return rc;
+    s.partial = sc.partial;
+    s.flags = sc.flags;
+    s.epoch = g_sk_epoch.fetch_add(1);
+    { const char* e = getenv("NBCI_STREAMK_DBG"); s.dbg = e ? atoi(e) : 0; }
+    constexpr int lds = 128 * EPI_LD * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e3 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e4 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(NBCI_EHIP, "gemm stream-K: LDS attribute");
+        attr_set = true;
+    }
+    dim3 grid(slots);
+    if (ak && bk) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, s);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, s);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, dim3(GEMM_THREADS), lds, stream, s);
+    else hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, dim3(GEMM_THREADS), lds, stream, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm stream-K launch: ") + hipGetErrorString(e));
+    return NBCI_OK;
+}
+
+}  // namespace nbci

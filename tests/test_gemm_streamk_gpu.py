@@ -1,0 +1,88 @@
+"""GPU parity of the balanced grouped launch (llm_bci_amd/csrc/gemm_streamk.hip) behind nbci_gemm_grouped: K tiles of all output tiles
+dealt out evenly over the workgroup slots, partial tiles summed by the tile's owner. Integer-valued operands make every partial sum exact
+in f32, so the result must be BIT-equal to the float64 product whatever the split — a lost, doubled or misplaced partial is an O(1) error.
+The reference has no counterpart kernel: these are the four weight-gradient matmuls of a layer inside loss.backward()
+(models/trainer.py:339)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ints(shape, seed, lo=-2, hi=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+def _run_group(probs, ak, bk, mode, beta=1.0, repeats=2):
+    """probs: [(M, N, K)]; returns (outputs, float64 references) of C = beta * C0 + A B^T"""
+    from llm_bci_amd import ops
+    from llm_bci_amd._lib import GemmDesc, check, lib
+    l = lib()
+    check(l.nbci_debug_gemm_streamk(mode), "mode")
+    try:
+        descs = (GemmDesc * len(probs))()
+        keep, refs, outs = [], [], []
+        for i, (M, N, K) in enumerate(probs):
+            a, b = _ints((M, K), 50 + i), _ints((N, K), 70 + i)
+            ad = (a if ak else a.t().contiguous()).to(DEV, torch.bfloat16)
+            bd = (b if bk else b.t().contiguous()).to(DEV, torch.bfloat16)
+            c0 = _ints((M, N), 90 + i, -8, 9).to(DEV)
+            d = descs[i]
+            d.M, d.N, d.K, d.in_dtype = M, N, K, ops.NBCI_BF16
+            d.A, d.B = ops.operand(ad, ad.stride(0), ak), ops.operand(bd, bd.stride(0), bk)
+            d.ldc, d.c_dtype, d.batch, d.zdiv, d.splitk, d.alpha, d.beta = N, ops.NBCI_F32, 1, 1, 1, 1.0, beta
+            keep += [ad, bd, c0]
+            refs.append(beta * c0.double() + a.to(DEV).double() @ b.to(DEV).double().t())
+        for _ in range(repeats):      # a second launch reuses the scratch slots and flags under a new epoch
+            outs = []
+            for i, (M, N, K) in enumerate(probs):
+                out = keep[3 * i + 2].clone()
+                descs[i].C = out.data_ptr()
+                outs.append(out)
+            check(l.nbci_gemm_grouped(descs, len(probs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "grouped")
+            torch.cuda.synchronize()
+            for o, r in zip(outs, refs):
+                assert torch.equal(o.double(), r)
+    finally:
+        check(l.nbci_debug_gemm_streamk(1), "mode")
+
+
+GROUPS = {
+    # a layer's weight gradients at the bench batch: 384 tiles on 512 slots, every tile split in two
+    "layer_wgrad": [(3072, 1024, 9152), (1024, 1024, 9152), (1024, 1024, 9152), (1024, 1024, 9152)],
+    # 4 tiles, 256 K tiles each: 64 workgroups per tile, the owner adds 63 partials; ragged rows (130)
+    "few_tiles_long_k": [(130, 256, 16384), (128, 256, 16384)],
+    # 600 tiles on 512 slots: runs cover a tail, whole tiles and a head
+    "more_tiles_than_slots": [(3840, 1280, 1024), (2560, 1280, 1024)],
+    # K differs per problem
+    "mixed_k": [(256, 384, 4096), (384, 256, 8192), (1024, 512, 2048)],
+}
+
+
+@pytest.mark.parametrize("name", list(GROUPS))
+@pytest.mark.parametrize("ak,bk", [(False, False), (True, True), (True, False), (False, True)])
+def test_streamk_group_exact(name, ak, bk):
+    if name == "layer_wgrad" and (ak or bk) and not (ak and bk):
+        pytest.skip("the large case runs in the weight-gradient and forward layouts only")
+    _run_group(GROUPS[name], ak, bk, mode=2)
+
+
+def test_streamk_default_rule_and_plain_assign():
+    """mode 1 (shipped): the layer group takes the balanced launch, beta = 0 overwrites whatever C held"""
+    _run_group(GROUPS["layer_wgrad"], False, False, mode=1, beta=0.0)
+    _run_group([(256, 128, 1000), (128, 384, 1000)], False, False, mode=2)   # K % 64 != 0: not dealt out, classic launch, same result
+
+
+def test_streamk_with_fewer_available_cus():
+    from llm_bci_amd._lib import check, lib
+    check(lib().nbci_set_available_cus(200), "cus")
+    try:
+        _run_group(GROUPS["mixed_k"], False, False, mode=2)
+    finally:
+        check(lib().nbci_set_available_cus(256), "cus")
+    check(lib().nbci_release_scratch(), "release")
+    _run_group(GROUPS["mixed_k"], True, True, mode=2, repeats=1)   # scratch is allocated again on demand
