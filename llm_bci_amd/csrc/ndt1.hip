@@ -577,9 +577,12 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
             const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
+            static const bool attn_bias = [] { const char* e = getenv("NBCI_ATTN_BIASGRAD"); return !(e && e[0] == '0'); }();   // q/k/v bias sums inside the attention backward (DPP row sums + LDS atomics: +6 us on the two kernels, -11 us colsum launch per layer)
+            bool bias_in_attn = false;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
+                bias_in_attn = attn_bias && !c.use_rope;
                 TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
-                                    nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
+                                    bias_in_attn ? RG(lo.qb) : nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
             } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
                 TRY(fattn_masked_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, ws + w.dB2, (const float*)(ws + lw.lse),
@@ -618,7 +621,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             const bool fused_bwd = (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) || (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh));
             if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
-            if (c.use_rope || fused_bwd)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
+            if ((c.use_rope || fused_bwd) && !bias_in_attn)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
                 TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
             TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
             TRY(wq.flush());   // all four operand pairs exist now; the LayerNorm backward below overwrites dA
