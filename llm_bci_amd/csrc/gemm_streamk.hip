@@ -32,6 +32,7 @@
 namespace nbci {
 
 constexpr int SK_MAX = 6;
+constexpr int SK_MAXP = 8;   // aligned scheme: most pieces (scratch slots) one helper workgroup may produce
 struct StreamK {
     int n;
     int tile_start[SK_MAX + 1];    // prefix sums of output tiles per problem
@@ -43,6 +44,7 @@ struct StreamK {
     int* flags;                    // [grid]
     int epoch;
     int dbg;                       // measurement only: 1 = no partial exchange at all (wrong results)
+    int aligned, q, lk, ex, tx, r, maxp;   // aligned scheme (see the kernel): owner K tiles, remainder, helpers and tiles per XCD, tiles per helper (0: not integral), slots per helper
     GemmK sub[SK_MAX];
 };
 
@@ -68,15 +70,136 @@ __device__ __forceinline__ int sk_iter_of_tile(const StreamK& s, int gtile) {   
 // run j of an XCD whose K tiles are [i0, i0 + len): [i0 + j len / wpx, i0 + (j + 1) len / wpx)
 __device__ __forceinline__ int sk_run_begin(int i0, int len, int wpx, int j) { return i0 + (int)(((long long)j * len) / wpx); }
 
-template <bool AK, bool BKM>
-__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_streamk_kernel(StreamK s) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One piece: K tiles [kb, ke) of output tile `tile` of problem p. write_slot >= 0: a contributor piece, the raw accumulators go to that
+// scratch slot and its flag is raised; otherwise an owner piece: the partials in slot_of(0 .. nadd-1) are added (in that order) and the
+// normal epilogue stores the tile.
+template <bool AK, bool BKM, typename SlotOf>
+__device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, int tile, int kb, int ke, int write_slot, int nadd, SlotOf slot_of) {
     constexpr int MI = 4, NI = 4, BM = 128;
     constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 16384, NPA = A_BYTES / 1024, NPB = 16;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w / 2, wn = w % 2;
+    const GemmK& d = s.sub[p];
+    int tm, tn;
+    {
+        const int per_group = 8 * d.tiles_n;
+        const int grp = tile / per_group, in_grp = tile % per_group;
+        const int first_m = grp * 8;
+        const int gsize = min(8, d.tiles_m - first_m);
+        tm = first_m + in_grp % gsize;
+        tn = in_grp / gsize;
+    }
+    const int m0 = tm * BM, n0 = tn * 128;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    GldsOperand<AK, NPA> ga;
+    GldsOperand<BKM, NPB> gb;
+    glds_setup<AK, NPA>(ga, d.A, m0, d.M, w, lane);
+    glds_setup<BKM, NPB>(gb, d.B, n0, d.N, w, lane);
+    int cur = 0;
+    glds_stage<AK, NPA, 4>(ga, d.A, smem, kb, w);
+    glds_stage<BKM, NPB, 4>(gb, d.B, smem + A_BYTES, kb, w);
+    __syncthreads();
+    for (int kt = kb; kt < ke; ++kt) {
+        if (kt + 1 < ke) {
+            char* nx = smem + (cur ^ 1) * STAGE;
+            glds_stage<AK, NPA, 4>(ga, d.A, nx, kt + 1, w);
+            glds_stage<BKM, NPB, 4>(gb, d.B, nx + A_BYTES, kt + 1, w);
+        }
+        const char* sA = smem + cur * STAGE;
+        compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (write_slot >= 0) {
+        if (!(s.dbg & 1)) {
+            float4* slot = (float4*)s.partial + (size_t)write_slot * (MI * NI * GEMM_THREADS);
+            // write-through stores (sc0 sc1: past every non-coherent cache level), acknowledged before the flag goes out: no cache-wide
+            // writeback / invalidate, which would also throw out the operand panels the other workgroups are reusing.
+            // (s_nop 4: the scalar base may have just been written by a VALU instruction — v_readlane of a spilled SGPR — and the hazard
+            // recogniser does not look inside inline asm: VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states)
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(t * 16), "v"(acc[a][b]), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(s.flags + write_slot, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    for (int i = 0; i < nadd && !(s.dbg & 1); ++i) {
+        const int sl = slot_of(i);
+        const float4* slot = (const float4*)s.partial + (size_t)sl * (MI * NI * GEMM_THREADS);
+        if (t == 0) {
+            while (__hip_atomic_load(s.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        // the partial was never cached here (first touch) but may be on another XCD: read it past the caches as well
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+            f32x4 v[NI];
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(v[b]) : "v"(t * 16), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] += v[b];
+        }
+    }
+    gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, 0, t, GEMM_THREADS, smem);
+    __syncthreads();   // the epilogue's LDS tile is read out before the next piece stages into it
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_streamk_kernel(StreamK s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (s.aligned) {
+        // ---- aligned scheme (all problems share K, fewer tiles than slots): the XCD's tx tiles have one OWNER workgroup each (blocks
+        // j >= ex) doing K tiles [0, q) in lockstep — same panel reuse as one workgroup per tile — and ex HELPER workgroups (j < ex,
+        // i.e. lower block indices: dispatched first, never waiting) sweep the remainders [q, kt) tile after tile in equal runs.
+        const int ex = s.ex, tx = s.tx, lk = s.lk, q = s.q, L = tx * lk;
+        auto run_begin = [&](int c) { return (int)(((long long)c * L) / ex); };
+        if (j < ex) {
+            int pos = run_begin(j);
+            const int end = run_begin(j + 1), u0 = pos / lk;
+            while (pos < end) {
+                const int u = pos / lk, koff = pos - u * lk, n = min(lk - koff, end - pos);
+                const int gt = xcd * tx + (s.r > 0 ? (u % s.r) * ex + u / s.r : u);   // helpers running side by side work on neighbouring tiles
+                int p = 0;
+#pragma unroll
+                for (int i = 1; i < SK_MAX; ++i)
+                    if (i < s.n && gt >= s.tile_start[i]) p = i;
+                sk_piece<AK, BKM>(s, smem, p, gt - s.tile_start[p], q + koff, q + koff + n, (int)blockIdx.x * s.maxp + (u - u0), 0, [](int) { return 0; });
+                pos += n;
+            }
+            return;
+        }
+        const int tau = j - ex;
+        if (tau >= tx) return;
+        const int gt = xcd * tx + tau, u = s.r > 0 ? (tau % ex) * s.r + tau / ex : tau;
+        auto helper_of = [&](int pos) {
+            int c = (int)(((long long)pos * ex) / L);
+            while (c > 0 && run_begin(c) > pos) --c;
+            while (run_begin(c + 1) <= pos) ++c;
+            return c;
+        };
+        const int c_lo = helper_of(u * lk), c_hi = helper_of((u + 1) * lk - 1);
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < SK_MAX; ++i)
+            if (i < s.n && gt >= s.tile_start[i]) p = i;
+        sk_piece<AK, BKM>(s, smem, p, gt - s.tile_start[p], 0, q, -1, c_hi - c_lo + 1,
+                          [&](int i) { const int c = c_lo + i; return (c * 8 + xcd) * s.maxp + (u - run_begin(c) / lk); });
+        return;
+    }
+    // ---- contiguous scheme (any K per problem, any tile count): the XCD's K tiles, tile-major, in wpx equal runs
     const int i0 = sk_iter_of_tile(s, s.xcd_tile[xcd]);
     const int len = (s.xcd_tile[xcd + 1] == s.tile_start[s.n] ? s.iter_start[s.n] : sk_iter_of_tile(s, s.xcd_tile[xcd + 1])) - i0;
     if (len <= 0) return;
@@ -94,102 +217,22 @@ __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2,
             g_end = first;
         }
     }
-    int g = first >= 0 ? first : g_begin;
-    bool contrib = first >= 0;
-    while (true) {
-        if (!contrib && g >= g_end) break;
+    if (first >= 0) {
+        const SkPos ps = sk_locate(s, first);
+        sk_piece<AK, BKM>(s, smem, ps.p, ps.tile, ps.k, ps.k + (first_end - first), (int)blockIdx.x, 0, [](int) { return 0; });
+    }
+    for (int g = g_begin; g < g_end;) {
         const SkPos ps = sk_locate(s, g);
-        const GemmK& d = s.sub[ps.p];
         const int ktn = s.kt[ps.p];
-        const int piece_end = contrib ? first_end : g + (ktn - ps.k);   // an owner piece always runs to its tile's end
-        const int kt_begin = ps.k, kt_end = ps.k + (piece_end - g);
-        int tm, tn;
-        {
-            const int per_group = 8 * d.tiles_n;
-            const int grp = ps.tile / per_group, in_grp = ps.tile % per_group;
-            const int first_m = grp * 8;
-            const int gsize = min(8, d.tiles_m - first_m);
-            tm = first_m + in_grp % gsize;
-            tn = in_grp / gsize;
-        }
-        const int m0 = tm * BM, n0 = tn * 128;
-
-        f32x4 acc[MI][NI];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
-#pragma unroll
-            for (int b = 0; b < NI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        GldsOperand<AK, NPA> ga;
-        GldsOperand<BKM, NPB> gb;
-        glds_setup<AK, NPA>(ga, d.A, m0, d.M, w, lane);
-        glds_setup<BKM, NPB>(gb, d.B, n0, d.N, w, lane);
-        int cur = 0;
-        glds_stage<AK, NPA, 4>(ga, d.A, smem, kt_begin, w);
-        glds_stage<BKM, NPB, 4>(gb, d.B, smem + A_BYTES, kt_begin, w);
-        __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) {
-                char* nx = smem + (cur ^ 1) * STAGE;
-                glds_stage<AK, NPA, 4>(ga, d.A, nx, kt + 1, w);
-                glds_stage<BKM, NPB, 4>(gb, d.B, nx + A_BYTES, kt + 1, w);
-            }
-            const char* sA = smem + cur * STAGE;
-            compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
-            __syncthreads();
-            cur ^= 1;
-        }
-
-        if (contrib) {
-            float4* slot = (float4*)s.partial + (size_t)blockIdx.x * (MI * NI * GEMM_THREADS);
-            if (!(s.dbg & 1)) {
-                // (s_nop 4: the scalar base may have just been written by a VALU instruction — v_readlane of a spilled SGPR — and the
-                // hazard recogniser does not look inside inline asm: VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states)
-                // write-through stores (sc0 sc1: past every non-coherent cache level), acknowledged before the flag goes out: no
-                // cache-wide writeback / invalidate, which would also throw out the operand panels the other workgroups are reusing
-#pragma unroll
-                for (int a = 0; a < MI; ++a)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(t * 16), "v"(acc[a][b]), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (t == 0) __hip_atomic_store(s.flags + blockIdx.x, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            contrib = false;
-            g = g_begin;
-            continue;
-        }
-        if (kt_begin > 0) {
-            // contributors: the runs of this XCD that cover [tile begin, g): run indices jc .. j - 1
-            const int tile_it = g - kt_begin;
-            int jc = (int)((((long long)(tile_it - i0)) * s.wpx) / len);
+        int jc = j;
+        if (ps.k > 0) {   // contributors: the runs of this XCD that cover [tile begin, g): run indices jc .. j - 1
+            const int tile_it = g - ps.k;
+            jc = (int)((((long long)(tile_it - i0)) * s.wpx) / len);
             while (jc > 0 && sk_run_begin(i0, len, s.wpx, jc) > tile_it) --jc;
             while (sk_run_begin(i0, len, s.wpx, jc + 1) <= tile_it) ++jc;
-            for (int c = jc; c < j && !(s.dbg & 1); ++c) {
-                const int cb = c * 8 + xcd;
-                const float4* slot = (const float4*)s.partial + (size_t)cb * (MI * NI * GEMM_THREADS);
-                {
-                    if (t == 0) {
-                        while (__hip_atomic_load(s.flags + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) __builtin_amdgcn_s_sleep(8);
-                    }
-                    __syncthreads();
-                    // the partial was never cached here (first touch) but may be on another XCD: read it past the caches as well
-#pragma unroll
-                    for (int a = 0; a < MI; ++a) {
-                        f32x4 v[NI];
-#pragma unroll
-                        for (int b = 0; b < NI; ++b)
-                            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(v[b]) : "v"(t * 16), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int b = 0; b < NI; ++b) acc[a][b] += v[b];
-                    }
-                }
-            }
         }
-        gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, 0, t, GEMM_THREADS, smem);
-        __syncthreads();   // the epilogue's LDS tile is read out before the next piece stages into it
-        g = piece_end;
+        sk_piece<AK, BKM>(s, smem, ps.p, ps.tile, ps.k, ktn, -1, j - jc, [&](int i) { return (jc + i) * 8 + xcd; });   // an owner piece always runs to its tile's end
+        g += ktn - ps.k;
     }
 }
 
@@ -281,6 +324,26 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
         }
         if (it != 0 && it < s.wpx) return false;
     }
+    // aligned scheme when it applies: one K for all problems, tiles a multiple of 8 and fewer than the slots, a remainder of at least
+    // one K tile per tile, at most SK_MAXP pieces per helper. NBCI_STREAMK_ALIGNED=0 keeps the contiguous scheme (A/B).
+    s.aligned = 0; s.q = s.lk = s.ex = s.tx = s.r = 0; s.maxp = 1;
+    static const bool no_aligned = [] { const char* e = getenv("NBCI_STREAMK_ALIGNED"); return e && e[0] == '0'; }();
+    bool same_k = true;
+    for (int i = 1; i < n; ++i) same_k = same_k && s.kt[i] == s.kt[0];
+    if (!no_aligned && same_k && tiles % 8 == 0 && tiles < slots) {
+        const int kt = s.kt[0];
+        const int q = (int)(((long)kt * tiles + slots - 1) / slots), lk = kt - q;
+        const int ex = (slots - tiles) / 8, tx = tiles / 8;
+        if (lk >= 1 && (long)tx * lk >= ex) {
+            const long L = (long)tx * lk;
+            const int run_max = (int)((L + ex - 1) / ex);
+            const int maxp = (run_max + lk - 1) / lk + 1;
+            if (maxp <= SK_MAXP) {
+                s.aligned = 1; s.q = q; s.lk = lk; s.ex = ex; s.tx = tx; s.maxp = maxp;
+                s.r = (tx % ex == 0) ? tx / ex : 0;
+            }
+        }
+    }
     return true;
 }
 
@@ -303,7 +366,7 @@ int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hip
     const bool ak = descs[0].A.kmajor != 0, bk = descs[0].B.kmajor != 0;
     const int slots = 8 * s.wpx;
     SkScratch sc;
-    int rc = sk_scratch(stream, slots, sc);
+    int rc = sk_scratch(stream, slots * (s.aligned ? s.maxp : 1), sc);
     if (rc != NBCI_OK) return rc;
     s.partial = sc.partial;
     s.flags = sc.flags;

@@ -60,14 +60,18 @@ GROUPS = {
     "more_tiles_than_slots": [(3840, 1280, 1024), (2560, 1280, 1024)],
     # K differs per problem
     "mixed_k": [(256, 384, 4096), (384, 256, 8192), (1024, 512, 2048)],
+    # aligned scheme, tiles per helper not integral (336 tiles: 42 owners + 22 helpers per XCD), ragged last row tile
+    "aligned_336_tiles": [(2304, 768, 4096), (768, 768, 4096), (2040, 768, 4096), (768, 2048, 4096)],
+    # aligned scheme, more helpers than tiles: every remainder is split between several helpers
+    "aligned_128_tiles": [(1024, 1024, 2048), (1024, 1024, 2048)],
 }
 
 
 @pytest.mark.parametrize("name", list(GROUPS))
 @pytest.mark.parametrize("ak,bk", [(False, False), (True, True), (True, False), (False, True)])
 def test_streamk_group_exact(name, ak, bk):
-    if name == "layer_wgrad" and (ak or bk) and not (ak and bk):
-        pytest.skip("the large case runs in the weight-gradient and forward layouts only")
+    if name in ("layer_wgrad", "aligned_336_tiles") and (ak or bk) and not (ak and bk):
+        pytest.skip("the large cases run in the weight-gradient and forward layouts only")
     _run_group(GROUPS[name], ak, bk, mode=2)
 
 
