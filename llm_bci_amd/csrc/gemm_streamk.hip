@@ -115,6 +115,17 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
         __syncthreads();
         cur ^= 1;
     }
+    if (ke == s.kt[p] && (d.K & 63)) {   // the piece that ends the tile also takes the partial last K tile: masked register-staged loads (zero fill)
+        uint4 ra[4], rb[4];
+        load_chunks<bf16_t, AK>(d.A, m0, d.M, ke * 64, d.K, ra, t);
+        load_chunks<bf16_t, BKM>(d.B, n0, d.N, ke * 64, d.K, rb, t);
+        char* sA = smem + cur * STAGE;
+        store_chunks<bf16_t, AK>(sA, ra, t);
+        store_chunks<bf16_t, BKM>(sA + A_BYTES, rb, t);
+        __syncthreads();
+        compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
+        __syncthreads();
+    }
     if (write_slot >= 0) {
         if (!(s.dbg & 1)) {
             float4* slot = (float4*)s.partial + (size_t)write_slot * (MI * NI * GEMM_THREADS);
@@ -290,8 +301,7 @@ static int sk_scratch(hipStream_t stream, int slots, SkScratch& out) {
     return NBCI_OK;
 }
 
-// Fills the launch description; false when the group cannot be dealt out (a K that is not a multiple of 64, or an XCD's share of
-// the tiles with fewer K tiles than workgroups).
+// Fills the launch description; false when the group cannot be dealt out (an XCD's share of the tiles with fewer K tiles than workgroups).
 static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK& s) {
     if (n < 1 || n > SK_MAX) return false;
     s.n = n;
@@ -299,7 +309,7 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
     s.iter_start[0] = 0;
     long iters = 0;
     for (int i = 0; i < n; ++i) {
-        if (descs[i].K % 64 || descs[i].K < 64) return false;
+        if (descs[i].K < 64) return false;   // (kt counts the FULL K tiles; a partial last one rides with the piece that ends its tile)
         s.sub[i] = ks[i];
         s.sub[i].tiles_m = (descs[i].M + 127) / 128;
         s.kt[i] = descs[i].K / 64;
@@ -324,11 +334,21 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
         }
         if (it != 0 && it < s.wpx) return false;
     }
-    // aligned scheme when it applies: one K for all problems, tiles a multiple of 8 and fewer than the slots, a remainder of at least
-    // one K tile per tile, at most SK_MAXP pieces per helper. NBCI_STREAMK_ALIGNED=0 keeps the contiguous scheme (A/B).
+    // aligned scheme: one K for all problems, tiles a multiple of 8 and fewer than the slots, a remainder of at least one K tile per tile,
+    // at most SK_MAXP pieces per helper — and only where the contiguous runs' K phases do NOT fall into a few aligned classes by
+    // themselves: with tiles / slots = a / b in lowest terms there are b phase classes; up to 4 (the NDT1 layer group: 3 / 4) the
+    // contiguous scheme measured faster inside the train step (140 vs 148 us per launch), beyond it the aligned one (iTransformer
+    // group, 21 / 32: 318 vs 374 us). NBCI_STREAMK_ALIGNED=0 / 1 forces never / whenever it applies (A/B); mode 3 does the latter too.
     s.aligned = 0; s.q = s.lk = s.ex = s.tx = s.r = 0; s.maxp = 1;
-    static const bool no_aligned = [] { const char* e = getenv("NBCI_STREAMK_ALIGNED"); return e && e[0] == '0'; }();
-    bool same_k = true;
+    static const int env_aligned = [] { const char* e = getenv("NBCI_STREAMK_ALIGNED"); return e ? atoi(e) : -1; }();
+    const bool no_aligned = env_aligned == 0;
+    bool want = env_aligned == 1 || gemm_streamk_mode() == 3;
+    if (!want && tiles > 0) {
+        long a = tiles, b = slots;
+        while (b) { const long t = a % b; a = b; b = t; }
+        want = slots / a > 4;
+    }
+    bool same_k = want;
     for (int i = 1; i < n; ++i) same_k = same_k && s.kt[i] == s.kt[0];
     if (!no_aligned && same_k && tiles % 8 == 0 && tiles < slots) {
         const int kt = s.kt[0];
@@ -353,7 +373,7 @@ bool gemm_streamk_wanted(const nbci_gemm_desc* descs, const GemmK* ks, int n) {
     const int mode = gemm_streamk_mode();
     StreamK s;
     if (mode == 0 || !sk_plan(descs, ks, n, s)) return false;
-    if (mode == 2) return true;        // forced (tests)
+    if (mode >= 2) return true;        // forced (tests)
     const long tiles = s.tile_start[n], iters = s.iter_start[n], slots = 8L * s.wpx;
     const long rounds = (tiles + slots - 1) / slots;
     if (rounds > 3 || iters < slots * 16) return false;

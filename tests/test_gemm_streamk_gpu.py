@@ -59,9 +59,9 @@ GROUPS = {
     # 600 tiles on 512 slots: runs cover a tail, whole tiles and a head
     "more_tiles_than_slots": [(3840, 1280, 1024), (2560, 1280, 1024)],
     # K differs per problem
-    "mixed_k": [(256, 384, 4096), (384, 256, 8192), (1024, 512, 2048)],
+    "mixed_k": [(256, 384, 4096), (384, 256, 8200), (1024, 512, 2048)],   # (8200: a partial last K tile rides with the piece that ends the tile)
     # aligned scheme, tiles per helper not integral (336 tiles: 42 owners + 22 helpers per XCD), ragged last row tile
-    "aligned_336_tiles": [(2304, 768, 4096), (768, 768, 4096), (2040, 768, 4096), (768, 2048, 4096)],
+    "aligned_336_tiles": [(2304, 768, 4112), (768, 768, 4112), (2040, 768, 4112), (768, 2048, 4112)],   # K = 64 x 64 + 16
     # aligned scheme, more helpers than tiles: every remainder is split between several helpers
     "aligned_128_tiles": [(1024, 1024, 2048), (1024, 1024, 2048)],
 }
@@ -72,13 +72,18 @@ GROUPS = {
 def test_streamk_group_exact(name, ak, bk):
     if name in ("layer_wgrad", "aligned_336_tiles") and (ak or bk) and not (ak and bk):
         pytest.skip("the large cases run in the weight-gradient and forward layouts only")
-    _run_group(GROUPS[name], ak, bk, mode=2)
+    _run_group(GROUPS[name], ak, bk, mode=3 if name.startswith("aligned") else 2)
+
+
+def test_layer_group_in_the_aligned_scheme_too():
+    """the shipped rule gives the layer group the contiguous scheme (3/4 tile per workgroup: phases align by themselves); the aligned one must agree"""
+    _run_group(GROUPS["layer_wgrad"], False, False, mode=3)
 
 
 def test_streamk_default_rule_and_plain_assign():
     """mode 1 (shipped): the layer group takes the balanced launch, beta = 0 overwrites whatever C held"""
     _run_group(GROUPS["layer_wgrad"], False, False, mode=1, beta=0.0)
-    _run_group([(256, 128, 1000), (128, 384, 1000)], False, False, mode=2)   # K % 64 != 0: not dealt out, classic launch, same result
+    _run_group([(256, 128, 1000), (128, 384, 1000)], False, False, mode=2)   # K = 15 full K tiles + 40: fewer K tiles than workgroups on an XCD -> classic launch, same result
 
 
 def test_streamk_with_fewer_available_cus():

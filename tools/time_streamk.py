@@ -14,7 +14,7 @@ from llm_bci_amd._lib import GemmDesc, check, lib   # noqa: E402
 GROUPS = {
     "NDT1 layer (B=64: 9152 tokens)": [(3072, 1024, 9152), (1024, 1024, 9152), (1024, 1024, 9152), (1024, 1024, 9152)],
     "NDT1 layer (B=128: 18304 tokens)": [(3072, 1024, 18304), (1024, 1024, 18304), (1024, 1024, 18304), (1024, 1024, 18304)],
-    "iTransformer layer (768 wide, 16 x 1501 tokens -> 24000 rows)": [(2304, 768, 24000), (768, 768, 24000), (2048, 768, 24000), (768, 2048, 24000)],
+    "iTransformer layer (768 wide, 16 x 1501 tokens = 24016 rows)": [(2304, 768, 24016), (768, 768, 24016), (2048, 768, 24016), (768, 2048, 24016)],
     "two square problems (2 x 64 tiles)": [(1024, 1024, 9152), (1024, 1024, 9152)],
 }
 
