@@ -835,8 +835,16 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     if (Sb > S) Sb = S;
     const int L = 2 * Sb + 1;
     const float* lpg = preds + (long long)b * Tp * V;
-    if constexpr (STAGED)
-        for (int i = tid; i < Tb * V; i += 256) lpl[i] = lpg[i];
+    if constexpr (STAGED) {   // eight loads in flight per thread: the plain copy loop waited for each load before its LDS store (~23 round trips)
+        const int n = Tb * V;
+        for (int base = 0; base < n; base += 256 * 8) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = base + k * 256 + tid; r[k] = i < n ? lpg[i] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = base + k * 256 + tid; if (i < n) lpl[i] = r[k]; }
+        }
+    }
     const float* lp = STAGED ? lpl : lpg;
     float* aw = ws + (long long)b * Tp * Lmax;
     float* bw = ws + ((long long)Bn + b) * Tp * Lmax;
@@ -844,43 +852,69 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     __syncthreads();
     const bool is_alpha = tid < 128;
     const int ht = tid & 127;
-    // Usual case (2S + 1 <= 128: one lattice state per thread): everything that depends only on the state — its label, whether the
-    // skip transition is allowed, its column of the log-probabilities — is taken out of the frame loop, so a step is one round of
-    // independent LDS reads (three lattice entries + one log-probability), the log-add, one LDS write and the barrier.
+    // Usual case (2S + 1 <= 128): the whole lattice row lives in ONE wave's registers, two states per lane (lane i: blank state 2i and
+    // label state 2i + 1), alpha in wave 0 and beta in wave 1. A frame step is then register arithmetic plus one (alpha) or two (beta)
+    // DPP wave shifts for the neighbour lane's states — no LDS row, no barrier, nothing to wait for but the log-add itself (the previous
+    // version: one state per thread over two waves each, an LDS round trip and a four-wave barrier per frame, ~0.4 us per frame).
+    // The frame's two log-probabilities are read one step ahead; lattice rows go to the workspace with fire-and-forget stores.
     if (L <= 128) {
-        const int s = ht;
-        const bool live = s < L;
-        const int e = live ? ext[s] : 0;
-        const bool skipa = live && s >= 2 && e != blank && e != ext[s - 2];
-        const bool skipb = live && s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e;
-        const float* lpe = lp + e;
-        float* row = is_alpha ? rowA : rowB;
-        float* lat = is_alpha ? aw : bw;
-        for (int step = 0; step < Tb; ++step) {
-            const int t = is_alpha ? step : Tb - 1 - step;
-            const float* prev = row + ((step + 1) & 1) * Lmax;
-            float* cur = row + (step & 1) * Lmax;
-            if (live) {
-                const float lpv = lpe[(long long)t * V];
-                float v;
+        const int wv = tid >> 6, i = tid & 63;
+        if (wv < 2) {
+            const bool alpha = wv == 0;
+            const bool live0 = 2 * i < L, live1 = 2 * i + 1 < L;
+            const int e = live1 ? ext[2 * i + 1] : blank;
+            // skip transitions: alpha into state 2i+1 from 2i-1 ; beta into state 2i+1 from 2i+3
+            const bool skipa = live1 && i >= 1 && e != blank && e != ext[2 * i - 1];
+            const bool skipb = live1 && 2 * i + 3 < L && ext[2 * i + 3] != blank && ext[2 * i + 3] != e;
+            // log-add on the raw hardware exp2 / log2 (1 ulp; the sum lies in [1, 3], so no denormal fix-ups are needed), branch-free:
+            // with every term -inf the floor keeps (x - m) = -inf, the sum is 0 and log2 returns -inf
+            constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+            auto lse2 = [&](float x, float y) {
+                const float m = fmaxf(fmaxf(x, y), -3.0e38f);
+                return m + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((x - m) * LOG2E) + __builtin_amdgcn_exp2f((y - m) * LOG2E));
+            };
+            auto lse3 = [&](float x, float y, float z) {
+                const float m = fmaxf(fmaxf(fmaxf(x, y), z), -3.0e38f);
+                return m + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((x - m) * LOG2E) + __builtin_amdgcn_exp2f((y - m) * LOG2E) +
+                                                       __builtin_amdgcn_exp2f((z - m) * LOG2E));
+            };
+            // States past the sample's lattice (s >= L) need no masking: beta's only ever see -inf (nothing above them is initialised),
+            // alpha's turn finite but feed nothing below them; they are simply not stored.
+            const int t0 = alpha ? 0 : Tb - 1, dt = alpha ? 1 : -1;
+            const float* pbp = lp + blank + (long long)t0 * V;   // this frame's log-probabilities (blank / the lane's label), stepped by dt * V
+            const float* pep = lp + e + (long long)t0 * V;
+            float* latp = (alpha ? aw : bw) + (long long)t0 * Lmax + 2 * i;
+            const int dV = dt * V, dL = dt * Lmax;
+            const int ninf = __builtin_bit_cast(int, -INFINITY);
+            float v0 = -INFINITY, v1 = -INFINITY;
+            float pb = Tb > 0 ? *pbp : 0.f, pe = Tb > 0 ? *pep : 0.f;
+            for (int step = 0; step < Tb; ++step) {
+                const int adv = (step + 1 < Tb) ? 1 : 0;
+                const float nb = pbp[adv * dV], ne = pep[adv * dV];   // next frame's log-probabilities, requested a step ahead
                 if (step == 0) {
-                    v = (is_alpha ? (s < 2) : (s >= L - 2)) ? lpv : -INFINITY;
-                } else if (is_alpha) {
-                    const float a0 = prev[s];
-                    const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-                    const float a2 = skipa ? prev[s - 2] : -INFINITY;
-                    v = log_add3(a0, a1, a2) + lpv;
+                    if (alpha) { v0 = (i == 0) ? pb : -INFINITY; v1 = (i == 0 && live1) ? pe : -INFINITY; }
+                    else { v0 = (2 * i == L - 1) ? pb : -INFINITY; v1 = (live1 && 2 * i + 1 == L - 2) ? pe : -INFINITY; }
+                } else if (alpha) {
+                    const float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x138, 0xF, 0xF, false));   // wave_shr:1: state 2i-1
+                    const float n0 = lse2(v0, pl) + pb;
+                    v1 = lse3(v1, v0, skipa ? pl : -INFINITY) + pe;
+                    v0 = n0;
                 } else {
-                    const float b0 = prev[s];
-                    const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
-                    const float b2 = skipb ? prev[s + 2] : -INFINITY;
-                    v = log_add3(b0, b1, b2) + lpv;
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v0), 0x130, 0xF, 0xF, false));   // wave_shl:1: state 2i+2
+                    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x130, 0xF, 0xF, false));   // state 2i+3
+                    v0 = lse2(v0, v1) + pb;
+                    v1 = lse3(v1, r0, skipb ? r1 : -INFINITY) + pe;
                 }
-                cur[s] = v; lat[(long long)t * Lmax + s] = v;
+                if (live0) latp[0] = v0;
+                if (live1) latp[1] = v1;
+                pb = nb; pe = ne;
+                pbp += adv * dV; pep += adv * dV; latp += dL;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's row write has landed in LDS
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            if (alpha && Tb > 0) {   // the last row, where the tail below expects it
+                float* last = rowA + ((Tb - 1) & 1) * Lmax;
+                if (live0) last[2 * i] = v0;
+                if (live1) last[2 * i + 1] = v1;
+            }
         }
     } else
     for (int step = 0; step < Tb; ++step) {
@@ -951,18 +985,19 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
         for (int i = tid; i < (c1 - c0) * V; i += 256) occ[i] = 0.f;
         __syncthreads();
         // wave w takes frames c0 + w, + 4, ...; lanes run along the states. Four frames' lattice rows are loaded together:
-        // they were just written by this block and come back from L2 (~1 us each if taken one by one).
-        for (int t0 = c0 + (tid >> 6); t0 < c1; t0 += 16) {
+        // they were just written by this block and come back from L2 (~1 us each if taken one by one; eight together measured no faster).
+        constexpr int NF = 4;
+        for (int t0 = c0 + (tid >> 6); t0 < c1; t0 += 4 * NF) {
             for (int s = tid & 63; s < L; s += 64) {
-                float ab[4];
+                float ab[NF];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NF; ++k) {
                     const int t = t0 + 4 * k;
                     ab[k] = t < c1 ? aw[(long long)t * Lmax + s] + bw[(long long)t * Lmax + s] : -INFINITY;
                 }
                 const int e = ext[s];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NF; ++k) {
                     const int t = t0 + 4 * k;
                     if (ab[k] > -INFINITY) atomicAdd(&occ[(t - c0) * V + e], expf(ab[k] - lp[(long long)t * V + e] + nll));
                 }
