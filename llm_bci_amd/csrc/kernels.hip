@@ -1012,6 +1012,148 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ pred
     }
 }
 
+// ---- "meet in the middle" variant (2S + 1 <= 128 and everything fits the 160 KB LDS: the train step's shape) -----------------------
+// The plain kernel above runs the alpha and beta recursions over ALL frames (30 us at 143 frames), writes both lattices to the
+// workspace and then spends another 38 us reading them back for the occupancy sums. Here wave 0 runs alpha over the first half of
+// the frames and wave 1 runs beta over the second half, both keeping their rows in LDS; after one barrier each wave continues into
+// the half where the OTHER lattice is already known, so the posterior exp(alpha + beta - lp + nll) of a frame is formed in the same
+// step that produces the frame's row — no lattice in HBM, no separate occupancy pass. The likelihood comes from the identity
+// P = sum_s alpha_t(s) beta_t(s) / y_t(s) (any t) at the first frame each wave has both rows for.
+template <typename TD>
+__global__ __launch_bounds__(256) void ctc_mid_kernel(const float* __restrict__ preds, const int64_t* __restrict__ targets,
+                                                      const int32_t* __restrict__ in_lens, const int64_t* __restrict__ tgt_lens,
+                                                      int Tp, int V, int S, int blank, int zero_inf, float* __restrict__ loss,
+                                                      TD* __restrict__ dlogits, int ldd, float grad_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Lmax = 2 * S + 1, Hm = (Tp + 1) / 2;
+    float* latA = sm;                      // [Hm][Lmax] alpha rows of frames [0, m)
+    float* latB = latA + Hm * Lmax;        // [Hm][Lmax] beta rows of frames [m, Tb): row t - m
+    float* occ = latB + Hm * Lmax;         // [Tp][V] posterior mass per (frame, class)
+    float* lpl = occ + Tp * V;             // [Tp][V] staged log-probabilities
+    int* ext = (int*)(lpl + Tp * V);       // [Lmax]
+    __shared__ float s_nll;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int Tb = in_lens[b];
+    if (Tb > Tp) Tb = Tp;
+    if (Tb < 0) Tb = 0;
+    int Sb = (int)tgt_lens[b];
+    if (Sb > S) Sb = S;
+    const int L = 2 * Sb + 1;
+    const float* lpg = preds + (long long)b * Tp * V;
+    {
+        const int n = Tb * V;
+        for (int base = 0; base < n; base += 256 * 8) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = base + k * 256 + tid; r[k] = i < n ? lpg[i] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = base + k * 256 + tid; if (i < n) { lpl[i] = r[k]; occ[i] = 0.f; } }
+        }
+    }
+    for (int s = tid; s < L; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * S + (s >> 1)] : blank;
+    if (tid == 0) s_nll = (Tb == 0 && Sb == 0) ? 0.f : INFINITY;   // (Tb = 0: the empty path has probability 1 for an empty target only)
+    __syncthreads();
+    const int wv = tid >> 6, i = tid & 63;
+    const int m = Tb / 2;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const bool alpha = wv == 0;
+    const bool live0 = 2 * i < L, live1 = 2 * i + 1 < L;
+    const int e = (wv < 2 && live1) ? ext[2 * i + 1] : blank;
+    const bool skipa = wv < 2 && live1 && i >= 1 && e != blank && e != ext[2 * i - 1];
+    const bool skipb = wv < 2 && live1 && 2 * i + 3 < L && ext[2 * i + 3] != blank && ext[2 * i + 3] != e;
+    auto lse2 = [&](float x, float y) {
+        const float mx = fmaxf(fmaxf(x, y), -3.0e38f);
+        return mx + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((x - mx) * LOG2E) + __builtin_amdgcn_exp2f((y - mx) * LOG2E));
+    };
+    auto lse3 = [&](float x, float y, float z) {
+        const float mx = fmaxf(fmaxf(fmaxf(x, y), z), -3.0e38f);
+        return mx + LN2 * __builtin_amdgcn_logf(__builtin_amdgcn_exp2f((x - mx) * LOG2E) + __builtin_amdgcn_exp2f((y - mx) * LOG2E) +
+                                                __builtin_amdgcn_exp2f((z - mx) * LOG2E));
+    };
+    const int ninf = __builtin_bit_cast(int, -INFINITY);
+    float v0 = -INFINITY, v1 = -INFINITY;
+    const float* lpb = lpl + blank;
+    const float* lpe = lpl + e;
+    // one frame of the recursion for this wave's lattice (states past L need no masking: see ctc_kernel)
+    auto frame = [&](int t, float pb, float pe) {
+        if (alpha) {
+            if (t == 0) { v0 = (i == 0) ? pb : -INFINITY; v1 = (i == 0 && live1) ? pe : -INFINITY; }
+            else {
+                const float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x138, 0xF, 0xF, false));   // wave_shr:1
+                const float n0 = lse2(v0, pl) + pb;
+                v1 = lse3(v1, v0, skipa ? pl : -INFINITY) + pe;
+                v0 = n0;
+            }
+        } else {
+            if (t == Tb - 1) { v0 = (2 * i == L - 1) ? pb : -INFINITY; v1 = (live1 && 2 * i + 1 == L - 2) ? pe : -INFINITY; }
+            else {
+                const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v0), 0x130, 0xF, 0xF, false));   // wave_shl:1
+                const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x130, 0xF, 0xF, false));
+                v0 = lse2(v0, v1) + pb;
+                v1 = lse3(v1, r0, skipb ? r1 : -INFINITY) + pe;
+            }
+        }
+    };
+    if (wv < 2 && Tb > 0) {
+        // ---- first half: rows to LDS
+        const int t_first = alpha ? 0 : Tb - 1, n1 = alpha ? m : Tb - m, dt = alpha ? 1 : -1;
+        float* lat = alpha ? latA : latB - (long long)m * Lmax;   // row t of the wave's own lattice
+        int t = t_first;
+        float pb = lpb[t * V], pe = lpe[t * V];
+        for (int step = 0; step < n1; ++step) {
+            const int tn = t + dt, tc = min(max(tn, 0), Tb - 1);
+            const float nb = lpb[tc * V], ne = lpe[tc * V];
+            frame(t, pb, pe);
+            if (live0) lat[t * Lmax + 2 * i] = v0;
+            if (live1) lat[t * Lmax + 2 * i + 1] = v1;
+            pb = nb; pe = ne; t = tn;
+        }
+    }
+    __syncthreads();
+    float nll = INFINITY;
+    if (wv < 2 && Tb > 0) {
+        // ---- second half: the other wave's rows are known, the posterior is formed on the spot
+        const int n2 = alpha ? Tb - m : m, dt = alpha ? 1 : -1;
+        const float* oth = alpha ? latB - (long long)m * Lmax : latA;   // row t of the OTHER lattice
+        int t = alpha ? m : m - 1;
+        float pb = n2 > 0 ? lpb[t * V] : 0.f, pe = n2 > 0 ? lpe[t * V] : 0.f;
+        for (int step = 0; step < n2; ++step) {
+            const int tn = t + dt, tc = min(max(tn, 0), Tb - 1);
+            const float nb = lpb[tc * V], ne = lpe[tc * V];
+            const float o0 = live0 ? oth[t * Lmax + 2 * i] : -INFINITY, o1 = live1 ? oth[t * Lmax + 2 * i + 1] : -INFINITY;
+            frame(t, pb, pe);
+            const float x0 = live0 ? v0 + o0 - pb : -INFINITY, x1 = live1 ? v1 + o1 - pe : -INFINITY;   // log alpha beta / y
+            if (step == 0) {   // log-likelihood = logsumexp over the states of this frame
+                const float mx = wave_max(fmaxf(x0, x1));
+                if (mx > -INFINITY) {
+                    const float sm2 = wave_sum(expf(x0 - mx) + expf(x1 - mx));
+                    nll = -(mx + logf(sm2));
+                }
+                if (alpha && i == 0) s_nll = nll;
+            }
+            if (nll < INFINITY) {
+                if (x0 > -INFINITY) atomicAdd(&occ[t * V + blank], __builtin_amdgcn_exp2f((x0 + nll) * LOG2E));
+                if (x1 > -INFINITY) atomicAdd(&occ[t * V + e], __builtin_amdgcn_exp2f((x1 + nll) * LOG2E));
+            }
+            pb = nb; pe = ne; t = tn;
+        }
+    }
+    __syncthreads();
+    nll = s_nll;
+    const bool finite = nll < INFINITY;
+    if (tid == 0) loss[b] = finite ? nll : (zero_inf ? 0.f : INFINITY);
+    if (!dlogits) return;
+    // rows beyond the input length (and whole infeasible samples) get zero gradient
+    const int tz = finite ? Tb : 0;
+    for (long long k = tid + (long long)tz * ldd; k < (long long)Tp * ldd; k += 256) stf<TD>(dlogits, (long long)b * Tp * ldd + k, 0.f);
+    if (!finite || Tb == 0) return;
+    for (int k = tid; k < Tb * ldd; k += 256) {
+        const int t = k / ldd, c = k % ldd;
+        const float v = (c < V) ? (expf(lpl[t * V + c]) - occ[t * V + c]) * grad_scale : 0.f;
+        stf<TD>(dlogits, ((long long)b * Tp + t) * ldd + c, v);
+    }
+}
+
 int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_lens, const int64_t* tgt_lens, int B, int Tp,
                int V, int S, int blank, int zero_infinity, float* loss, float* alpha_ws, void* dlogits, int d_dtype,
                int ldd, float grad_scale, hipStream_t s) {
@@ -1019,6 +1161,23 @@ int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_len
     NBCI_REQUIRE(fixed + 16 * per_frame <= 64000, NBCI_ESHAPE, "ctc: targets x vocab too large for the LDS-resident lattice rows");
     NBCI_REQUIRE(blank >= 0 && blank < V, NBCI_EINVAL, "ctc: blank id out of range");
     const size_t lds1 = fixed + (size_t)Tp * per_frame, lds2 = lds1 + (size_t)Tp * per_frame;
+    const size_t lds_mid = ((size_t)2 * ((Tp + 1) / 2) * (2 * S + 1) + (size_t)2 * Tp * V + (2 * S + 1)) * sizeof(float);
+    static const bool mid_on = [] { const char* e = getenv("NBCI_CTC_MID"); return !(e && e[0] == '0'); }();
+    if (mid_on && 2 * S + 1 <= 128 && lds_mid <= 160000) {   // both half lattices, the log-probabilities and the posteriors in LDS: no workspace traffic
+        static bool attr_f = false, attr_b = false;
+        bool& attr = d_dtype == NBCI_BF16 ? attr_b : attr_f;
+        if (!attr && lds_mid > 65536) {
+            hipError_t er = d_dtype == NBCI_BF16
+                                ? hipFuncSetAttribute((const void*)ctc_mid_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000)
+                                : hipFuncSetAttribute((const void*)ctc_mid_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
+            if (er != hipSuccess) return fail(NBCI_EHIP, std::string("ctc: LDS attribute: ") + hipGetErrorString(er));
+            attr = true;
+        }
+        DISPATCH_DTYPE(d_dtype, TD,
+                       hipLaunchKernelGGL((ctc_mid_kernel<TD>), dim3(B), dim3(256), lds_mid, s, preds, targets, in_lens, tgt_lens, Tp, V, S, blank,
+                                          zero_infinity, loss, (TD*)dlogits, ldd, grad_scale));
+        return check_launch("ctc");
+    }
     if (lds2 <= 64000) {   // room to stage the log-probabilities as well
         DISPATCH_DTYPE(d_dtype, TD,
                        hipLaunchKernelGGL((ctc_kernel<TD, true>), dim3(B), dim3(256), lds2, s, preds, targets, in_lens, tgt_lens, Tp, V,
