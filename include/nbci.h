@@ -269,7 +269,7 @@ int nbci_debug_gemm_pc(int32_t mode);
 /* Measurement / test aid: how nbci_gemm_grouped launches a group of direct-to-LDS problems (K % 64 == 0): 0 = one workgroup per
  * 128 x 128 output tile, 1 = deal the K tiles of all output tiles out evenly over the chip's workgroup slots when one workgroup
  * per tile would leave more than 12 % of the slot-rounds empty (default; gemm_streamk.hip: partial tiles go through a scratch buffer
- * of 64 KB per slot that the library keeps per (device, stream); fixed summation order, no atomics), 2 = always, 3 = always and with the owner / helper ("aligned") scheme wherever it applies. Initial value:
+ * of 64 KB per slot that the library keeps per (device, stream); fixed summation order, no atomics), 2 = always, 3 = always and with the owner / helper ("aligned") scheme wherever it applies, 4 = always and with the block-per-XCD scheme wherever it applies. Initial value:
  * NBCI_STREAMK. The reference has no counterpart (a layer's weight gradients are four cuBLAS calls inside loss.backward(),
  * models/trainer.py:339). */
 int nbci_debug_gemm_streamk(int32_t mode);

@@ -102,7 +102,7 @@ int nbci_gemm_fp8(const void* A8, const void* sA, const void* W8, const void* sW
 }
 int nbci_debug_gemm_pc(int32_t mode) { nbci::gemm_pc_set_mode(mode); return NBCI_OK; }
 int nbci_debug_gemm_streamk(int32_t mode) {
-    if (mode < 0 || mode > 3) return nbci::fail(NBCI_EINVAL, "stream-K mode must be 0 .. 3");
+    if (mode < 0 || mode > 4) return nbci::fail(NBCI_EINVAL, "stream-K mode must be 0 .. 4");
     nbci::gemm_streamk_set_mode(mode);
     return NBCI_OK;
 }

@@ -45,6 +45,7 @@ struct StreamK {
     int epoch;
     int dbg;                       // measurement only: 1 = no partial exchange at all (wrong results)
     int aligned, q, lk, ex, tx, r, maxp;   // aligned scheme (see the kernel): owner K tiles, remainder, helpers and tiles per XCD, tiles per helper (0: not integral), slots per helper
+    int nb;                        // aligned == 2 (blocked scheme): number of 64-tile blocks = owner XCDs
     GemmK sub[SK_MAX];
 };
 
@@ -69,6 +70,14 @@ __device__ __forceinline__ int sk_iter_of_tile(const StreamK& s, int gtile) {   
 }
 // run j of an XCD whose K tiles are [i0, i0 + len): [i0 + j len / wpx, i0 + (j + 1) len / wpx)
 __device__ __forceinline__ int sk_run_begin(int i0, int len, int wpx, int j) { return i0 + (int)(((long long)j * len) / wpx); }
+
+// a pointer the inline asm below takes as a SCALAR base: made wave-uniform explicitly (the "s" constraint does not insert the readfirstlane
+// when the compiler keeps a — provably uniform — value in vector registers)
+__device__ __forceinline__ float4* sk_uniform(float4* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (float4*)(((unsigned long long)hi << 32) | lo);
+}
 
 // One piece: K tiles [kb, ke) of output tile `tile` of problem p. write_slot >= 0: a contributor piece, the raw accumulators go to that
 // scratch slot and its flag is raised; otherwise an owner piece: the partials in slot_of(0 .. nadd-1) are added (in that order) and the
@@ -128,7 +137,7 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
     }
     if (write_slot >= 0) {
         if (!(s.dbg & 1)) {
-            float4* slot = (float4*)s.partial + (size_t)write_slot * (MI * NI * GEMM_THREADS);
+            float4* slot = sk_uniform((float4*)s.partial + (size_t)write_slot * (MI * NI * GEMM_THREADS));
             // write-through stores (sc0 sc1: past every non-coherent cache level), acknowledged before the flag goes out: no cache-wide
             // writeback / invalidate, which would also throw out the operand panels the other workgroups are reusing.
             // (s_nop 4: the scalar base may have just been written by a VALU instruction — v_readlane of a spilled SGPR — and the hazard
@@ -146,7 +155,7 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
     }
     for (int i = 0; i < nadd && !(s.dbg & 1); ++i) {
         const int sl = slot_of(i);
-        const float4* slot = (const float4*)s.partial + (size_t)sl * (MI * NI * GEMM_THREADS);
+        const float4* slot = sk_uniform((float4*)s.partial + (size_t)sl * (MI * NI * GEMM_THREADS));
         if (t == 0) {
             while (__hip_atomic_load(s.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) __builtin_amdgcn_s_sleep(8);
         }
@@ -158,7 +167,9 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
 #pragma unroll
             for (int b = 0; b < NI; ++b)
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(v[b]) : "v"(t * 16), "s"(slot + (a * NI + b) * GEMM_THREADS) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the loaded registers are operands of the wait: the adds below must not be scheduled above it)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+            static_assert(NI == 4, "the wait names the four loaded registers");
 #pragma unroll
             for (int b = 0; b < NI; ++b) acc[a][b] += v[b];
         }
@@ -168,9 +179,40 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
 }
 
 template <bool AK, bool BKM>
-__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_streamk_kernel(StreamK s) {
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_streamk_kernel(StreamK s_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The description is read where it lies, in the kernel-argument segment (it is the only argument: offset 0). Indexing the by-value
+    // copy with a run-time problem number made the compiler move the whole 2 KB struct to scratch once a third call site appeared.
+    const StreamK& s = *(const StreamK*)__builtin_amdgcn_kernarg_segment_ptr();
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (s.aligned == 2) {
+        // ---- blocked scheme (the NDT1 layer group: six blocks of 8 x 8 tiles, one K, 512 slots). A block's 64 tiles share 8 + 8
+        // operand panels; with its 64 owner workgroups on ONE XCD, all in lockstep over K tiles [0, q), every panel slab crosses the
+        // fabric once for that XCD instead of once per XCD that holds some of the block's tiles. The remaining XCDs run the helpers:
+        // workgroup j of helper XCD hx does K tiles [q, kt) of tile j in each of its `per` blocks, one after the other — again 64
+        // workgroups in lockstep on one block. Helper j serves owner j (block indices within 8 of each other: dispatched together).
+        const int nb = s.nb, per = nb / (8 - nb);
+        if (j >= 64) return;
+        if (xcd >= nb) {
+            const int hx = xcd - nb;
+            for (int k = 0; k < per; ++k) {
+                const int gt = (hx * per + k) * 64 + j;
+                int p = 0;
+#pragma unroll
+                for (int i = 1; i < SK_MAX; ++i)
+                    if (i < s.n && gt >= s.tile_start[i]) p = i;
+                sk_piece<AK, BKM>(s, smem, p, gt - s.tile_start[p], s.q, s.kt[0], (int)blockIdx.x * s.maxp + k, 0, [](int) { return 0; });
+            }
+            return;
+        }
+        const int gt = xcd * 64 + j;
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < SK_MAX; ++i)
+            if (i < s.n && gt >= s.tile_start[i]) p = i;
+        sk_piece<AK, BKM>(s, smem, p, gt - s.tile_start[p], 0, s.q, -1, 1, [&](int) { return (j * 8 + nb + xcd / per) * s.maxp + xcd % per; });
+        return;
+    }
     if (s.aligned) {
         // ---- aligned scheme (all problems share K, fewer tiles than slots): the XCD's tx tiles have one OWNER workgroup each (blocks
         // j >= ex) doing K tiles [0, q) in lockstep — same panel reuse as one workgroup per tile — and ex HELPER workgroups (j < ex,
@@ -339,7 +381,23 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
     // themselves: with tiles / slots = a / b in lowest terms there are b phase classes; up to 4 (the NDT1 layer group: 3 / 4) the
     // contiguous scheme measured faster inside the train step (140 vs 148 us per launch), beyond it the aligned one (iTransformer
     // group, 21 / 32: 318 vs 374 us). NBCI_STREAMK_ALIGNED=0 / 1 forces never / whenever it applies (A/B); mode 3 does the latter too.
-    s.aligned = 0; s.q = s.lk = s.ex = s.tx = s.r = 0; s.maxp = 1;
+    s.aligned = 0; s.q = s.lk = s.ex = s.tx = s.r = 0; s.maxp = 1; s.nb = 0;
+    {   // blocked scheme: every problem a whole number of 64-tile blocks with 8 tile columns, one K, 4 / 6 / 7 blocks on 512 slots.
+        // OFF unless asked for (mode 4 or NBCI_STREAMK_BLOCKED=1): on the NDT1 layer group it halves the fabric traffic (FETCH_SIZE
+        // 591 -> 279 MB per launch against 187 MB algorithmic) and is nevertheless 3 % slower inside the step (143.4 vs 138.8 us).
+        static const bool env_blocked = [] { const char* e = getenv("NBCI_STREAMK_BLOCKED"); return e && e[0] == '1'; }();
+        bool ok = (env_blocked || gemm_streamk_mode() == 4) && slots == 512 && tiles % 64 == 0;
+        for (int i = 0; i < n && ok; ++i) ok = s.kt[i] == s.kt[0] && s.sub[i].tiles_n == 8 && s.sub[i].tiles_m % 8 == 0;
+        const int nb = tiles / 64;
+        if (ok && (nb == 4 || nb == 6 || nb == 7)) {
+            const int per = nb / (8 - nb);
+            const int q = (s.kt[0] * nb + 7) / 8;
+            if (q < s.kt[0] && per <= SK_MAXP) {
+                s.aligned = 2; s.nb = nb; s.q = q; s.lk = s.kt[0] - q; s.maxp = per;
+                return true;
+            }
+        }
+    }
     static const int env_aligned = [] { const char* e = getenv("NBCI_STREAMK_ALIGNED"); return e ? atoi(e) : -1; }();
     const bool no_aligned = env_aligned == 0;
     bool want = env_aligned == 1 || gemm_streamk_mode() == 3;
@@ -386,7 +444,7 @@ int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hip
     const bool ak = descs[0].A.kmajor != 0, bk = descs[0].B.kmajor != 0;
     const int slots = 8 * s.wpx;
     SkScratch sc;
-    int rc = sk_scratch(stream, slots * (s.aligned ? s.maxp : 1), sc);
+    int rc = sk_scratch(stream, slots * (s.aligned ? s.maxp : 1), sc);   // (slot index = block index x maxp + piece)
     if (rc != NBCI_OK) return rc;
     s.partial = sc.partial;
     s.flags = sc.flags;

@@ -60,6 +60,9 @@ GROUPS = {
     "more_tiles_than_slots": [(3840, 1280, 1024), (2560, 1280, 1024)],
     # K differs per problem
     "mixed_k": [(256, 384, 4096), (384, 256, 8200), (1024, 512, 2048)],   # (8200: a partial last K tile rides with the piece that ends the tile)
+    # blocked scheme with four and with seven blocks (one / seven remainders per helper workgroup)
+    "blocked_4_blocks": [(1024, 1024, 4096)] * 4,
+    "blocked_7_blocks": [(3072, 1024, 2048)] + [(1024, 1024, 2048)] * 4,
     # aligned scheme, tiles per helper not integral (336 tiles: 42 owners + 22 helpers per XCD), ragged last row tile
     "aligned_336_tiles": [(2304, 768, 4112), (768, 768, 4112), (2040, 768, 4112), (768, 2048, 4112)],   # K = 64 x 64 + 16
     # aligned scheme, more helpers than tiles: every remainder is split between several helpers
@@ -70,14 +73,16 @@ GROUPS = {
 @pytest.mark.parametrize("name", list(GROUPS))
 @pytest.mark.parametrize("ak,bk", [(False, False), (True, True), (True, False), (False, True)])
 def test_streamk_group_exact(name, ak, bk):
-    if name in ("layer_wgrad", "aligned_336_tiles") and (ak or bk) and not (ak and bk):
+    if name in ("layer_wgrad", "aligned_336_tiles", "blocked_7_blocks") and (ak or bk) and not (ak and bk):
         pytest.skip("the large cases run in the weight-gradient and forward layouts only")
-    _run_group(GROUPS[name], ak, bk, mode=3 if name.startswith("aligned") else 2)
+    _run_group(GROUPS[name], ak, bk, mode=3 if name.startswith("aligned") else (4 if name.startswith("blocked") else 2))
 
 
 def test_layer_group_in_the_aligned_scheme_too():
-    """the shipped rule gives the layer group the contiguous scheme (3/4 tile per workgroup: phases align by themselves); the aligned one must agree"""
+    """the shipped rule gives the layer group the contiguous scheme; the aligned (mode 3) and the blocked one (mode 4: six 8 x 8 blocks,
+    one per XCD) must agree"""
     _run_group(GROUPS["layer_wgrad"], False, False, mode=3)
+    _run_group(GROUPS["layer_wgrad"], False, False, mode=4)
 
 
 def test_streamk_default_rule_and_plain_assign():
