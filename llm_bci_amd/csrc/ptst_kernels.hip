@@ -154,21 +154,42 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // combine the chunk partials (Chan et al.), produce mean / rstd for the normalisation and update the running statistics
 // (momentum 0.1, unbiased variance) in train mode; in eval mode just turn the running statistics into mean / rstd.
+// One block = 16 channels x 16 groups: group g combines chunks g, g + 16, ... in order, then the 16 group results are combined in
+// order by the channel's first thread (a fixed tree: deterministic). One thread per channel walking all chunks — 820 dependent
+// double-precision updates at 420 k rows — took 270 us per call, three times the parallel statistics pass it follows.
+constexpr int BN_FG = 16;   // groups (and channels) per block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunks, long long M, int D, float eps,
                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, int train) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    if (!train) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); return; }
+    __shared__ double sn[BN_FG][BN_FG], smu[BN_FG][BN_FG], sm2[BN_FG][BN_FG];
+    const int cl = threadIdx.x % BN_FG, g = threadIdx.x / BN_FG;
+    const int c = blockIdx.x * BN_FG + cl;
+    if (!train) {
+        if (g == 0 && c < D) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); }
+        return;
+    }
     double n = 0.0, mu = 0.0, m2 = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nchunks; ++k) {
-        const long long r0 = (long long)k * BN_ROWS;
-        const double nb = (double)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
-        const double mb = part[((long long)k * 2) * D + c], m2b = part[((long long)k * 2 + 1) * D + c];
-        const double delta = mb - mu, tot = n + nb;
+    if (c < D) {
+#pragma unroll 4
+        for (int k = g; k < nchunks; k += BN_FG) {
+            const long long r0 = (long long)k * BN_ROWS;
+            const double nb = (double)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
+            const double mb = part[((long long)k * 2) * D + c], m2b = part[((long long)k * 2 + 1) * D + c];
+            const double delta = mb - mu, tot = n + nb;
+            mu += delta * nb / tot;
+            m2 += m2b + delta * delta * n * nb / tot;
+            n = tot;
+        }
+    }
+    sn[g][cl] = n; smu[g][cl] = mu; sm2[g][cl] = m2;
+    __syncthreads();
+    if (g != 0 || c >= D) return;
+    for (int j = 1; j < BN_FG; ++j) {
+        const double nb = sn[j][cl];
+        if (nb == 0.0) continue;
+        const double delta = smu[j][cl] - mu, tot = n + nb;
         mu += delta * nb / tot;
-        m2 += m2b + delta * delta * n * nb / tot;
+        m2 += sm2[j][cl] + delta * delta * n * nb / tot;
         n = tot;
     }
     const double var = m2 / n;
@@ -236,7 +257,7 @@ int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* 
         int rc = check_launch("bn_stats");
         if (rc != NBCI_OK) return rc;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partials, nchunks, M, D, eps, mean, rstd, run_mean, run_var, train);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + BN_FG - 1) / BN_FG), dim3(256), 0, s, partials, nchunks, M, D, eps, mean, rstd, run_mean, run_var, train);
     int rc = check_launch("bn_finalize");
     if (rc != NBCI_OK) return rc;
     const long long n4 = M * D / 4;
@@ -269,11 +290,18 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int D, float* __restrict__ sums,
                                                               float* __restrict__ dw, float* __restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    __shared__ double sa[BN_FG][BN_FG], sb[BN_FG][BN_FG];   // (16 channels x 16 groups per block, fixed combination order: see bn_finalize_kernel)
+    const int cl = threadIdx.x % BN_FG, g = threadIdx.x / BN_FG;
+    const int c = blockIdx.x * BN_FG + cl;
     double a = 0.0, b = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nchunks; ++k) { a += part[((long long)k * 2) * D + c]; b += part[((long long)k * 2 + 1) * D + c]; }
+    if (c < D) {
+#pragma unroll 4
+        for (int k = g; k < nchunks; k += BN_FG) { a += part[((long long)k * 2) * D + c]; b += part[((long long)k * 2 + 1) * D + c]; }
+    }
+    sa[g][cl] = a; sb[g][cl] = b;
+    __syncthreads();
+    if (g != 0 || c >= D) return;
+    for (int j = 1; j < BN_FG; ++j) { a += sa[j][cl]; b += sb[j][cl]; }
     sums[c] = (float)a; sums[D + c] = (float)b;
     db[c] += (float)a; dw[c] += (float)b;
 }
@@ -308,7 +336,7 @@ int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, con
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, dy, x, mean, rstd, partials, M, D);
     int rc = check_launch("bn_bwd_stats");
     if (rc != NBCI_OK) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partials, nchunks, D, sums, dw, db);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + BN_FG - 1) / BN_FG), dim3(256), 0, s, partials, nchunks, D, sums, dw, db);
     rc = check_launch("bn_bwd_finalize");
     if (rc != NBCI_OK) return rc;
     const long long n4 = M * D / 4;
