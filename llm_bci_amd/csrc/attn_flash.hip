@@ -122,7 +122,7 @@ __device__ __forceinline__ void fa_to_image(char* img, const bf16x8 (&f)[2][HD /
 #endif
 constexpr int NQ = FA_NQ;
 
-template <int HD, bool TAIL, bool MASK>
+template <int HD, bool TAIL, bool MASK, int NQ>
 __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
                                             f32x4 (&o)[NQ][HD / 16], float (&m)[NQ], float (&l)[NQ], const unsigned (&rbase)[NQ],
                                             const int (&qidx)[NQ], int sq, int lane) {
@@ -229,7 +229,8 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
     }
 #endif
 
-template <int HD, bool MASK>
+// NQ = 16-query tiles per wave (forward: FA_NQF; the backward kernels keep FA_NQ, they run out of registers beyond two)
+template <int HD, bool MASK, int NQ>
 __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
     const bf16_t* kp = base + a.H + 8 * g;
     const bf16_t* vp = base + 2 * a.H + 8 * g;
 #define FWD_LOAD(B, R0) fa_load<HD>(B, kp, ld, vp, ld, R0, a.S, i16)
-#define FWD_STEP(T, B, R0) fa_fwd_step<HD, T, MASK>(a, img, B, R0, qf, o, m, l, rbase, qidx, sq, lane)
+#define FWD_STEP(T, B, R0) fa_fwd_step<HD, T, MASK, NQ>(a, img, B, R0, qf, o, m, l, rbase, qidx, sq, lane)
     FA_PIPELINE(FWD_LOAD, FWD_STEP)
 #undef FWD_LOAD
 #undef FWD_STEP
@@ -546,8 +547,17 @@ static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32
 template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
-    if (which == 0) hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
-    else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
+    if (which == 0) {
+        // forward: three tiles per wave where the kernel is bound by streaming K / V (head >= 64, long sequences: 551 -> 494 us at
+        // 16 x 8 heads x 1501 x 96, every streamed fragment used three times; same two waves per SIMD), two where the softmax's VALU work
+        // dominates (head 32: 800 vs 1004 us) or the sequence is short; four spills at head 128
+        if (HD >= 64 && a.S >= 400) {
+            dim3 gf(a.NS * a.nh, (a.S + 64 * 3 - 1) / (64 * 3));
+            hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK, 3>), gf, dim3(256), 4 * FA_IMG, s, a);
+        } else {
+            hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK, 2>), g, dim3(256), 4 * FA_IMG, s, a);
+        }
+    } else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
     else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK>), g, dim3(256), 8 * FA_IMG, s, a);
     return check_launch("flash attention");
 }
