@@ -181,7 +181,7 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.scores = bump(cur, w.small_attn ? 0 : (size_t)B * C * nh * P * w.ldS * 4);
     w.dsum = bump(cur, nstat * 4);
     w.bnpart = bump(cur, bn_partial_floats((long long)M, (int)D) * 4);
-    w.bnsums = bump(cur, 2 * D * 4);
+    w.bnsums = bump(cur, 3 * D * 4);   // per-column coefficients of the BatchNorm backward's second pass
     w.dx = bump(cur, M * D * 4);
     w.dtmp = bump(cur, M * D * 4);
     w.cA = bump(cur, M * D * es);

@@ -288,8 +288,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     o[c] = s1; o[D + c] = s2;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int D, float* __restrict__ sums,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int D, float* __restrict__ coef,
+                                                              float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ w,
+                                                              const float* __restrict__ rstd, float invM, int train) {
     __shared__ double sa[BN_FG][BN_FG], sb[BN_FG][BN_FG];   // (16 channels x 16 groups per block, fixed combination order: see bn_finalize_kernel)
     const int cl = threadIdx.x % BN_FG, g = threadIdx.x / BN_FG;
     const int c = blockIdx.x * BN_FG + cl;
@@ -302,32 +303,38 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     __syncthreads();
     if (g != 0 || c >= D) return;
     for (int j = 1; j < BN_FG; ++j) { a += sa[j][cl]; b += sb[j][cl]; }
-    sums[c] = (float)a; sums[D + c] = (float)b;
     db[c] += (float)a; dw[c] += (float)b;
+    // per-column coefficients of pass 2: dx += A dy - B - C (x - mean)
+    const float wr = w[c] * rstd[c];
+    coef[c] = wr;
+    coef[D + c] = train ? wr * (float)a * invM : 0.f;
+    coef[2 * D + c] = train ? wr * rstd[c] * (float)b * invM : 0.f;
 }
 
-// pass 2: dx += w * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M)   (eval mode: dx += dy * w * rstd)
+// pass 2: dx += w * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M)   (eval mode: dx += dy * w * rstd), as dx += A dy - B - C (x - mean)
+// with the per-column A, B, C of the finalize kernel: four vector loads of column data per thread instead of twenty scalar ones, two
+// float4 elements per thread in flight
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ sums,
-                                                           float* __restrict__ dx, long long n4, int D, float invM, int train) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % D);
-    const float4 g = *(const float4*)(dy + i * 4), v = *(const float4*)(x + i * 4);
-    float4 o = *(const float4*)(dx + i * 4);
-    const float gg[4] = {g.x, g.y, g.z, g.w}, vv[4] = {v.x, v.y, v.z, v.w};
-    float oo[4] = {o.x, o.y, o.z, o.w};
+                                                           const float* __restrict__ coef, float* __restrict__ dx, long long n4, int D) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+    float4 g[2], v[2], o[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float rs = rstd[c + e], ww = w[c + e];
-        if (train) {
-            const float xh = (vv[e] - mean[c + e]) * rs;
-            oo[e] += ww * rs * (gg[e] - sums[c + e] * invM - xh * sums[D + c + e] * invM);
-        } else {
-            oo[e] += gg[e] * ww * rs;
-        }
+    for (int u = 0; u < 2; ++u) {
+        const long long i = i0 + u;
+        if (i < n4) { g[u] = *(const float4*)(dy + i * 4); v[u] = *(const float4*)(x + i * 4); o[u] = *(const float4*)(dx + i * 4); }
     }
-    *(float4*)(dx + i * 4) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long long i = i0 + u;
+        if (i >= n4) break;
+        const int c = (int)((i * 4) % D);
+        const float4 A = *(const float4*)(coef + c), B = *(const float4*)(coef + D + c), Cc = *(const float4*)(coef + 2 * D + c), mu = *(const float4*)(mean + c);
+        o[u].x += A.x * g[u].x - B.x - Cc.x * (v[u].x - mu.x);
+        o[u].y += A.y * g[u].y - B.y - Cc.y * (v[u].y - mu.y);
+        o[u].z += A.z * g[u].z - B.z - Cc.z * (v[u].z - mu.z);
+        o[u].w += A.w * g[u].w - B.w - Cc.w * (v[u].w - mu.w);
+        *(float4*)(dx + i * 4) = o[u];
+    }
 }
 
 int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
@@ -336,12 +343,13 @@ int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, con
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, dy, x, mean, rstd, partials, M, D);
     int rc = check_launch("bn_bwd_stats");
     if (rc != NBCI_OK) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + BN_FG - 1) / BN_FG), dim3(256), 0, s, partials, nchunks, D, sums, dw, db);
+    NBCI_REQUIRE(D % 4 == 0, NBCI_ESHAPE, "batchnorm backward: features must be a multiple of 4");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + BN_FG - 1) / BN_FG), dim3(256), 0, s, partials, nchunks, D, sums, dw, db, w, rstd, 1.0f / (float)M,
+                       train);
     rc = check_launch("bn_bwd_finalize");
     if (rc != NBCI_OK) return rc;
     const long long n4 = M * D / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dy, x, mean, rstd, w, sums, dx, n4, D,
-                       1.0f / (float)M, train);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 511) / 512)), dim3(256), 0, s, dy, x, mean, sums, dx, n4, D);
     return check_launch("bn_bwd_apply");
 }
 
