@@ -231,7 +231,7 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
 
 // NQ = 16-query tiles per wave (forward: FA_NQF; the backward kernels keep FA_NQ, they run out of registers beyond two)
 template <int HD, bool MASK, int NQ>
-__global__ __launch_bounds__(256) void fattn_fwd_kernel(FAArgs a) {
+__global__ __launch_bounds__(256, (HD <= 96 && NQ == 2) ? 2 : 1) void fattn_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const F
 }
 
 template <int HD, bool MASK>
-__global__ __launch_bounds__(256) void fattn_bwd_q_kernel(FAArgs a) {
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn_bwd_q_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -548,10 +548,14 @@ template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
     if (which == 0) {
-        // forward: three tiles per wave where the kernel is bound by streaming K / V (head >= 64, long sequences: 551 -> 494 us at
-        // 16 x 8 heads x 1501 x 96, every streamed fragment used three times; same two waves per SIMD), two where the softmax's VALU work
-        // dominates (head 32: 800 vs 1004 us) or the sequence is short; four spills at head 128
-        if (HD >= 64 && a.S >= 400) {
+        // forward: two 16-query tiles per wave. Up to head 96 the kernel (and the dq kernel) is told to fit two waves per SIMD
+        // (__launch_bounds__(256, 2)): left alone the compiler spread 180 + 92 registers over VGPRs and AGPRs for ONE wave per SIMD;
+        // 212 VGPRs, no spill, twice the occupancy: 551 -> 427 us at 16 x 8 heads x 1501 x 96 (dq + dk/dv 1172 -> 1105 us; the dk/dv
+        // kernel spills under the same bound and runs 2 x slower: left alone). Head 128 cannot fit two waves; there three tiles per
+        // wave (every streamed K / V fragment used three times) are worth 5 % on long sequences (139 -> 132 us at 593 tokens), while
+        // at head 96 they lose to the occupancy (495 us) and at head 32 to the softmax's VALU work (758 vs 998 us).
+        static const int env_nqf = [] { const char* e = getenv("NBCI_FA_NQF"); return e ? atoi(e) : 0; }();   // measurement: force 2 or 3
+        if (env_nqf ? env_nqf == 3 : (HD > 96 && a.S >= 400)) {
             dim3 gf(a.NS * a.nh, (a.S + 64 * 3 - 1) / (64 * 3));
             hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK, 3>), gf, dim3(256), 4 * FA_IMG, s, a);
         } else {
