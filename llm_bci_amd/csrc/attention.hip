@@ -49,7 +49,7 @@ __device__ __forceinline__ void load_key_valid(int* kv, const int32_t* tmask_row
 
 // K and V images together, every global load of a pass issued before the first LDS store. (One load -> one store per
 // iteration, as load_image does, exposed a memory round trip per 16-byte chunk: 4.2 of the forward kernel's 15 us.)
-__device__ __forceinline__ void load_images_kv(char* sK, char* sV, const bf16_t* srcK, const bf16_t* srcV, long long ld, int nrows, int tid) {
+__device__ __forceinline__ void load_images_kv(char* sK, char* sV, const bf16_t* srcK, const bf16_t* srcV, long long ld, int nrows, int tid, int krows = AT_TPAD) {
     constexpr int U = 5;   // 2560 chunks per image / 576 threads (143 tokens -> 9 waves)
     const int nthr = (int)blockDim.x;
     for (int i0 = tid; i0 < AT_TPAD * 16; i0 += U * nthr) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void load_images_kv(char* sK, char* sV, const bf16_t*
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * nthr, row = i >> 4, ch = i & 15;
             if (i < AT_TPAD * 16) {
-                *(uint4*)(sK + img_off(row, ch)) = vk[u];
+                if (row < krows) *(uint4*)(sK + img_off(row, ch)) = vk[u];   // (the 9-block forward keeps a 144-row K image)
                 *(uint4*)(sV + img_off(row, ch)) = vv[u];
             }
         }
@@ -120,9 +120,10 @@ struct AttnArgs {
 };
 
 // scores of one 16-query block against all keys: acc[kb][r] = S[query i16][key 16kb + 4g + r]
-__device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4], f32x4 (&acc)[AT_NB], int i16, int g) {
+template <int NB>
+__device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4], f32x4 (&acc)[NB], int i16, int g) {
 #pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb) {
+    for (int kb = 0; kb < NB; ++kb) {
         acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -132,10 +133,11 @@ __device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4
 }
 
 // masked softmax of the register-resident row; returns normalised probabilities in place
-__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs& a, const int* kv, int query, int g, float* lse_out) {
+template <int NB>
+__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[NB], const AttnArgs& a, const int* kv, int query, int g, float* lse_out) {
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb) {
+    for (int kb = 0; kb < NB; ++kb) {
         const int4 k4 = *(const int4*)(kv + 16 * kb + 4 * g);
         const int kvr[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
@@ -151,7 +153,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float e = (acc[kb][r] == -INFINITY) ? 0.f : __expf(acc[kb][r] - mx);
@@ -163,7 +165,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&acc)[AT_NB], const AttnArgs
     const float inv = 1.0f / sum;
     if (lse_out && g == 0) *lse_out = mx + __logf(sum);   // (the diagonal is always attendable: sum > 0)
 #pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[kb][r] *= inv;
 }
@@ -180,18 +182,21 @@ static __device__ unsigned long long g_astamps[1024 * 8];
 #define ASTAMP(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
+// NB = 16-key blocks held per score row: 10 (T' <= 160), or 9 (T' <= 144) with a 144-row K image and at most 102 registers, so that TWO
+// workgroups (18 waves) share a CU and all B x heads workgroups run in one round
+template <int NB>
+__global__ __launch_bounds__(640, NB == 9 ? 5 : 3) void attn_fwd_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ASTAMP(0);
     char* sK = smem;
-    char* sV = smem + AT_TPAD * 256;
+    char* sV = smem + NB * 16 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
-    load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid);
-    int* sKV = (int*)(smem + 2 * AT_TPAD * 256);
+    load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid, NB * 16);
+    int* sKV = (int*)(smem + (NB * 16 + AT_TPAD) * 256);
     load_key_valid(sKV, a.tmask + (long long)b * a.Tp, a.Tp, tid);
     __syncthreads();
     ASTAMP(1);
@@ -202,15 +207,15 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
-        f32x4 acc[AT_NB];
-        score_block(sK, qf, acc, i16, g);
+        f32x4 acc[NB];
+        score_block<NB>(sK, qf, acc, i16, g);
         ASTAMP(2);
-        softmax_rows(acc, a, sKV, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
+        softmax_rows<NB>(acc, a, sKV, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
         ASTAMP(3);
         if (a.p_thr) {
             const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
 #pragma unroll
-            for (int kb = 0; kb < AT_NB; ++kb)
+            for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * kb + 4 * g + r;
@@ -222,8 +227,9 @@ __global__ __launch_bounds__(640) void attn_fwd_kernel(AttnArgs a) {   // one wa
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < AT_NB / 2; ++s) {
-            const bf16x8 pf = pack8(acc[2 * s], acc[2 * s + 1]);
+        for (int s = 0; s < (NB + 1) / 2; ++s) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 pf = pack8(acc[2 * s], 2 * s + 1 < NB ? acc[2 * s + 1] : zero4);   // (NB = 9: the V image keeps 160 zero-padded rows)
 #pragma unroll
             for (int db = 0; db < 8; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, i16), pf,
@@ -461,13 +467,19 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse,
                     uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
     static bool once = false;
-    const int lds = 2 * AT_TPAD * 256 + AT_TPAD * 4;
-    if (!once) { int r = set_lds((const void*)attn_fwd_kernel, lds); if (r) return r; once = true; }
+    const int lds = 2 * AT_TPAD * 256 + AT_TPAD * 4, lds9 = (144 + AT_TPAD) * 256 + AT_TPAD * 4;
+    if (!once) {
+        int r = set_lds((const void*)attn_fwd_kernel<10>, lds); if (r) return r;
+        r = set_lds((const void*)attn_fwd_kernel<9>, lds9); if (r) return r;
+        once = true;
+    }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
     a.ad = (bf16_t*)ad; a.lse = lse;
     const int nblk = (Tp + 15) / 16;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
+    static const bool nb9 = [] { const char* e = getenv("NBCI_ATTN_NB9"); return !(e && e[0] == '0'); }();
+    if (nb9 && Tp <= 144 && nblk >= 2) hipLaunchKernelGGL(attn_fwd_kernel<9>, dim3(B * nh), dim3(64 * nblk), lds9, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<10>, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_fwd: ") + hipGetErrorString(e));
     return NBCI_OK;
