@@ -593,6 +593,12 @@ if __name__ == "__main__" and "--itr" in sys.argv:
     masker_cases()
 
 
+if __name__ == "__main__" and "--itr-wide" in sys.argv:   # the recipe's channel count (configs/itransformer.yaml: 668 channels): sampled fixture
+    _install_torchvision_mlp()
+    itr_case("g_itr_c3w", {"encoder": {"embedder": {"dropout": 0.0}, "dropout": 0.0, "embed_region": False},
+                           "masker": {"main": {"active": True, "regions": None}}}, 2, 668, [100, 73], full=False)
+
+
 # ------------------------------------------------------------------------------------------------
 # PatchTST (models/patchtst.py over transformers' PatchTSTModel) — `--ptst`
 # ------------------------------------------------------------------------------------------------

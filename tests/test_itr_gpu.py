@@ -159,8 +159,9 @@ def test_fp32_matches_reference_golden_tiny(name):
     assert st["n_examples"] == int(fx["n_examples_step0"]) + int(fx["n_examples_step1"])
 
 
-def test_fp32_matches_reference_golden_c3_and_bf16_close():
-    fx = load("g_itr_c3")
+@pytest.mark.parametrize("name", ["g_itr_c3", "g_itr_c3w"])   # 64 channels x 4 samples; the recipe's 668 channels x 2 samples (streaming attention, 669 tokens)
+def test_fp32_matches_reference_golden_c3_and_bf16_close(name):
+    fx = load(name)
     batch = _dev(itr_batch(fx))
     m = _model(fx).to(DEV)
     for k, v in m.state_dict().items():

@@ -79,8 +79,9 @@ def test_itr_tiny_forward_backward_adamw(name):
         assert np.mean(d > 2e-5) < 0.02 and d.max() < 5e-4, (k, d.max())
 
 
-def test_itr_c3_real_shapes():
-    fx = load("g_itr_c3")
+@pytest.mark.parametrize("name", ["g_itr_c3", "g_itr_c3w"])   # 64 channels x 4 samples; the recipe's 668 channels x 2 samples
+def test_itr_c3_real_shapes(name):
+    fx = load(name)
     cfg = itr_cfg(fx)
     import torch
     from llm_bci_amd.itransformer import reference_order_init   # host-side init (pure torch CPU): bit-equal to the reference
@@ -105,7 +106,9 @@ def test_itr_c3_real_shapes():
         gs = fx["gsum:" + k]
         ref = fx["gval:" + k]
         got = g[k].reshape(-1)[fx["gidx:" + k]]
-        np.testing.assert_allclose(got, ref, atol=1e-5 + 1e-3 * max(np.abs(ref).max(), gs[1] / g[k].size), err_msg=k)
+        # (668 channels: the LayerNorm / bias gradients are f32 sums over 1 336 token rows with cancellation; numpy's summation order differs from torch's)
+        tol = 1e-3 if name == "g_itr_c3" else 3e-3
+        np.testing.assert_allclose(got, ref, atol=1e-5 + tol * max(np.abs(ref).max(), gs[1] / g[k].size), err_msg=k)
 
 
 def test_masker_rules_match_reference_structure():
