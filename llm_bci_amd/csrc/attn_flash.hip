@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn_bwd_q_kernel(FAAr
         }
 }
 
-template <int HD, bool TAIL, bool MASK>
+template <int HD, bool TAIL, bool MASK, int NQ>
 __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[NQ][HD / 32],
                                               const bf16x8 (&vf)[NQ][HD / 32], f32x4 (&dk)[NQ][HD / 16], f32x4 (&dv)[NQ][HD / 16], const float* Lu,
                                               const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], const bool (&key_valid)[NQ], int lane) {
@@ -470,8 +470,9 @@ __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char*
     asm volatile("" ::: "memory");
 }
 
-template <int HD, bool MASK>
-__global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
+// NQ = 16-key tiles per wave: two (every streamed Q / dO fragment used twice), or — NBCI_FA_NKV=1, measurement — one tile at two waves per SIMD
+template <int HD, bool MASK, int NQ>
+__global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn_bwd_kv_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void fattn_bwd_kv_kernel(FAArgs a) {
     const bf16_t* qp = base + 8 * g;
     const bf16_t* dp_ = dob + 8 * g;
 #define BK_LOAD(B, R0) fa_load<HD>(B, qp, ld, dp_, (long long)a.H, R0, a.S, i16)
-#define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T, MASK>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, key_valid, lane)
+#define BK_STEP(T, B, R0) fa_bwdkv_step<HD, T, MASK, NQ>(a, imgQ, imgD, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, key_valid, lane)
     FA_PIPELINE(BK_LOAD, BK_STEP)
 #undef BK_LOAD
 #undef BK_STEP
@@ -562,7 +563,15 @@ static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK, 2>), g, dim3(256), 4 * FA_IMG, s, a);
         }
     } else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
-    else hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK>), g, dim3(256), 8 * FA_IMG, s, a);
+    else {
+        static const int env_nkv = [] { const char* e = getenv("NBCI_FA_NKV"); return e ? atoi(e) : 0; }();   // measurement: 1 = one key tile per wave
+        if (env_nkv == 1) {
+            dim3 g1(a.NS * a.nh, (a.S + 64 - 1) / 64);
+            hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK, 1>), g1, dim3(256), 8 * FA_IMG, s, a);
+        } else {
+            hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK, 2>), g, dim3(256), 8 * FA_IMG, s, a);
+        }
+    }
     return check_launch("flash attention");
 }
 
