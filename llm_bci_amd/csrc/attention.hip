@@ -252,16 +252,6 @@ __global__ __launch_bounds__(640, NB == 9 ? 5 : 3) void attn_fwd_kernel(AttnArgs
     ASTAMP(6);
 }
 
-// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15) with four VALU adds — quad swaps, then the mirrored half / row — instead
-// of four ds_bpermute round trips through the LDS crossbar; every lane of the row ends up with the total
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-
 __global__ __launch_bounds__(640) void attn_bwd_dq_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
