@@ -273,6 +273,11 @@ int nbci_debug_gemm_pc(int32_t mode);
  * NBCI_STREAMK. The reference has no counterpart (a layer's weight gradients are four cuBLAS calls inside loss.backward(),
  * models/trainer.py:339). */
 int nbci_debug_gemm_streamk(int32_t mode);
+/* Host-only (no launch, no device access; works without a GPU): how nbci_gemm_grouped would launch this group under the current mode and
+ * nbci_set_available_cus. out8 = {1 if the K tiles are dealt out over all workgroup slots / 0 one workgroup per tile / -1 one launch per
+ * problem, scheme (0 contiguous runs, 1 owner + helper "aligned", 2 block per XCD), workgroups, owner K tiles, remainder K tiles, scratch
+ * slots of 64 KB, output tiles, K tiles per output tile of problem 0}. The pointers in the descriptors are only checked for alignment. */
+int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8);
 /* Frees the scratch buffers the library allocated on its own (the grouped GEMM's partial tiles). Call with the streams idle. */
 int nbci_release_scratch(void);
 int nbci_profile_collect(double* out24);

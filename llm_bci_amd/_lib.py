@@ -185,6 +185,7 @@ _SIGNATURES = {
     "nbci_debug_gemm_pc": (C.c_int, [C.c_int32]),
     "nbci_debug_gemm_streamk": (C.c_int, [C.c_int32]),
     "nbci_release_scratch": (C.c_int, []),
+    "nbci_debug_gemm_grouped_plan": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.POINTER(C.c_int32)]),
     "nbci_mx_quantize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "nbci_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "nbci_comm_unique_id": (C.c_int, [C.c_void_p]),

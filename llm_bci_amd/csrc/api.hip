@@ -107,6 +107,7 @@ int nbci_debug_gemm_streamk(int32_t mode) {
     return NBCI_OK;
 }
 int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
+int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8) { return nbci::gemm_grouped_describe(descs, n, out8); }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");

@@ -239,6 +239,24 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream) {
     return launch_layout<float>(k, d.A.kmajor != 0, d.B.kmajor != 0, grid, stream);
 }
 
+// Host-only: how gemm_grouped_launch would launch this group (nbci_debug_gemm_grouped_plan). out8[0] = -1: one launch per problem.
+void gemm_streamk_describe(const nbci_gemm_desc* descs, const GemmK* ks, int n, int32_t* out8);
+int gemm_grouped_describe(const nbci_gemm_desc* descs, int n, int32_t* out8) {
+    NBCI_REQUIRE(descs && n >= 1 && out8, NBCI_EINVAL, "gemm grouped plan: no problems");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    GemmK ks[6];
+    bool ok = n <= 6;
+    for (int i = 0; i < n && ok; ++i) {
+        int rc = build_gemmk(descs[i], ks[i]);
+        if (rc != NBCI_OK) return rc;
+        ok = descs[i].in_dtype == NBCI_BF16 && ks[i].splitk == 1 && descs[i].batch <= 1 && glds_eligible(descs[i], ks[i]) && !glds_view(descs[i]) &&
+             (descs[i].A.kmajor != 0) == (descs[0].A.kmajor != 0) && (descs[i].B.kmajor != 0) == (descs[0].B.kmajor != 0);
+    }
+    if (!ok) { out8[0] = -1; return NBCI_OK; }
+    gemm_streamk_describe(descs, ks, n, out8);
+    return NBCI_OK;
+}
+
 // Up to 6 independent bf16 GEMMs of one layout in one launch; falls back to one launch each when a
 // problem does not qualify for the direct-to-LDS kernel.
 int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream) {

@@ -438,6 +438,16 @@ bool gemm_streamk_wanted(const nbci_gemm_desc* descs, const GemmK* ks, int n) {
     return (double)tiles / (double)(rounds * slots) < 0.88;   // the classic launch would idle > 12 % of its slot-rounds
 }
 
+// what the grouped launch would do with this group (no launch, no device access): out = {dealt out (0 / 1), scheme (0 contiguous runs,
+// 1 aligned, 2 blocked), workgroups, owner K tiles q, remainder K tiles, scratch slots, tiles, K tiles per tile of problem 0}
+void gemm_streamk_describe(const nbci_gemm_desc* descs, const GemmK* ks, int n, int32_t* out8) {
+    StreamK s;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!gemm_streamk_wanted(descs, ks, n) || !sk_plan(descs, ks, n, s)) return;
+    out8[0] = 1; out8[1] = s.aligned; out8[2] = 8 * s.wpx; out8[3] = s.q; out8[4] = s.lk; out8[5] = 8 * s.wpx * (s.aligned ? s.maxp : 1);
+    out8[6] = s.tile_start[n]; out8[7] = s.kt[0];
+}
+
 int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipStream_t stream) {
     StreamK s;
     NBCI_REQUIRE(sk_plan(descs, ks, n, s), NBCI_EINVAL, "gemm stream-K: group cannot be dealt out");

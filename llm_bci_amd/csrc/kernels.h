@@ -10,6 +10,7 @@ int gemm_launch(const nbci_gemm_desc& d, hipStream_t stream);
 int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream);  // = gemm_launch unless profiling is on
 int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream);        // <= 6 problems, one launch
 int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream);
+int gemm_grouped_describe(const nbci_gemm_desc* descs, int n, int32_t* out8);   // host-only: the launch scheme gemm_grouped_launch would pick
 void gemm_profile_enable(bool on);
 void gemm_pc_set_mode(int m);
 void gemm_streamk_set_mode(int m);   // gemm_streamk.hip: 0 off, 1 where the tile count leaves slots idle, 2 always (nbci_debug_gemm_streamk)
