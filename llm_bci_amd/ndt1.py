@@ -70,9 +70,9 @@ class NDT1(nn.Module):
         super().__init__()
         config = ndt1_config(config)
         self.method = kwargs["method_name"]
-        if self.method not in ("ctc",):
+        if self.method not in ("ctc", "endtoend"):   # the reference treats the two alike everywhere (ndt1.py:488,498,516,580)
             raise Exception(f"Method {self.method} not implemented yet for NDT1 on the HIP path "
-                            "(only 'ctc'; mlm/autoregressive/endtoend stay on the reference implementation)")
+                            "(only 'ctc' / 'endtoend'; mlm / autoregressive stay on the reference implementation)")
         enc = config["encoder"]
         pt_path = enc.pop("from_pt", None)
         if pt_path is not None:  # warm start (ndt1.py:468-476)

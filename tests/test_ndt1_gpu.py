@@ -80,6 +80,23 @@ def test_tiny_golden_fp32(name):
         np.testing.assert_allclose(gv, ref, atol=5e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
 
 
+def test_endtoend_method_is_the_ctc_branch():
+    """ndt1.py:488,498,516,580: the reference handles "endtoend" exactly like "ctc" (trainer_bci.yaml passes it): same head, same loss"""
+    from llm_bci_amd.ndt1 import NDT1
+    fx = load("g_tiny")
+    over = _det_over(str(fx["config_json"]))
+    torch.manual_seed(1)
+    m = NDT1(over, method_name="endtoend", vocab_size=11, blank_id=0, zero_infinity=True, compute_dtype="fp32")
+    m.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w0:")})
+    m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(**_to_dev(batch_of(fx)))
+    np.testing.assert_allclose(out.preds.cpu().numpy(), fx["eval_preds"], atol=1e-3)
+    np.testing.assert_allclose(out.loss.item(), float(fx["eval_loss"]), rtol=1e-4)
+    with pytest.raises(Exception, match="not implemented"):
+        NDT1(over, method_name="mlm", vocab_size=11, blank_id=0, zero_infinity=True)
+
+
 LONG = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
 LONG_CTX = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}, "context": {"forward": 5, "backward": 40}}}
 
