@@ -9,7 +9,14 @@ synthetic batch already resident in HBM: forward (recipe dropout + noise ON) -> 
 backward -> (N>1: overlapped RCCL all-reduce) -> fused AdamW + OneCycle -> zero_grad, plus the
 on-device PER metric the reference computes every step. Workload = BASELINE.json configs[1]:
 default configs/ndt1.yaml (5 layers x 1024, 41.06 M params), 256 ch x 600 bins, bf16 operands.
-Weak scaling: --batch is PER GPU (default 64 = the recipe's train_batch_size).
+Run as `python bench.py --gpus N` with N > 1 and no torchrun around it, the script starts its own N ranks
+(`python -m torch.distributed.run`, one per GPU) BEFORE touching the GPU and relays rank 0's JSON line; it exits non-zero
+when fewer than N GPUs are visible or WORLD_SIZE disagrees with --gpus (never a silent 1-GPU number).
+Scaling modes: `--scaling weak` (default): --batch is PER GPU (64 = the recipe's train_batch_size on every rank);
+`--scaling strong`: the reference's own semantics (trainer.py:77-80 `split_batches=True`: configs/trainer_ctc_ndt1.yaml's
+train_batch_size 64 is the GLOBAL batch, each of W ranks gets 64 / W). At N > 1 BOTH are measured in the one run: `value` is the
+mode asked for, the other is in `other_scaling`. `dp` reports the ranks, all-reduce bytes per step and the exposed communication
+(step time with the exchange minus the same step with it skipped).
 Timing: W warm-up steps, then --repeats windows of EXACTLY K steps, each bracketed by barrier + device sync (max over ranks);
 `value` / `ms_per_step` are the MEDIAN window's, `ms_per_step_min/max` the spread. Extra keys at N=1: `extra_points` (B = 8 and a
 ragged-length batch), `roofline` (dominant GEMM, HIP events live), `cpu_baseline` (PyTorch-CPU restatement on the host cores).
@@ -146,39 +153,79 @@ def feed_from_host(tr, args, dev, n_rows=256, windows=3):
             "h2d_mbytes_per_step": round(B * T * N * 4 / 1e6, 1), "pinned_buffers_allocated": pool.allocated}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves, before anything touches the GPU in this
+    process (torch.cuda.device_count() does not initialise it), and leave with the launcher's exit code. The reference gets its
+    ranks the same way, from `accelerate launch` (models/trainer.py:77-80,258-262)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("NBCI_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for but only {ndev} GPU(s) are visible; refusing to report a {ndev}-GPU number as "
+              f"{args.gpus} (rehearse the multi-rank path on one GPU with NBCI_DIST_BACKEND=gloo)", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=64, help="global batch split over the ranks (strong scaling; the recipe's train_batch_size)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="which mode `value` reports (N > 1 measures both)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce dtype (fp32 = the reference's DDP)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--bins", type=int, default=600)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--target-len", type=int, default=60)
-    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps each; the median window is reported")
-    ap.add_argument("--no-extra-points", action="store_true", help="skip the B=8 and ragged-length points (N=1 only)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed windows of --steps steps each; the median window is reported "
+                    "(0 = as many as fill about 2 s of GPU time, 5..40)")
+    ap.add_argument("--no-extra-points", action="store_true", help="skip the B=8 / ragged / other-model points (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or run `python bench.py --gpus {args.gpus}` "
+              "alone and let it start them)", file=sys.stderr, flush=True)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("NBCI_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {ndev} visible")
     local = local % max(1, ndev)          # (rehearsal: several ranks may share one GPU with NBCI_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("NBCI_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from llm_bci_amd._lib import check, lib
     from llm_bci_amd.ndt1 import NDT1
@@ -188,11 +235,14 @@ def main():
     over = {"encoder": {"embedder": {"n_channels": args.channels}}}
     model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    # OneCycle horizon: warm-up + timed windows + the 3 profiling steps + the two extra points (2 warm-up + 3 windows each)
-    total_steps = args.warmup + args.steps * max(1, args.repeats) + 3 + 3 * (2 + 3 * args.steps) + 16
-    tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=total_steps, warmup_pct=0.0,
-                       div_factor=25)
-    _, batch = make_batch(args.batch, args.bins, args.channels, args.target_len, 41, dev, seed=rank)
+    # OneCycle horizon: far beyond anything this script runs (the schedule only sets lr / beta1 scalars of the fused AdamW)
+    tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0,
+                       div_factor=25, comm_dtype=args.comm_dtype)
+    if args.global_batch % world:
+        raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+    per_gpu = {"weak": args.batch, "strong": args.global_batch // world}
+    batches = {m: make_batch(per_gpu[m], args.bins, args.channels, args.target_len, 41, dev, seed=rank)[1] for m in per_gpu}
+    batch = batches[args.scaling]
 
     def sync():
         if world > 1:
@@ -216,9 +266,45 @@ def main():
             e = float(t.item())
         return e
 
-    windows = sorted(timed_window(batch, args.steps, 1000 + 1000 * r) for r in range(max(1, args.repeats)))
+    def measure(b, seed0, repeats):
+        """sorted windows of EXACTLY --steps steps each. repeats = 0: as many as fill about 2 s of GPU time (so that a once-a-second
+        utilisation sampler sees the GPU busy), between 5 and 40; every rank takes the count from rank 0's first window."""
+        ws = [timed_window(b, args.steps, seed0)]
+        n = repeats if repeats > 0 else int(min(40, max(5, 2.0 / max(ws[0], 1e-6))))
+        ws += [timed_window(b, args.steps, seed0 + 1000 * (r + 1)) for r in range(n - 1)]
+        return sorted(ws)
+
+    windows = measure(batch, 1000, args.repeats)
     el = windows[len(windows) // 2]                          # the median window is the reported one
     stats = tr.read_stats()
+
+    other = dp = None
+    if world > 1:
+        # the other scaling mode, same binary, same run
+        om = "strong" if args.scaling == "weak" else "weak"
+        for i in range(2):
+            tr.train_step(batches[om], seed=300 + i + 100003 * rank)
+        wo = measure(batches[om], 50000, 5)
+        eo = wo[len(wo) // 2]
+        gbo = per_gpu[om] * world
+        other = {"scaling": om, "global_batch": gbo, "per_gpu_batch": per_gpu[om], "value": round(gbo * args.steps / eo, 2),
+                 "unit": "samples/s", "ms_per_step": round(1e3 * eo / args.steps, 3), "ms_per_step_min": round(1e3 * wo[0] / args.steps, 3),
+                 "ms_per_step_max": round(1e3 * wo[-1] / args.steps, 3), "repeats": len(wo)}
+        # exposed communication: the same step with the gradient exchange skipped (every rank steps on its local gradients;
+        # weights diverge across ranks from here on, which no later measurement depends on)
+        exposed = {}
+        tr.reducer.enabled = False
+        for m2 in (args.scaling, om):
+            tr.train_step(batches[m2], seed=400 + 100003 * rank)
+            wl = measure(batches[m2], 60000, 5)
+            t_comm = (el if m2 == args.scaling else eo) / args.steps
+            exposed[m2] = {"ms_per_step_no_exchange": round(1e3 * wl[len(wl) // 2] / args.steps, 3),
+                           "exposed_comm_ms": round(1e3 * (t_comm - wl[len(wl) // 2] / args.steps), 3)}
+        tr.reducer.enabled = True
+        esz = 2 if args.comm_dtype == "bf16" else 4
+        dp = {"ranks": dist.get_world_size(), "backend": "rccl" if backend == "nccl" else backend, "comm_dtype": args.comm_dtype,
+              "allreduce_bytes_per_step": int(model._total) * esz, "buckets_per_step": tr.reducer.last_buckets,
+              "algorithm": "bucketed all-reduce(SUM) per backward segment, overlapped with backward; 1/W folded into AdamW", **exposed}
 
     roof = None
     if not args.no_roofline:
@@ -263,7 +349,7 @@ def main():
             _, b2 = make_batch(B2, args.bins, args.channels, args.target_len, 41, dev, seed=7, ragged=rg)
             tr.train_step(b2, seed=3)
             tr.train_step(b2, seed=4)
-            w = sorted(timed_window(b2, args.steps, 9000 + 100 * j) for j in range(3))[1]
+            w = measure(b2, 9000, 5)[2]
             extra[name] = {"ms_per_step": round(1e3 * w / args.steps, 3), "samples_per_s": round(B2 * args.steps / w, 1)}
             if rg:
                 extra[name]["mean_valid_fraction"] = round(float(b2["spikes_lengths"].float().mean().item()) / args.bins, 3)
@@ -280,22 +366,22 @@ def main():
 
     if rank == 0:
         fps, Tp = fwd_flops_per_sample(args.bins, args.channels)
-        gb = args.batch * world
+        gb = per_gpu[args.scaling] * world
         value = gb * args.steps / el
         res = {
             "metric": "train-step samples/sec (spike windows), NDT1-CTC", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
             "repeats": len(windows), "ms_per_step_min": round(1e3 * windows[0] / args.steps, 3), "ms_per_step_max": round(1e3 * windows[-1] / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "NDT1 CTC, default configs/ndt1.yaml (5 layers x 1024 hidden, 8 heads, stack 32/4), "
                                    f"{args.channels} ch x {args.bins} bins -> {Tp} tokens, target len {args.target_len}, "
                                    "recipe trainer_ctc_ndt1.yaml (dropout 0.2/0.4 + noise on, AdamW lr 1e-3 wd 5e-5, OneCycle cosine)",
-                       "global_batch": gb, "per_gpu_batch": args.batch, "params": n_params,
+                       "global_batch": gb, "per_gpu_batch": per_gpu[args.scaling], "params": n_params, "params_padded": int(model._total),
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "step": "fwd + CTC + bwd + grad all-reduce(mean) + fused AdamW + on-device PER"},
             "model_tflops_per_s": round(3 * fps * value / 1e12, 1),
             "train_loss_per_example": round(stats["loss"], 4), "train_PER": stats["PER"],
-            "roofline": roof, "extra_points": extra,
+            "roofline": roof, "extra_points": extra, "other_scaling": other, "dp": dp,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()

@@ -46,6 +46,8 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._pending = None                     # [begin, end) accumulated but not yet launched
+        self.enabled = True                      # False: measurement only (bench.py's exposed-communication leg) - buckets are formed, nothing is exchanged
+        self.last_buckets = 0                    # buckets put on the wire by the last drained step
 
     def segment_done(self, flat, seg):
         """Call after segment `seg`'s backward kernels are queued (segments finish high -> low)."""
@@ -73,7 +75,9 @@ class GradReducer:
     def _launch(self, flat):
         b, e = self._pending
         self._pending = None
-        if self.comm_bf16:
+        if not self.enabled:
+            self._works.append((b, e, None, None))
+        elif self.comm_bf16:
             lp = flat[b:e].to(torch.bfloat16)    # (on the backward's stream, before the collective is queued behind it)
             self._works.append((b, e, dist.all_reduce(lp, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lp))
         else:
@@ -89,8 +93,10 @@ class GradReducer:
         if self._pending is not None and flat is not None:
             self._launch(flat)
         works, self._works = self._works, []
+        self.last_buckets = len(works)
         for (b, e, w, lp) in works:
-            w.wait()
+            if w is not None:
+                w.wait()
             if lp is not None:
                 if flat is None:
                     raise ValueError("drain(flat) needs the gradient buffer in bf16 communication mode")

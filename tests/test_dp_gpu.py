@@ -16,3 +16,37 @@ def test_two_rank_native_trainer_equals_single_process():
            "--master-port", "29517", os.path.join(ROOT, "tools", "dp_check.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus2_refuses_on_a_one_gpu_box():
+    """`python bench.py --gpus 2` with one GPU visible and RCCL asked for must fail loudly, never print a 1-GPU number."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs: the refusal does not apply")
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "n_gpus" not in r.stdout and "only 1 GPU" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_self_launches_its_ranks_and_reports_both_scaling_modes():
+    """gloo rehearsal on the one GPU: bench.py starts its own two ranks, prints n_gpus 2, the weak-scaling value, the strong-scaling
+    point (global batch split over the ranks: trainer.py:77-80) and the exchange bookkeeping."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", "8", "--global-batch", "8", "--no-roofline"],
+               {"NBCI_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["per_gpu_batch"] == 8
+    o = d["other_scaling"]
+    assert o["scaling"] == "strong" and o["global_batch"] == 8 and o["per_gpu_batch"] == 4 and o["value"] > 0
+    assert d["dp"]["ranks"] == 2 and d["dp"]["allreduce_bytes_per_step"] == 4 * d["config"]["params_padded"]
+    assert d["dp"]["buckets_per_step"] >= 2 and "exposed_comm_ms" in d["dp"]["weak"] and "exposed_comm_ms" in d["dp"]["strong"]
