@@ -270,7 +270,7 @@ class BCI(nn.Module):
                 llm = AutoModelForCausalLM.from_config(LlamaConfig(num_hidden_layers=2, hidden_size=32, intermediate_size=32,
                                                                    num_attention_heads=4))
             else:
-                llm = AutoModelForCausalLM.from_pretrained(pt_path or llm_path)
+                llm = self._load_llm(pt_path, base_path=llm_path) if pt_path else AutoModelForCausalLM.from_pretrained(llm_path)
             if lora is not None and pt_path is None:
                 llm = self._add_lora(llm, lora)
             if freeze_llm:
@@ -567,13 +567,66 @@ class BCI(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, save_dir):
-        self.llm.save_pretrained(save_dir)
+        """Reference bci.py:250-257: `llm.save_pretrained` (with peft that is an ADAPTER-ONLY checkpoint), the NDT1 files,
+        projector.bin / projector_config.pth. Without peft the LoRA'd LLM is saved in the same adapter-only format
+        (llm_bci_amd/lora.py save_adapter), never as a full model with wrapper key names."""
+        from .lora import has_injected_lora, save_adapter
+        if has_injected_lora(self.llm):
+            save_adapter(self.llm, save_dir)
+        else:
+            self.llm.save_pretrained(save_dir)
         self.ndt1.save_checkpoint(save_dir)
         torch.save({k: v.detach().clone() for k, v in self.projector.state_dict().items()}, os.path.join(save_dir, "projector.bin"))
         torch.save(dict(self.config.projector), os.path.join(save_dir, "projector_config.pth"))
 
+    @staticmethod
+    def _load_llm(load_dir, current=None, base_path=None):
+        """The LLM of a checkpoint directory (reference bci.py:262: `AutoModelForCausalLM.from_pretrained(load_dir)`). A directory
+        holding an adapter-only checkpoint needs peft for that call; without peft the adapter is loaded into `current` (wrappers
+        injected when absent), or into a base model built from `base_path` / the adapter's `base_model_name_or_path`."""
+        from .lora import is_adapter_dir, load_adapter
+        from transformers import AutoModelForCausalLM
+        if is_adapter_dir(load_dir):
+            try:
+                import peft  # noqa: F401
+                return AutoModelForCausalLM.from_pretrained(load_dir)
+            except ImportError:
+                pass
+            if current is None:
+                import json
+                base = base_path or json.load(open(os.path.join(load_dir, "adapter_config.json"))).get("base_model_name_or_path")
+                if not base:
+                    raise ValueError(f"{load_dir} is an adapter-only checkpoint: a base model path (llm_path) is needed to load it without peft")
+                current = AutoModelForCausalLM.from_pretrained(base)
+            return load_adapter(current, load_dir)
+        return AutoModelForCausalLM.from_pretrained(load_dir)
+
     def load_checkpoint(self, load_dir):
+        """Reference bci.py:259-264: the LLM (or its adapters) is reloaded too, then the NDT1 files and the projector. The joint flat
+        buffer of the native train step is dropped: it is rebuilt on next use, which re-seeds the f32 masters of the LLM's trainable
+        tensors from the tensors just loaded (NativeTrainer.load_checkpoint then restores the saved masters for an exact resume)."""
+        dev, dt = next(self.llm.parameters()).device, self.llm.dtype
+        self.llm = self._load_llm(load_dir, current=self.llm).to(dev).to(dt)
+        self.llm_config = self.llm.config
         self.ndt1.load_checkpoint(load_dir)
         self.projector.load_state_dict(torch.load(os.path.join(load_dir, "projector.bin")))
-        if self._native is not None:
-            self._native["lp"] = None
+        self._native = None
+        self._nat = None
+
+    # what NativeTrainer adds to trainer_state.pth for an exact resume: the f32 masters of the LLM's trainable tensors (the tensors
+    # themselves are fp16 / bf16 roundings of them)
+    def _resume_state(self):
+        self._ensure_native()
+        ee = self._native["eentries"]
+        flat = self._native["flat"]
+        return {"llm_masters": {n: flat[o:o + p.numel()].detach().cpu().clone() for n, p, o in ee}}
+
+    def _load_resume_state(self, st):
+        self._ensure_native()
+        flat = self._native["flat"]
+        masters = (st or {}).get("llm_masters", {})
+        with torch.no_grad():
+            for n, p, o in self._native["eentries"]:
+                if n in masters:
+                    flat[o:o + p.numel()] = masters[n].to(flat.device)
+        self._native["lp"] = None

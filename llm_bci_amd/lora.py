@@ -46,3 +46,98 @@ def inject_lora(model, r, alpha, dropout, target_modules):
     if n == 0:
         raise ValueError(f"LoRA: no nn.Linear named any of {sorted(targets)} in the model")
     return model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# adapter-only checkpoints in peft's on-disk format (what `PeftModel.save_pretrained` writes for the reference, models/bci.py:252):
+#   adapter_config.json        peft's LoraConfig fields (the ones that define the adapter)
+#   adapter_model.safetensors  ONLY the lora_A / lora_B tensors, keyed `base_model.model.<module path>.lora_A.weight`
+#                              (peft drops the adapter name "default" from the keys it saves)
+# so a directory written here loads with peft where peft exists, and a directory written by peft loads here.
+# ---------------------------------------------------------------------------------------------------------------------
+ADAPTER_CONFIG, ADAPTER_WEIGHTS = "adapter_config.json", "adapter_model.safetensors"
+
+
+def lora_modules(model):
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, LoRALinear)]
+
+
+def has_injected_lora(model):
+    return any(True for _ in lora_modules(model))
+
+
+def adapter_state_dict(model):
+    out = {}
+    for name, m in lora_modules(model):
+        out[f"base_model.model.{name}.lora_A.weight"] = m.lora_A["default"].weight.detach().contiguous().cpu()
+        out[f"base_model.model.{name}.lora_B.weight"] = m.lora_B["default"].weight.detach().contiguous().cpu()
+    return out
+
+
+def save_adapter(model, save_dir):
+    """Adapter-only checkpoint of a model wrapped by inject_lora (module docstring above)."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    mods = lora_modules(model)
+    if not mods:
+        raise ValueError("save_adapter: the model carries no LoRA wrappers")
+    m0 = mods[0][1]
+    r = m0.lora_A["default"].weight.shape[0]
+    drop = m0.lora_dropout["default"]
+    cfg = {"peft_type": "LORA", "task_type": None, "inference_mode": True, "r": int(r), "lora_alpha": float(m0.scaling * r),
+           "lora_dropout": float(drop.p) if isinstance(drop, nn.Dropout) else 0.0, "bias": "none", "fan_in_fan_out": False,
+           "target_modules": sorted({n.rsplit(".", 1)[-1] for n, _ in mods}), "modules_to_save": None,
+           "base_model_name_or_path": getattr(getattr(model, "config", None), "_name_or_path", None) or None, "init_lora_weights": True}
+    os.makedirs(save_dir, exist_ok=True)
+    with open(os.path.join(save_dir, ADAPTER_CONFIG), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
+    save_file(adapter_state_dict(model), os.path.join(save_dir, ADAPTER_WEIGHTS), metadata={"format": "pt"})
+
+
+def is_adapter_dir(path):
+    import os
+    return os.path.exists(os.path.join(path, ADAPTER_CONFIG))
+
+
+def load_adapter(model, load_dir):
+    """Load an adapter-only checkpoint (written by save_adapter or by peft) into `model`: wrappers are injected first when the model
+    has none (from adapter_config.json), then every lora_A / lora_B tensor of the file must find its module, and every wrapper its
+    two tensors — nothing is silently re-initialised."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    cfg = json.load(open(os.path.join(load_dir, ADAPTER_CONFIG)))
+    if cfg.get("peft_type", "LORA") != "LORA":
+        raise ValueError(f"load_adapter: peft_type {cfg.get('peft_type')} is not LoRA")
+    if not has_injected_lora(model):
+        inject_lora(model, int(cfg["r"]), float(cfg["lora_alpha"]), float(cfg.get("lora_dropout", 0.0)), cfg["target_modules"])
+    wpath = os.path.join(load_dir, ADAPTER_WEIGHTS)
+    sd = load_file(wpath) if os.path.exists(wpath) else torch.load(os.path.join(load_dir, "adapter_model.bin"), map_location="cpu")
+    mods = dict(lora_modules(model))
+    seen = set()
+    def locate(key):
+        """(module path, "lora_A" | "lora_B") of a saved tensor name; peft drops the adapter name, a raw state dict keeps it."""
+        name = key[len("base_model.model."):] if key.startswith("base_model.model.") else key
+        for part in ("lora_A", "lora_B"):
+            for suffix in (f".{part}.weight", f".{part}.default.weight"):
+                if name.endswith(suffix):
+                    return name[:-len(suffix)], part
+        return None, None
+
+    for k, v in sd.items():
+        path, part = locate(k)
+        if part is None:
+            raise KeyError(f"load_adapter: unexpected tensor {k} in an adapter checkpoint")
+        if path not in mods:
+            raise KeyError(f"load_adapter: no LoRA wrapper for {k}")
+        w = getattr(mods[path], part)["default"].weight
+        if tuple(w.shape) != tuple(v.shape):
+            raise ValueError(f"load_adapter: {k} has shape {tuple(v.shape)}, the wrapper expects {tuple(w.shape)}")
+        with torch.no_grad():
+            w.copy_(v.to(w.dtype))
+        seen.add((path, part))
+    missing = [(n, p) for n in mods for p in ("lora_A", "lora_B") if (n, p) not in seen]
+    if missing:
+        raise KeyError(f"load_adapter: checkpoint has no tensors for {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+    return model

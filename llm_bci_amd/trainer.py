@@ -218,6 +218,8 @@ class NativeTrainer:
         state = {"layout": [(n, o, k) for (n, o, k, _s, _g) in m._layout], "m": self.m.cpu(), "v": self.v.cpu(),
                  "global_step": self.global_step, "opt_step": self.opt_step, "step_seed": m._step_seed,
                  "sched_epoch": getattr(self.sched, "epoch", 0), "grads": self.grads.cpu()}
+        if hasattr(m, "_resume_state"):   # BCI: f32 masters of the LLM's trainable (half-precision) tensors
+            state["model_extra"] = m._resume_state()
         torch.save(state, os.path.join(save_dir, "trainer_state.pth"))
 
     def load_checkpoint(self, load_dir):
@@ -229,5 +231,7 @@ class NativeTrainer:
         self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.grads.copy_(st["grads"])
         self.global_step, self.opt_step = st["global_step"], st["opt_step"]
         self.model._step_seed = st["step_seed"]
+        if hasattr(self.model, "_load_resume_state"):
+            self.model._load_resume_state(st.get("model_extra"))
         if hasattr(self.sched, "epoch"):
             self.sched.epoch = st["sched_epoch"]

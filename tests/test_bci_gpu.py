@@ -232,6 +232,50 @@ def test_native_trainer_trains_bci_with_lora(dtype):
         assert torch.equal(m._flat_lp, m._flat.bfloat16())
 
 
+def test_native_trainer_resume_restores_llm_adapters_and_masters(tmp_path):
+    """ADVICE r2 (bci.py:575): save after 3 steps, 3 more steps; a FRESH LoRA'd BCI restored by NativeTrainer.load_checkpoint and fed
+    the same steps ends on the same adapters / projector / encoder. Before the fix load_checkpoint left the LLM untouched and the
+    stale f32 masters overwrote the adapters on the next step."""
+    import os
+    from llm_bci_amd.trainer import NativeTrainer
+    from llm_bci_amd.lora import has_injected_lora
+    fx = load("g_bci_fwd")
+    batch = _batch_dict(fx)
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = _build_fwd(fx, "bf16", llm_dtype=torch.float16, lora=LORA)
+        return m, NativeTrainer(m, lr=5e-3, wd=0.0, total_steps=40, compute_per=False)
+
+    m, tr = fresh(3)
+    if not has_injected_lora(m.llm):
+        pytest.skip("peft installed: adapter files are peft's own")
+    for s in range(3):
+        tr.train_step(batch, seed=s)
+    tr.save_checkpoint(str(tmp_path))
+    assert {"adapter_config.json", "adapter_model.safetensors", "trainer_state.pth", "projector.bin", "encoder.bin"} <= set(os.listdir(tmp_path))
+    for s in range(3, 6):
+        tr.train_step(batch, seed=s)
+    torch.cuda.synchronize()
+    want_llm = {n: p.detach().clone() for n, p in m.llm.named_parameters() if "lora_" in n}
+    want_flat = m._flat.clone()
+
+    m2, tr2 = fresh(99)                      # other adapter init (lora_A is random): everything must come from the checkpoint
+    tr2.load_checkpoint(str(tmp_path))
+    a3 = {n: p for n, p in m2.llm.named_parameters() if "lora_" in n}
+    for n, p, off in m2._native["eentries"]:  # masters restored exactly, tensors = their fp16 rounding
+        assert torch.equal(p.detach(), m2._flat[off:off + p.numel()].view(p.shape).to(p.dtype)), n
+    for s in range(3, 6):
+        tr2.train_step(batch, seed=s)
+    torch.cuda.synchronize()
+    assert tr2.opt_step == tr.opt_step == 6
+    for n, p in a3.items():
+        d = (p.float() - want_llm[n].float()).abs().max().item()
+        assert d <= 2e-3, (n, d)             # (atomics / fp16 LLM backward order noise through Adam's normalised steps)
+    d = (m2._flat - want_flat).abs()
+    assert (d > 1e-4).float().mean() < 0.02 and d.max() < 2e-2, (d.max().item(), (d > 1e-4).float().mean().item())
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # the coupler at its real widths (configs/bci.yaml: 1024*s -> 2048 -> 4096) and the phoneme_coupler.yaml variant vs the oracle
 # ------------------------------------------------------------------------------------------------------------------------

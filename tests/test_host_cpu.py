@@ -219,6 +219,60 @@ def test_lora_fallback_is_lora_by_its_published_definition():
         inject_lora(llm, 4, 8, 0.0, ["no_such_module"])
 
 
+def _tiny_bci(lora):
+    from llm_bci_amd.bci import BCI
+    over = {"ndt1": {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                                 "transformer": {"n_layers": 1, "hidden_size": 32, "n_heads": 2, "inter_size": 48}}},
+            "projector": {"inter_size": 24}}
+    torch.manual_seed(0)
+    return BCI(over, lora=lora, debug=True)
+
+
+def test_lora_checkpoint_is_adapter_only_and_round_trips_without_peft(tmp_path):
+    """the no-peft fallback used to write a full HF checkpoint with wrapper key names that from_pretrained re-initialises
+    with a warning. BCI.save_checkpoint now writes peft's adapter-only format (reference bci.py:252 under peft) and load_checkpoint
+    reloads the LLM side too (bci.py:262)."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from llm_bci_amd import lora as L
+    cfg = dict(r=4, alpha=8, dropout=0.0, target_modules=["q_proj", "v_proj"], modules_to_save=None)
+    m = _tiny_bci(cfg)
+    if not L.has_injected_lora(m.llm):
+        pytest.skip("peft is installed: its own save_pretrained / from_pretrained handle the adapter")
+    for n, p in m.llm.named_parameters():
+        if "lora_B" in n:
+            p.data.normal_(0, 0.1)
+    d = str(tmp_path / "ck")
+    m.save_checkpoint(d)
+    files = sorted(os.listdir(d))
+    assert "adapter_config.json" in files and "adapter_model.safetensors" in files
+    assert not any(f.startswith("model") or f == "config.json" for f in files)            # adapter ONLY, as peft writes it
+    sd = load_file(os.path.join(d, "adapter_model.safetensors"))
+    assert all(k.startswith("base_model.model.") and (k.endswith("lora_A.weight") or k.endswith("lora_B.weight")) for k in sd)
+    assert len(sd) == 2 * 2 * 2                                                             # 2 layers x {q,v} x {A,B}
+    ac = json.load(open(os.path.join(d, "adapter_config.json")))
+    assert ac["peft_type"] == "LORA" and ac["r"] == 4 and ac["lora_alpha"] == 8 and ac["target_modules"] == ["q_proj", "v_proj"]
+    m2 = _tiny_bci(cfg)
+    m2.load_checkpoint(d)
+    a, b = m.llm.state_dict(), m2.llm.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    # into a model WITHOUT wrappers: injected from adapter_config.json, then loaded
+    m3 = _tiny_bci(None)
+    assert not L.has_injected_lora(m3.llm)
+    m3.load_checkpoint(d)
+    c = m3.llm.state_dict()
+    assert a.keys() == c.keys() and all(torch.equal(a[k], c[k]) for k in a if "lora_" in k)
+    # nothing is silently dropped or re-initialised
+    bad = dict(sd); bad["base_model.model.model.layers.0.mlp.up_proj.lora_A.weight"] = torch.zeros(4, 32)
+    save_file(bad, os.path.join(d, "adapter_model.safetensors"))
+    with pytest.raises(KeyError):
+        _tiny_bci(cfg).load_checkpoint(d)
+    few = {k: v for k, v in sd.items() if "layers.1" not in k}
+    save_file(few, os.path.join(d, "adapter_model.safetensors"))
+    with pytest.raises(KeyError):
+        _tiny_bci(cfg).load_checkpoint(d)
+
+
 def test_bci_joint_flat_layout_on_cpu():
     """BCI's native layout [ndt1 | projector | trainable LLM tensors]: contiguous 8-aligned segments, ndt1 / projector parameters
     re-homed as views, adapter masters copied in and written back in the adapters' dtype."""

@@ -3,7 +3,7 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "per_kernel" in r["Kernel_Name"]]
 mid = len(idx) // 2   # a step from the middle of the run (the last ones may belong to bench.py's event-instrumented pass)
