@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--target-len", type=int, default=60)
     ap.add_argument("--repeats", type=int, default=0, help="timed windows of --steps steps each; the median window is reported "
                     "(0 = as many as fill about 2 s of GPU time, 5..40)")
+    ap.add_argument("--side-stream", default="auto", choices=["auto", "on", "off"], help="NativeTrainer(side_stream=...)")
     ap.add_argument("--no-extra-points", action="store_true", help="skip the B=8 / ragged / other-model points (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -237,7 +238,7 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     # OneCycle horizon: far beyond anything this script runs (the schedule only sets lr / beta1 scalars of the fused AdamW)
     tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0,
-                       div_factor=25, comm_dtype=args.comm_dtype)
+                       div_factor=25, comm_dtype=args.comm_dtype, side_stream={"auto": "auto", "on": True, "off": False}[args.side_stream])
     if args.global_batch % world:
         raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
     per_gpu = {"weak": args.batch, "strong": args.global_batch // world}

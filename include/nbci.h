@@ -232,6 +232,11 @@ int nbci_step_stats(double* stats, const float* loss, int32_t B, double n_exampl
 int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
                nbci_stream_t stream);
+/* the same step + optimizer.zero_grad() (trainer.py:340-342) in one pass: g is cleared as it is consumed. max_blocks > 0 caps
+ * the launch's workgroups (a caller running it on a second stream beside other kernels leaves them wave slots); 0 = default. */
+int nbci_adamw_zero(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
+                    int32_t max_blocks, nbci_stream_t stream);
 
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream);
 
@@ -341,6 +346,14 @@ typedef struct nbci_ndt1_io {
     int32_t embed_part;                 /* backward of segment 0 only: 0 = whole segment; 1 = the stack-projection / position /
                                            token-table gradients (everything after embed_spikes.* in the flat layout), 2 = the rest.
                                            Lets a data-parallel caller all-reduce the large first part while part 2 computes. */
+    nbci_stream_t aux_stream;           /* backward, optional (bf16 mode): a second stream of the caller's. The weight-gradient GEMMs and
+                                           the fold of the bias / LayerNorm gradient sums are queued there, beside the data-gradient
+                                           chain on `stream` (ordered by events the plan owns). The gradients of the segments of the
+                                           call are then complete on aux_stream, not on `stream`: queue their consumer (optimizer,
+                                           all-reduce) behind aux_stream, and make `stream` wait for aux_stream before the next
+                                           forward on this workspace. NULL: everything on `stream` (the default). Pays when one
+                                           launch does not fill the chip (small batches); the reference has no counterpart
+                                           (autograd runs trainer.py:339's backward on one stream). */
 } nbci_ndt1_io;
 
 typedef void* nbci_ndt1_plan;

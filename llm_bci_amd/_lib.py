@@ -66,7 +66,7 @@ class NDT1IO(C.Structure):
                 ("preds", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p), ("hidden_out", C.c_void_p),
                 ("token_mask_out", C.c_void_p), ("d_hidden", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("day_idx", C.c_void_p), ("block_idx", C.c_void_p),
-                ("embed_part", C.c_int32)]
+                ("embed_part", C.c_int32), ("aux_stream", C.c_void_p)]
 
 
 class MaskerDesc(C.Structure):
@@ -160,6 +160,8 @@ _SIGNATURES = {
                                      C.c_int32, C.c_void_p]),
     "nbci_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "nbci_adamw_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "nbci_smooth_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "nbci_layernorm_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

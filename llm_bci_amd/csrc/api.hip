@@ -61,7 +61,11 @@ int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_l
 }
 int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, float bc1, float bc2, float grad_scale, nbci_stream_t stream) {
-    return nbci::adamw_launch(p, g, m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream);
+    return nbci::adamw_launch(p, const_cast<float*>(g), m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream);
+}
+int nbci_adamw_zero(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float bc1, float bc2, float grad_scale, int32_t max_blocks, nbci_stream_t stream) {
+    return nbci::adamw_launch(p, g, m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream, true, max_blocks);
 }
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream) {
     return nbci::cast_launch(in, out, out_dtype, n, (hipStream_t)stream);

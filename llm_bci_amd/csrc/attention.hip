@@ -15,6 +15,7 @@
 //             nine waves fit, one per 16-query block); dq = dS k -> dqkv; stores dS and Pd (bf16) for the second kernel
 //   bwd_dkv : dk = dS^T q, dv = Pd^T da  (contraction over queries: both operands tr-read)
 // Larger T', other head sizes and the f32 parity path use the batched-GEMM + softmax kernels.
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -432,6 +433,235 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_kernel(AttnArgs a) {   // on
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward in ONE launch for T' <= 144 (nine 16-row blocks): dS and Pd never go through HBM. Phase 1 is the dq kernel above with the
+// two bf16x4 global stores per 16-key block (16 rows x 32 B per wave instruction: partial cache lines, the slowest thing in that
+// kernel) replaced by LDS stores into two [query][key] images; after a barrier the K / V images are no longer needed, the q and da
+// rows of this (batch, head) take their place, and phase 2 is the dk / dv kernel above reading its X operands from those images.
+//   LDS: K 36 KB | V 36 KB | X(dS) 42.75 KB | X(Pd) 42.75 KB | bias sums 1.5 KB | key bits = 159.0 KB: one workgroup per CU.
+//   X image: 8-row blocks of 288-byte rows, 2432 bytes apart: consecutive blocks start 128 bytes apart modulo the 256-byte bank row,
+//   so the two 16-lane groups of a transposed read (rows r .. r+3 of blocks 4s and 4s+1) never share a bank.
+// Key validity: one 32-bit word per lane pair of blocks would do; here each lane keeps the 36 bits of ITS keys (block kb, keys
+// 16 kb + 4 g + r) in two registers, built once per query block from the workgroup's key bit table - the per-element mask rule of the
+// dq kernel (a global load of the token mask + five compares per score element) was a third of its VALU work.
+constexpr int AF_NB = 9;                       // 16-row blocks (T' <= 144)
+constexpr int AF_ROWS = AF_NB * 16;
+constexpr int AF_XBLK = 8 * 288 + 128;         // bytes per 8-row block of an X image
+constexpr int AF_XIMG = (AF_ROWS / 8) * AF_XBLK;
+__device__ __forceinline__ int xf_off(int row, int colbyte) { return (row >> 3) * AF_XBLK + (row & 7) * 288 + colbyte; }
+
+// global (rows x 128 bf16) -> 256-byte-row image of `img_rows` rows, rows >= nrows zero-filled; all loads of a pass before its stores
+__device__ __forceinline__ void load_image_rows(char* img, const bf16_t* src, long long ld, int nrows, int img_rows, int tid) {
+    constexpr int U = 4;
+    const int nthr = (int)blockDim.x, total = img_rows * 16;
+    for (int i0 = tid; i0 < total; i0 += U * nthr) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr, row = i >> 4, ch = i & 15;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < total && row < nrows) v[u] = *(const uint4*)(src + (long long)row * ld + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * nthr, row = i >> 4, ch = i & 15;
+            if (i < total) *(uint4*)(img + img_off(row, ch)) = v[u];
+        }
+    }
+}
+
+template <bool FULLCTX>   // FULLCTX: context.forward / backward = -2 (configs/ndt1.yaml): validity is the key bit or the diagonal
+__global__ __launch_bounds__(576) void attn_bwd_fused_kernel(AttnArgs a) {   // one wave per 16-row block (<= 9 waves)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                                  // phase 2: the q rows
+    char* sV = smem + AF_ROWS * 256;                  // phase 2: the da rows   (K rows 144..159 of a transposed read fall in here: finite)
+    char* sXs = smem + 2 * AF_ROWS * 256;             // dS  [query][key]
+    char* sXp = sXs + AF_XIMG;                        // Pd  [query][key]
+    float* sbias = (float*)(sXp + AF_XIMG);           // [3][128]
+    unsigned* sbits = (unsigned*)(sbias + 3 * AT_HD); // [5] key-valid bits (bit k of word k/32)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)(blockDim.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
+    for (int i = tid; i < 3 * AT_HD; i += (int)blockDim.x) sbias[i] = 0.f;
+    load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid, AF_ROWS);   // (V rows 144..159 land in the X image: overwritten below)
+    if (wave == 0) {
+        const int32_t* tm = a.tmask + (long long)b * a.Tp;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const int k = 64 * w + lane;
+            const unsigned long long m = __ballot(k < a.Tp && tm[k < a.Tp ? k : 0] != 0);
+            if (lane == 0) { sbits[2 * w] = (unsigned)m; if (w < 2) sbits[2 * w + 1] = (unsigned)(m >> 32); }
+        }
+    }
+    __syncthreads();
+    const int nqb = (a.Tp + 15) / 16;
+    const float inv_o_scale = 1.0f / a.o_scale;
+    const float c2 = a.scale * 1.4426950408889634f;   // exp(s * scale - lse) = exp2(s * c2 - lse * log2 e)
+    // ---------------- phase 1: per 16-query block, 32 keys at a time: S, dP -> Pd, dS (LDS) ; dq
+    for (int qb = wave; qb < nqb; qb += nwaves) {
+        const int query = 16 * qb + i16;
+        const int qrow = query < a.Tp ? query : a.Tp - 1;
+        const bool qok = query < a.Tp;
+        bf16x8 qf[4], df[4];
+        float delta = 0.f;
+        {
+            const long long arow = ((long long)b * a.Tp + qrow) * a.H + h * AT_HD;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+                df[ks] = *(const bf16x8*)(a.da + arow + 32 * ks + 8 * g);
+                const bf16x8 of = *(const bf16x8*)(a.ad + arow + 32 * ks + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) delta += bf2f(df[ks][e]) * bf2f(of[e]);
+            }
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        delta *= inv_o_scale;
+        const float nl2 = -a.lse[(long long)blockIdx.x * a.Tp + qrow] * 1.4426950408889634f;
+        const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
+        // this lane's key bits: bit 4 kb + r of vlo (kb < 8) / bit r of vhi (kb = 8) <=> key 16 kb + 4 g + r may be attended
+        unsigned vlo = 0u, vhi = 0u;
+#pragma unroll
+        for (int kb = 0; kb < AF_NB; ++kb) {
+            const unsigned nib = (sbits[kb >> 1] >> (16 * (kb & 1) + 4 * g)) & 0xFu;
+            if (kb < 8) vlo |= nib << (4 * kb); else vhi = nib;
+        }
+        if ((i16 >> 2) == g) {   // the diagonal is always attendable (ndt1.py:436)
+            if (qb < 8) vlo |= 1u << (4 * qb + (i16 & 3)); else vhi |= 1u << (i16 & 3);
+        }
+        f32x4 o[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < (AF_NB + 1) / 2; ++s) {
+            f32x4 sc[2], dp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kb = 2 * s + j;
+                sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kb < AF_NB) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, 16 * kb + i16, ks, g), qf[ks], sc[j], 0, 0, 0);
+                        dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, 16 * kb + i16, ks, g), df[ks], dp[j], 0, 0, 0);   // dPd = da . v^T
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kb = 2 * s + j;
+                if (kb >= AF_NB) { dp[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
+                const unsigned nib = kb < 8 ? (vlo >> (4 * kb)) : vhi;
+                const int key0 = 16 * kb + 4 * g;
+                float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.p_thr) drop4_any(a.p_key, a.p_thr, rbase + (unsigned)key0, a.p_scale, keep);
+                float pdv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool ok = ((nib >> r) & 1u) != 0u;
+                    if (!FULLCTX) ok = ok && ((key0 + r == qrow) || ctx_ok(qrow, key0 + r, a.cf, a.cb));
+                    const float p = (ok && qok) ? __builtin_amdgcn_exp2f(fmaf(sc[j][r], c2, nl2)) : 0.f;
+                    pdv[r] = p * keep[r];                                        // Pd
+                    dp[j][r] = p * (dp[j][r] * keep[r] - delta) * a.scale;       // dS (scaled), in place
+                }
+                bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
+                bf16x4 sv = {f2bf(dp[j][0]), f2bf(dp[j][1]), f2bf(dp[j][2]), f2bf(dp[j][3])};
+                *(bf16x4*)(sXp + xf_off(query, 2 * key0)) = pv;
+                *(bf16x4*)(sXs + xf_off(query, 2 * key0)) = sv;
+            }
+            // dq[query][d] += sum over these 32 keys of dS[query][key] k[key][d]   (k image read transposed)
+            const bf16x8 sf = pack8(dp[0], dp[1]);
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, i16), sf,
+                                                                o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long obase = ((long long)b * a.Tp + qrow) * ld + h * AT_HD;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            bf16x4 ov = {f2bf(o[db][0]), f2bf(o[db][1]), f2bf(o[db][2]), f2bf(o[db][3])};
+            if (qok) *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+            if (a.bias_grad) {  // query-bias gradient: column sums of the stored dq
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = qok ? bf2f(ov[r]) : 0.f;
+                    t = row16_sum(t);
+                    if (i16 == 0) atomicAdd(&sbias[16 * db + 4 * g + r], t);   // LDS atomic
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the K / V images; the X images are complete
+    // ---------------- phase 2: dk = dS^T q, dv = Pd^T da  (contraction over queries: both operands read transposed)
+    load_image_rows(sK, base, ld, a.Tp, AF_ROWS, tid);
+    load_image_rows(sV, a.da + (long long)b * a.Tp * a.H + h * AT_HD, a.H, a.Tp, AF_ROWS, tid);
+    __syncthreads();
+    const int q4 = i16 >> 2, p4 = i16 & 3;
+    const int qrows = 16 * nqb;   // X rows written by phase 1
+    for (int kb = wave; kb < nqb; kb += nwaves) {
+        f32x4 ok_[8], ov_[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) { ok_[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; ov_[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < (AF_NB + 1) / 2; ++s) {
+            if (32 * s >= qrows) break;   // (wave-uniform)
+            const int r0 = 32 * s + 8 * g;   // natural k order: query rows r0..r0+3 and r0+4..r0+7
+            const bool live = r0 < qrows;    // the last step of an odd block count has 16 query rows only
+            const int rr = live ? r0 : 0;
+            bf16x8 xs, xp;
+            {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sXs + xf_off(rr + q4, 2 * (16 * kb + 4 * p4))));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sXs + xf_off(rr + 4 + q4, 2 * (16 * kb + 4 * p4))));
+                union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+                u.p2.a = lo; u.p2.b = hi; xs = u.v;
+                lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sXp + xf_off(rr + q4, 2 * (16 * kb + 4 * p4))));
+                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sXp + xf_off(rr + 4 + q4, 2 * (16 * kb + 4 * p4))));
+                u.p2.a = lo; u.p2.b = hi; xp = u.v;
+                if (!live) {
+                    const bf16x8 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    xs = z; xp = z;
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                ok_[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, r0, r0 + 4, 16 * db, i16), xs, ok_[db], 0, 0, 0);
+                ov_[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, r0, r0 + 4, 16 * db, i16), xp, ov_[db], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int key = 16 * kb + i16;
+        const long long obase = ((long long)b * a.Tp + key) * ld + h * AT_HD;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const f32x4 acc = which == 0 ? ok_[db] : ov_[db];
+                bf16x4 ov = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+                if (key < a.Tp) *(bf16x4*)(a.dqkv + obase + (which + 1) * a.H + 16 * db + 4 * g) = ov;
+                if (a.bias_grad) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = key < a.Tp ? bf2f(ov[r]) : 0.f;
+                        t = row16_sum(t);
+                        if (i16 == 0) atomicAdd(&sbias[(which + 1) * AT_HD + 16 * db + 4 * g + r], t);
+                    }
+                }
+            }
+        }
+    }
+    if (a.bias_grad) {  // one contiguous global atomic pass per workgroup: q, k, v column sums
+        __syncthreads();
+        for (int i = tid; i < 3 * AT_HD; i += (int)blockDim.x)
+            atomicAdd(rep_ptr(a.bias_grad, a.rc, blockIdx.x) + (i / AT_HD) * a.H + h * AT_HD + (i % AT_HD), sbias[i]);
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------
 bool attn_fused_eligible(int dtype, int Tp, int H, int nh) {
     return dtype == NBCI_BF16 && nh > 0 && H / nh == AT_HD && Tp >= 1 && Tp <= AT_TPAD;
@@ -492,6 +722,22 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const
     a.ad = (bf16_t*)ad; a.lse = (float*)lse; a.o_scale = a.p_scale;
     a.da = (const bf16_t*)da; a.dS = (bf16_t*)dS; a.Pd = (bf16_t*)Pd; a.ldP = ldP; a.dqkv = (bf16_t*)dqkv; a.bias_grad = bias_grad; a.rc = rc;
     const int nblk = (Tp + 15) / 16;
+    static const bool one_launch = [] { const char* e = getenv("NBCI_ATTN_BWD1"); return !(e && e[0] == '0'); }();   // A/B: 0 = the dq + dk/dv pair
+    if (one_launch && Tp <= AF_ROWS) {
+        constexpr int lds3 = 2 * AF_ROWS * 256 + 2 * AF_XIMG + 3 * AT_HD * 4 + 32;
+        static bool once3 = false;
+        if (!once3) {
+            int r = set_lds((const void*)attn_bwd_fused_kernel<true>, lds3); if (r) return r;
+            r = set_lds((const void*)attn_bwd_fused_kernel<false>, lds3); if (r) return r;
+            once3 = true;
+        }
+        const dim3 blk(64 * (nblk < 2 ? 2 : nblk));
+        if (cf == -2 && cb == -2) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(B * nh), blk, lds3, s, a);
+        else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(B * nh), blk, lds3, s, a);
+        hipError_t e3 = hipGetLastError();
+        if (e3 != hipSuccess) return fail(NBCI_EHIP, std::string("attn_bwd (one launch): ") + hipGetErrorString(e3));
+        return NBCI_OK;
+    }
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds1, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(64 * (nblk < 2 ? 2 : nblk)), lds2, s, a);
     hipError_t e = hipGetLastError();

@@ -267,15 +267,17 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
 }
 
 constexpr int LNB_RPW = 1;                          // rows per wave and pass (their loads are in flight together)
-constexpr int LNB_ITERS = 4;                        // passes per block (the column partial sums stay in registers across them)
-constexpr int LNB_ROWS = 4 * LNB_RPW * LNB_ITERS;   // rows per block
+// passes per block (`iters`; the column partial sums stay in registers across them): 4 when the rows fill the chip (fewer atomic
+// tails), fewer for small row counts so that every CU gets a block (B = 8: 1144 rows -> 286 blocks of one pass instead of 72 of four,
+// 14 -> 8 us per launch, eleven launches per step)
+static inline int lnb_iters(int M) { return M >= 8192 ? 4 : (M >= 3072 ? 2 : 1); }
 
 template <int NV, typename DY>   // DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
-                                                     int accumulate, RepCfg rc, LnCast cz) {
+                                                     int accumulate, RepCfg rc, LnCast cz, int iters) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][NV*256]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float invH = 1.0f / (float)H;
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
 #pragma unroll
     for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; gc[k] = gw[k]; }
 #pragma unroll 1
-  for (int it = 0; it < LNB_ITERS; ++it) {
-    const int ra = blockIdx.x * LNB_ROWS + it * 4 * LNB_RPW + wv * LNB_RPW;
+  for (int it = 0; it < iters; ++it) {
+    const int ra = (blockIdx.x * iters + it) * 4 * LNB_RPW + wv * LNB_RPW;
     float4 xv[LNB_RPW][NV], dv[LNB_RPW][NV], od[LNB_RPW][NV];
     float mu[LNB_RPW], rs[LNB_RPW];
 #pragma unroll
@@ -374,10 +376,11 @@ int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const f
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz, int dy_bf16) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
     const int nv = (H + 255) / 256;
-    dim3 g((M + LNB_ROWS - 1) / LNB_ROWS);
+    const int iters = lnb_iters(M), rows = 4 * LNB_RPW * iters;
+    dim3 g((M + rows - 1) / rows);
 #define LNB(NVV, DYT)                                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, x, w, mean, \
-                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz)
+                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz, iters)
     if (dy_bf16) {
         if (nv <= 1) LNB(1, bf16_t);
         else if (nv <= 4) LNB(4, bf16_t);
@@ -1479,7 +1482,8 @@ int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat
 // ------------------------------------------------------------------------------------------
 // fused AdamW over the flat parameter buffer
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ plp, long long n, float lr,
                                                     float b1, float b2, float eps, float wd, float inv_bc1,
                                                     float inv_sqrt_bc2, float gscale) {
@@ -1502,17 +1506,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *(float4*)(v + i) = make_float4(v2[0], v2[1], v2[2], v2[3]);
         if (plp) { bf16x4 o = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])}; *(bf16x4*)(plp + i) = o; }
+        if (ZERO) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // zero_grad (trainer.py:342) in the pass that consumed the gradient
     }
 }
 
-int adamw_launch(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2,
-                 float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s) {
+int adamw_launch(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s, bool zero_grad, int max_blocks) {
     NBCI_REQUIRE(n % 4 == 0, NBCI_ESHAPE, "adamw: flat buffer length must be a multiple of 4");
     NBCI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                  NBCI_EALIGN, "adamw: buffers must be 16-byte aligned");
-    const long long blocks = std::min<long long>(2048, (n / 4 + 255) / 256);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
-                       (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
+    // max_blocks: a caller that runs the update beside other kernels (aux stream) keeps it to a few workgroups per CU so that
+    // those kernels' workgroups still find wave slots; 2 x 256 threads per CU keep ~32 KB of loads in flight per CU
+    const long long blocks = std::min<long long>(max_blocks > 0 ? max_blocks : 2048, (n / 4 + 255) / 256);
+    if (zero_grad)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
+                           (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
+                           (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
     return check_launch("adamw");
 }
 

@@ -82,6 +82,17 @@ __device__ __forceinline__ void drop4(uint32_t key, uint32_t thr16, uint32_t idx
     v[2] = ((h1 & 0xFFFFu) >= thr16) ? v[2] * scale : 0.f;
     v[3] = ((h1 >> 16) >= thr16) ? v[3] * scale : 0.f;
 }
+// 4 consecutive elements starting at ANY idx (the same bits as drop_keep per element): three pair hashes cover both parities
+// (attention probabilities: row base = (row index) * T', odd for odd T'); out[r] = keep ? scale : 0
+__device__ __forceinline__ void drop4_any(uint32_t key, uint32_t thr16, uint32_t idx, float scale, float (&out)[4]) {
+    const uint32_t base = idx >> 1;
+    const uint32_t ha = mix32(base ^ key), hb = mix32((base + 1u) ^ key), hc = mix32((base + 2u) ^ key);
+    const bool odd = (idx & 1u) != 0u;
+    const uint32_t b0 = odd ? (ha >> 16) : (ha & 0xFFFFu), b1 = odd ? (hb & 0xFFFFu) : (ha >> 16);
+    const uint32_t b2 = odd ? (hb >> 16) : (hb & 0xFFFFu), b3 = odd ? (hc & 0xFFFFu) : (hb >> 16);
+    out[0] = b0 >= thr16 ? scale : 0.f; out[1] = b1 >= thr16 ? scale : 0.f;
+    out[2] = b2 >= thr16 ? scale : 0.f; out[3] = b3 >= thr16 ? scale : 0.f;
+}
 __device__ __forceinline__ float rng_uniform01(uint32_t u) {  // (0,1]
     return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }

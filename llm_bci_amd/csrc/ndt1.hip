@@ -43,6 +43,10 @@ struct Plan {
     std::vector<std::pair<int, int>> cseg;  // compact [begin,end) per segment
     int* d_flat_of;
     int compact_total;
+    // aux-stream backward (nbci_ndt1_io.aux_stream): fork / join events, created on first use on the plan's device.
+    // ev_main: recorded on the main stream where the aux stream may start something; ev_wg[p]: recorded on the aux stream after
+    // the weight gradients of a layer of parity p, waited for by the main stream before it rewrites that parity's scratch buffers.
+    mutable hipEvent_t ev_main = nullptr, ev_wg[2] = {nullptr, nullptr};
     int compact_of(int64_t flat_off) const {
         for (size_t i = 0; i < cmap.size(); ++i) if (cmap[i].first == flat_off) return cmap[i].second;
         return -1;
@@ -151,7 +155,7 @@ struct WS {
     size_t fo, fgate, dfo;             // factors projection: output, act'(pre-activation), gradient (M, factors_size)
     size_t wsel, rsel, wpart, bpart;   // adapt: per-sample day weights (B,D,N), row -> day table (B*T), per-sample weight / bias gradients
     size_t scores;                     // f32 (B,nh,Tp,ldS): forward scores, backward dPd
-    size_t dx, dtmp, dA, dA2, dB, dB2, dqkv, dS, dwin, dpre, rep;
+    size_t dx, dtmp, dA[2], dA2[2], dB[2], dB2, dqkv[2], dS, dwin, dpre, rep;   // [layer parity]: what a layer's weight gradients read (see ndt1_backward, aux stream)
     size_t xtok;                       // (prefix tokens) stack-projection output of the spike tokens before the prefix rows are put in front
     size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
     int phase_ok, Q, P, npad;          // Q = T / stride output groups, P = Q + size/stride - 1 padded rows, npad = size/stride - 1
@@ -217,11 +221,13 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.scores = bump(cur, (size_t)B * c.n_heads * Tt * w.ldS * 4);
     w.dx = bump(cur, M * H * 4);
     w.dtmp = bump(cur, M * H * 4);
-    w.dA = bump(cur, M * H * es);
-    w.dA2 = bump(cur, M * H * es);
-    w.dB = bump(cur, M * std::max(H, I) * es);
+    for (int p2 = 0; p2 < 2; ++p2) {
+        w.dA[p2] = bump(cur, M * H * es);
+        w.dA2[p2] = bump(cur, M * H * es);
+        w.dB[p2] = bump(cur, M * std::max(H, I) * es);
+        w.dqkv[p2] = bump(cur, M * 3 * H * es);
+    }
     w.dB2 = bump(cur, M * H * es);
-    w.dqkv = bump(cur, M * 3 * H * es);
     w.dS = bump(cur, nP * es);
     // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
     w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
@@ -460,6 +466,27 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     const float scale = 1.0f / sqrtf((float)hd);
     float* rep = (float*)(ws + w.rep);
     const RepCfg rc{p.compact_total, NREP};
+    // io->aux_stream (bf16 mode): the layers' grouped weight gradients, the stack-projection weight gradient and the fold of the
+    // replicated small-vector gradients are queued on a SECOND stream, beside the data-gradient chain on `s`. With few rows per
+    // launch (small batches: B = 8 runs 72-144 workgroups on 256 CUs, every launch bound by its own latency) the two streams
+    // overlap; the caller decides (llm_bci_amd/trainer.py). Ordering: ev_main forks (main -> aux) wherever the aux work's inputs
+    // are complete; the scratch a layer's weight gradients read is double-buffered by layer parity and the main stream waits for
+    // ev_wg[parity] before the LayerNorm backward that rewrites it a layer later. The gradients of the segments of this call are
+    // then complete ON THE AUX STREAM: the caller orders its optimizer / all-reduce after it and joins it before the next forward.
+    hipStream_t aux = (io->aux_stream && dt == NBCI_BF16) ? (hipStream_t)io->aux_stream : s;
+    const bool two = aux != s;
+    hipStream_t wgs = aux;
+    if (two && !p.ev_main) {
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_main, hipEventDisableTiming));
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[0], hipEventDisableTiming));
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[1], hipEventDisableTiming));
+    }
+    auto fork = [&]() -> int {   // everything queued on the main stream so far happens-before what is queued on the aux stream from here on
+        if (!two) return NBCI_OK;
+        NBCI_CHECK_HIP(hipEventRecord(p.ev_main, s));
+        NBCI_CHECK_HIP(hipStreamWaitEvent(aux, p.ev_main, 0));
+        return NBCI_OK;
+    };
     auto RG = [&](int64_t flat_off) -> float* { return rep + p.compact_of(flat_off); };  // replica-0 slot of a 1-D param's grad
     // The f32 gradient stream dx is consumed by GEMMs in the operand dtype: the LayerNorm backward that
     // finalises dx also writes that (dropout-masked) copy into ws.dA and sums its columns (bias grad).
@@ -472,9 +499,9 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             return LnCast{ws + w.dAp, 1, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site), RG(p.stkb),
                           Tk, w.P, w.npad, 0};
         if (layer_below < 0 && npre > 0)     // same layout, but the prefix-token rows stay out of the stack-projection bias gradient
-            return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
+            return LnCast{ws + w.dA[1], dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
                           RG(p.stkb), Tp, Tp, 0, npre};
-        return LnCast{ws + w.dA, dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
+        return LnCast{ws + w.dA[layer_below & 1], dt == NBCI_BF16, drop_threshold(pp), pp > 0.f ? 1.f / (1.f - pp) : 1.f, drop_key(io->seed, site),
                       RG(layer_below >= 0 ? p.L[layer_below].dnb : p.stkb), 0, 0, 0, 0};
     };
 
@@ -534,31 +561,33 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
             const LayerOff& lo = p.L[l];
-            WgradQueue wq; wq.dtype = dt; wq.s = s;
+            // scratch read by this layer's weight gradients, by layer parity: with an aux stream they run beside the next layer's chain
+            const size_t o_dA = w.dA[l & 1], o_dA2 = w.dA2[l & 1], o_dB = w.dB[l & 1], o_dqkv = w.dqkv[l & 1];
+            WgradQueue wq; wq.dtype = dt; wq.s = wgs;
             // ---- MLP backward: x_out = x_mid + dropout(down(act(up(ln2(x_mid)))))
             const void* dm;  // d(down output) in the GEMM operand dtype (written by the previous LayerNorm backward)
             if (!need_cast) {
                 dm = dx;
                 TRY(colsum_launch(dm, dt, H, M, H, RG(lo.dnb), s, rc));
             } else {
-                dm = ws + w.dA;
+                dm = ws + o_dA;
             }
             TRY(wq.push(H, I, M, op(dm, es, 0, H, 0), op(ws + lw.g, es, 0, I, 0), grads + lo.dnw, I));
             {   // du = (dm W_down) * act'(u)
-                nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + w.dB, I, dt);
+                nbci_gemm_desc d = gd(M, I, H, dt, op(dm, es, 0, H, 1), op(x.W(lo.dnw), es, 0, I, 0), ws + o_dB, I, dt);
                 d.gate = ws + lw.u; d.ldg = I; d.gate_act = -1;   // lw.u already holds act'(u) (stored by the forward up_proj GEMM)
                 d.colsum = RG(lo.upb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;  // up_proj bias grad = column sums of du
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(wq.push(I, H, M, op(ws + w.dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
+            TRY(wq.push(I, H, M, op(ws + o_dB, es, 0, I, 0), op(ws + lw.h2, es, 0, H, 0), grads + lo.upw, H));
             {
-                nbci_gemm_desc d = gd(M, H, I, dt, op(ws + w.dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, dt);
+                nbci_gemm_desc d = gd(M, H, I, dt, op(ws + o_dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
                                      (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
                                      dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
-                                                    : LnCast{ws + w.dA2, 1, 0u, 1.f, 0u, RG(lo.ob)},
+                                                    : LnCast{ws + o_dA2, 1, 0u, 1.f, 0u, RG(lo.ob)},
                                      dt == NBCI_BF16 ? 1 : 0));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
@@ -566,7 +595,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 dxc = dx;
                 TRY(colsum_launch(dx, NBCI_F32, H, M, H, RG(lo.ob), s, rc));
             } else {
-                dxc = ws + w.dA2;  // bf16 copy + out_proj bias grad came out of the LayerNorm backward above
+                dxc = ws + o_dA2;  // bf16 copy + out_proj bias grad came out of the LayerNorm backward above
             }
             TRY(wq.push(H, H, M, op(dxc, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
             {   // da = (dx W_o) * keep(attn_out)  -> dB (M, H)
@@ -581,12 +610,12 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             bool bias_in_attn = false;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
                 bias_in_attn = attn_bias && !c.use_rope;
-                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + w.dqkv,
+                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + o_dqkv,
                                     bias_in_attn ? RG(lo.qb) : nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                     io->seed, 16 + 4 * l, s, rc));
             } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
                 TRY(fattn_masked_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, ws + w.dB2, (const float*)(ws + lw.lse),
-                                            (float*)(ws + w.scores), ws + w.dqkv, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
+                                            (float*)(ws + w.scores), ws + o_dqkv, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
                                             io->seed, 16 + 4 * l, s));
             } else {
                 {   // dPd = da v^T   (f32, reuses the score buffer)
@@ -597,7 +626,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 }
                 {   // dv = Pd^T da -> dqkv[:, 2H + h*hd ..]
                     nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + pd, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
-                                          op(ws + w.dB2, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + w.dqkv) + (size_t)2 * H * es, 3 * H, dt);
+                                          op(ws + w.dB2, es, 0, H, 0, 0, 0, az1, hd), (char*)(ws + o_dqkv) + (size_t)2 * H * es, 3 * H, dt);
                     d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd;
                     if (!c.use_rope) d.colsum = RG(lo.vb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
                     TRY(gemm_launch_timed(d, s));
@@ -606,30 +635,33 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                                        io->seed, 16 + 4 * l, s));
                 {   // dq = dS k * scale
                     nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 1, 0, 0, pz1, pz2),
-                                          op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + w.dqkv, 3 * H, dt);
+                                          op(ws + lw.qkv, es, H, 3 * H, 0, 0, 0, qz1, hd), ws + o_dqkv, 3 * H, dt);
                     d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
                     if (!c.use_rope) d.colsum = RG(lo.qb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
                     TRY(gemm_launch_timed(d, s));
                 }
                 {   // dk = dS^T q * scale
                     nbci_gemm_desc d = gd(Tp, hd, Tp, dt, op(ws + w.dS, es, 0, w.ldP, 0, 0, 0, pz1, pz2),
-                                          op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + w.dqkv) + (size_t)H * es, 3 * H, dt);
+                                          op(ws + lw.qkv, es, 0, 3 * H, 0, 0, 0, qz1, hd), (char*)(ws + o_dqkv) + (size_t)H * es, 3 * H, dt);
                     d.batch = B * nh; d.zdiv = nh; d.czs1 = qz1; d.czs2 = hd; d.alpha = scale;
                     if (!c.use_rope) d.colsum = RG(lo.kb); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
                     TRY(gemm_launch_timed(d, s));
                 }
             }
             const bool fused_bwd = (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) || (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh));
-            if (c.use_rope) TRY(rope_launch(ws + w.dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
+            if (c.use_rope) TRY(rope_launch(ws + o_dqkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 1, s));
             if ((c.use_rope || fused_bwd) && !bias_in_attn)  // q/k/v bias grads = column sums of dqkv (after the inverse rotation)
-                TRY(colsum_launch(ws + w.dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
-            TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
-            TRY(wq.flush());   // all four operand pairs exist now; the LayerNorm backward below overwrites dA
+                TRY(colsum_launch(ws + o_dqkv, dt, 3 * H, M, 3 * H, RG(lo.qb), s, rc));
+            TRY(wq.push(3 * H, H, M, op(ws + o_dqkv, es, 0, 3 * H, 0), op(ws + lw.h1, es, 0, H, 0), grads + lo.qw, H));
+            TRY(fork());
+            TRY(wq.flush());   // all four operand pairs exist now (aux stream: beside the rest of this layer and the next one)
+            if (two) NBCI_CHECK_HIP(hipEventRecord(p.ev_wg[l & 1], aux));
             {
-                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H, dt);
+                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + o_dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
             if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
+            if (two) NBCI_CHECK_HIP(hipStreamWaitEvent(s, p.ev_wg[(l + 1) & 1], 0));   // the cast below rewrites dA[(l - 1) & 1], which layer l + 1's weight gradients read
             TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
                                      (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1),
                                      dt == NBCI_BF16 ? 1 : 0));
@@ -641,7 +673,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 dx0 = dx;
                 if (io->embed_part != 2) TRY(colsum_launch(dx0, dt, H, M, H, RG(p.stkb), s, rc));
             } else {
-                dx0 = ws + w.dA;
+                dx0 = ws + w.dA[1];   // (the embedder is "layer -1": parity 1)
             }
             // io->embed_part splits this segment for the data-parallel trainer: 1 = everything that finishes the stack-projection /
             // position / token-table gradients (35 of the segment's 38 MB: their all-reduce then runs beside part 2), 2 = the rest
@@ -662,8 +694,9 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             if (w.phase_ok) {
                 // dx0 sits in zero-padded sample blocks (B, P, H): token j of sample b at row b*P + npad + j.
                 const int st = c.stack_stride, nwin = c.stack_size / st;
+                if (part != 2) TRY(fork());
                 if (part != 2)
-                    TRY(wgrad(s, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
+                    TRY(wgrad(wgs, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
                               op(ws + w.y, es, 0, (int64_t)st * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
                 if (part != 1) {
                 // d pre-activation WITHOUT the (M, size*D) window-gradient tensor and its col2im pass. The st bins t = st*q + ph of
@@ -679,8 +712,9 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 TRY(gemm_launch_timed(d, s));
                 }
             } else {
+            if (part != 2) TRY(fork());
             if (part != 2)
-                TRY(wgrad(s, dt, H, KS, Mk, dx0_rm,
+                TRY(wgrad(wgs, dt, H, KS, Mk, dx0_rm,
                           op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
             if (part != 1) {   // dwin = dx0 W_s  (B*T', S*D)
                 nbci_gemm_desc d = gd(Mk, KS, H, dt, dx0_km, op(x.W(p.stkw), es, 0, KS, 0), ws + w.dwin, KS, dt);
@@ -712,7 +746,10 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     int clo = p.cseg[seg_lo].first, chi = p.cseg[seg_hi].second;
     if (seg_lo == 0 && io->embed_part == 1) clo = p.compact_of(p.stkb);
     if (seg_lo == 0 && io->embed_part == 2) chi = p.compact_of(p.stkb);
-    if (chi > clo) TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, s));
+    if (chi > clo) {
+        TRY(fork());
+        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, aux));
+    }
     return NBCI_OK;
 }
 
@@ -784,6 +821,8 @@ void nbci_ndt1_plan_destroy(nbci_ndt1_plan plan) {
     if (!p) return;
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_flat_of) (void)hipFree(p->d_flat_of);
+    if (p->ev_main) (void)hipEventDestroy(p->ev_main);
+    for (hipEvent_t e : p->ev_wg) if (e) (void)hipEventDestroy(e);
     delete p;
 }
 

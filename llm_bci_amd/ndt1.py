@@ -66,6 +66,8 @@ class NDT1(nn.Module):
     """See module docstring. kwargs: method_name ("ctc"), vocab_size, blank_id, zero_infinity
     (reference ndt1.py:465,489,517); extra: compute_dtype ("bf16" | "fp32", default bf16)."""
 
+    _supports_aux_stream = True   # _run_backward(aux=...): weight gradients / fold on a second stream (NativeTrainer, small batches)
+
     def __init__(self, config, **kwargs):
         super().__init__()
         config = ndt1_config(config)
@@ -414,12 +416,16 @@ class NDT1(nn.Module):
         check(lib().nbci_ndt1_forward(self._plan, _ptr(self._flat), _ptr(self._flat_lp), C.byref(io), _stream()),
               "nbci_ndt1_forward")
         # keep every borrowed tensor alive until the backward of this step has been queued
+        self.last_rows = B * Tp
         self._io_keepalive = (io, spikes, mask, ts, lens, tg, tl, ws, preds, loss, argmax, hidden_out, token_mask_out, days, blocks)
         self.last_argmax = argmax
         return loss, preds
 
-    def _run_backward(self, grads, seg_hi=None, seg_lo=0, d_hidden=None, embed_part=0):
+    def _run_backward(self, grads, seg_hi=None, seg_lo=0, d_hidden=None, embed_part=0, aux=None):
+        """aux: an optional second torch.cuda.Stream (nbci_ndt1_io.aux_stream): weight gradients + the fold of the small-vector
+        gradients are queued there and the covered segments' gradients are complete on THAT stream."""
         io = self._io_keepalive[0]
+        io.aux_stream = C.c_void_p(aux.cuda_stream) if aux is not None else None
         io.d_hidden = _ptr(d_hidden)   # f32 (B,T',H): backward starts from the encoder output instead of the CTC head
         io.embed_part = embed_part     # segment 0 only: 1 = stack-projection/position/token gradients, 2 = the rest, 0 = both
         if not io.want_grad:

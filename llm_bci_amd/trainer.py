@@ -34,7 +34,7 @@ def register_into(reference_trainer_module):
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
                  div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
-                 compute_per=True, blank_id=0, comm_dtype="fp32"):
+                 compute_per=True, blank_id=0, comm_dtype="fp32", side_stream="auto", side_stream_max_rows=4608):
         self.model = model
         self.ga = gradient_accumulation_steps
         self.wd, self.eps, self.beta2 = wd, eps, betas[1]
@@ -62,6 +62,12 @@ class NativeTrainer:
         self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
         self._per_bufs = None
         self._mstream = None   # side stream for the per-step metric (train_step)
+        # Small batches (B x T' rows <= side_stream_max_rows) leave most CUs idle inside every launch of the backward chain, so
+        # the weight-gradient GEMMs, the fold of the bias / LayerNorm gradient sums and the optimizer update of every finished
+        # segment run on a SECOND stream beside it (nbci_ndt1_io.aux_stream). Same kernels, same bits. "auto" | True | False.
+        self.side_stream = side_stream
+        self.side_stream_max_rows = side_stream_max_rows
+        self._aux = None
 
     # -------------------------------------------------------------------------------------
     def _per(self, batch):
@@ -98,9 +104,11 @@ class NativeTrainer:
         layers, embedder) and BCI (trainable LLM tensors, projector, then the encoder's segments)."""
         m = self.model
         nseg = len(m._segments)
+        if self.reducer.world == 1 and self._use_side_stream():
+            return self._backward_two_streams(sync)
         if self.reducer.world == 1 or not sync:   # nothing to overlap with: the whole backward is one call (one fold of the small-vector gradients)
             m._run_backward(self.grads, nseg - 1, 0)
-            return
+            return False
         split = getattr(m, "_embed_split", None)
         for seg in range(nseg - 1, 0 if split is not None else -1, -1):
             m._run_backward(self.grads, seg, seg)
@@ -111,7 +119,58 @@ class NativeTrainer:
             self.reducer.range_done(self.grads, split, e0)
             m._run_backward(self.grads, 0, 0, embed_part=2)
             self.reducer.range_done(self.grads, b0, split)
+        return False
 
+    def _use_side_stream(self):
+        m = self.model
+        if not self.side_stream or not getattr(m, "_supports_aux_stream", False) or m.compute_dtype != NBCI_BF16:
+            return False
+        return self.side_stream is True or getattr(m, "last_rows", 1 << 30) <= self.side_stream_max_rows
+
+    def _adamw(self, b, e, zero=False, max_blocks=0):
+        """torch.optim.AdamW step (trainer.py:340) of flat range [b, e) on the current stream; zero: + zero_grad in the same pass."""
+        m = self.model
+        lr, beta1 = self.sched.at(self.opt_step)
+        t = self.opt_step + 1
+        lp = m._flat_lp if m.compute_dtype == NBCI_BF16 else None
+        pw, pg, pm, pv = (x.data_ptr() for x in (m._flat, self.grads, self.m, self.v))
+        plp = lp.data_ptr() if lp is not None else 0
+        args = (C.c_void_p(pw + 4 * b), C.c_void_p(pg + 4 * b), C.c_void_p(pm + 4 * b), C.c_void_p(pv + 4 * b),
+                C.c_void_p(plp + 2 * b) if plp else None, e - b, lr, beta1, self.beta2, self.eps, self.wd,
+                1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world)
+        if zero:
+            check(lib().nbci_adamw_zero(*args, max_blocks, _stream()), "nbci_adamw_zero")
+        else:
+            check(lib().nbci_adamw(*args, _stream()), "nbci_adamw")
+
+    def _backward_two_streams(self, sync):
+        """One GPU, small batch: segment by segment, the data-gradient chain on the current stream; weight gradients, the fold and -
+        on a step that synchronises - AdamW + zero_grad of the finished segment on the side stream (a segment's weights are last
+        read by its own backward, so its update may run while the segments below are still in their backward). Returns True
+        when the optimizer step has been taken here."""
+        m = self.model
+        main = torch.cuda.current_stream()
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.stats.device)
+        aux = self._aux
+        aux.wait_stream(main)     # (first use; afterwards every step ends with main waiting for aux)
+        import os
+        mb = int(os.environ.get("NBCI_SIDE_BLOCKS", "512"))
+        per_seg = os.environ.get("NBCI_SIDE_ADAMW", "1") == "1"
+        if per_seg:
+            for seg in range(len(m._segments) - 1, -1, -1):
+                m._run_backward(self.grads, seg, seg, aux=aux)
+                if sync:
+                    b, e = m._segments[seg]
+                    with torch.cuda.stream(aux):
+                        self._adamw(b, e, zero=True, max_blocks=mb)
+        else:
+            m._run_backward(self.grads, len(m._segments) - 1, 0, aux=aux)
+            if sync:
+                with torch.cuda.stream(aux):
+                    self._adamw(0, m._total, zero=True, max_blocks=0)
+        main.wait_stream(aux)     # the next forward reads the updated weights and reuses the activations the weight gradients read
+        return sync
     def train_step(self, batch, seed=None):
         """One micro-batch: forward, backward (+ overlapped all-reduce), and — on the steps the
         reference synchronises on (trainer.py:335) — AdamW + scheduler + zero_grad."""
@@ -140,21 +199,16 @@ class NativeTrainer:
                 if err is not None:
                     self.stats[2] += self._per_ratio(err)
                     self.stats[3] += 1
-        self._backward_and_reduce(sync)
-        if sync:
-            lr, beta1 = self.sched.at(self.opt_step)
-            t = self.opt_step + 1
-            lp = m._flat_lp if m.compute_dtype == NBCI_BF16 else None
-            pw, pg, pm, pv = (x.data_ptr() for x in (m._flat, self.grads, self.m, self.v))
-            plp = lp.data_ptr() if lp is not None else 0
+        stepped = self._backward_and_reduce(sync)
+        if sync and stepped:
+            self.opt_step += 1
+        elif sync:
             # One launch per reduced bucket, in the order the buckets were put on the wire: the update of the head / layer
             # ranges runs while the embedder's all-reduce is still in flight (AdamW is elementwise: same bits as one launch).
             # drain() is lazy: the stream waits on bucket i only just before bucket i's update is queued.
             done = 0
             for b, e in (self.reducer.drain(self.grads) if self.reducer.world > 1 else [(0, m._total)]):
-                check(lib().nbci_adamw(C.c_void_p(pw + 4 * b), C.c_void_p(pg + 4 * b), C.c_void_p(pm + 4 * b), C.c_void_p(pv + 4 * b),
-                                       C.c_void_p(plp + 2 * b) if plp else None, e - b, lr, beta1, self.beta2, self.eps, self.wd,
-                                       1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world, _stream()), "nbci_adamw")
+                self._adamw(b, e)
                 done += e - b
             if done != m._total:
                 raise RuntimeError("gradient buckets do not cover the flat parameter buffer")

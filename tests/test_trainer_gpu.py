@@ -143,3 +143,49 @@ def test_host_fed_batches_equal_reference_collate_and_survive_buffer_recycling()
             assert torch.equal(got[k].cpu(), ref[k]), (n, k)
         n += 1
     assert n == 24 and pool.allocated <= 5 * 6          # buffers are recycled: a handful per key, not one per batch
+
+
+@pytest.mark.parametrize("size", ["small", "default"])
+def test_side_stream_backward_gives_the_same_gradients_and_training(size):
+    """nbci_ndt1_io.aux_stream: weight gradients + fold on a second stream, per-segment AdamW + zero_grad behind them. Same kernels,
+    same operands: gradients equal the one-stream backward's up to the order of the f32 atomic sums, and so does training.
+    "small": split-K weight gradients (few output tiles); "default": configs/ndt1.yaml's widths, the grouped launch."""
+    from llm_bci_amd.trainer import NativeTrainer
+    if size == "small":
+        over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
+                            "transformer": {"n_layers": 3, "hidden_size": 128, "n_heads": 1, "inter_size": 128}}}
+        bd = _to_dev(_rand_batch(4, 60, 16, 5, 11, [60, 44, 34, 21], [5, 4, 2, 3]))
+    else:
+        over = {"encoder": {"embedder": {"n_channels": 32}}}
+        bd = _to_dev(_rand_batch(3, 200, 32, 6, 11, [200, 150, 97], [6, 4, 3]))
+    m = _model(over, 11, dtype="bf16").to(DEV)
+    m.train()
+    g1 = torch.zeros(m._total, device=DEV); g2 = torch.zeros(m._total, device=DEV)
+    m._run_forward(bd, want_grad=True, seed=5)
+    m._run_backward(g1)
+    aux = torch.cuda.Stream()
+    aux.wait_stream(torch.cuda.current_stream())
+    for seg in range(len(m._segments) - 1, -1, -1):      # per segment, as the trainer drives it
+        m._run_backward(g2, seg, seg, aux=aux)
+    torch.cuda.current_stream().wait_stream(aux)
+    torch.cuda.synchronize()
+    d = (g1 - g2).abs().max().item()
+    assert g1.abs().max().item() > 0 and d <= 1e-5 * max(1.0, g1.abs().max().item()), d
+    g3 = torch.zeros(m._total, device=DEV)
+    m._run_backward(g3, aux=aux)                          # and the whole backward in one call
+    torch.cuda.current_stream().wait_stream(aux)
+    torch.cuda.synchronize()
+    assert (g1 - g3).abs().max().item() <= 1e-5 * max(1.0, g1.abs().max().item())
+
+    def run(side):
+        mm = _model(over, 11, dtype="bf16").to(DEV)
+        tr = NativeTrainer(mm, total_steps=30, side_stream=side, gradient_accumulation_steps=2)
+        for s in range(7):                      # micro-steps 1, 3, 5, 7 synchronise (trainer.py:335), the others accumulate
+            tr.train_step(bd, seed=s)
+        torch.cuda.synchronize()
+        assert tr.opt_step == 4 and float(tr.grads.abs().max()) == 0.0   # zero_grad happened (side stream: inside the update)
+        return mm._flat.clone(), mm._flat_lp.clone()
+    (a, alp), (b, blp) = run(False), run(True)
+    d = (a - b).abs()
+    assert (d > 2e-5).float().mean() < 0.01 and d.max() < 4.1e-3, (d.max().item(), (d > 2e-5).float().mean().item())
+    assert torch.equal(blp, b.bfloat16())
