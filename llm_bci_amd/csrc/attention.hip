@@ -133,38 +133,50 @@ __device__ __forceinline__ void score_block(const char* sK, const bf16x8 (&qf)[4
     }
 }
 
-// masked softmax of the register-resident row; returns normalised probabilities in place
-template <int NB>
-__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[NB], const AttnArgs& a, const int* kv, int query, int g, float* lse_out) {
+// masked softmax of the register-resident row; returns normalised probabilities in place.
+// kbits: the workgroup's key-valid bits (bit k of word k / 32). Each lane first gathers the bits of ITS keys (block kb, keys
+// 16 kb + 4 g + r -> bit 4 kb + r of vlo / vhi) and sets the diagonal's; per element the test is then one bit (FULLCTX: the context
+// span is unbounded, configs/ndt1.yaml) - the int table + five compares per element this replaces were a third of the kernel's VALU work.
+template <int NB, bool FULLCTX>
+__device__ __forceinline__ void softmax_rows(f32x4 (&acc)[NB], const AttnArgs& a, const unsigned* kbits, int query, int qb, int i16, int g, float* lse_out) {
+    unsigned vlo = 0u, vhi = 0u;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const unsigned nib = (kbits[kb >> 1] >> (16 * (kb & 1) + 4 * g)) & 0xFu;
+        if (kb < 8) vlo |= nib << (4 * kb); else vhi |= nib << (4 * (kb - 8));
+    }
+    if ((i16 >> 2) == g) {   // the diagonal is always attendable (ndt1.py:436)
+        if (qb < 8) vlo |= 1u << (4 * qb + (i16 & 3)); else vhi |= 1u << (4 * (qb - 8) + (i16 & 3));
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-        const int4 k4 = *(const int4*)(kv + 16 * kb + 4 * g);
-        const int kvr[4] = {k4.x, k4.y, k4.z, k4.w};
+        const unsigned nib = kb < 8 ? (vlo >> (4 * kb)) : (vhi >> (4 * (kb - 8)));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kb + 4 * g + r;
-            const bool ok = (key == query) || (ctx_ok(query, key, a.cf, a.cb) && kvr[r] != 0);   // (query < Tp; kv = 0 beyond Tp)
-            const float s = ok ? acc[kb][r] * a.scale : -INFINITY;
+            bool ok = ((nib >> r) & 1u) != 0u;
+            if (!FULLCTX) { const int key = 16 * kb + 4 * g + r; ok = ok && ((key == query) || ctx_ok(query, key, a.cf, a.cb)); }
+            const float s = ok ? acc[kb][r] : -INFINITY;   // (raw scores: the positive scale is applied inside the exponent)
             acc[kb][r] = s;
             mx = fmaxf(mx, s);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c2 = a.scale * 1.4426950408889634f, nm = -mx * c2;   // exp((s - mx) * scale) = exp2(s * c2 - mx * c2); exp2(-inf) = 0
     float sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = (acc[kb][r] == -INFINITY) ? 0.f : __expf(acc[kb][r] - mx);
+            const float e = __builtin_amdgcn_exp2f(fmaf(acc[kb][r], c2, nm));
             acc[kb][r] = e;
             sum += e;
         }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (lse_out && g == 0) *lse_out = mx + __logf(sum);   // (the diagonal is always attendable: sum > 0)
+    if (lse_out && g == 0) *lse_out = mx * a.scale + __logf(sum);   // (the diagonal is always attendable: sum > 0)
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
@@ -185,7 +197,7 @@ static __device__ unsigned long long g_astamps[1024 * 8];
 
 // NB = 16-key blocks held per score row: 10 (T' <= 160), or 9 (T' <= 144) with a 144-row K image and at most 102 registers, so that TWO
 // workgroups (18 waves) share a CU and all B x heads workgroups run in one round
-template <int NB>
+template <int NB, bool FULLCTX>
 __global__ __launch_bounds__(640, NB == 9 ? 5 : 3) void attn_fwd_kernel(AttnArgs a) {   // one wave per 16-query block (<= 10 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ASTAMP(0);
@@ -197,8 +209,16 @@ __global__ __launch_bounds__(640, NB == 9 ? 5 : 3) void attn_fwd_kernel(AttnArgs
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)b * a.Tp * ld + h * AT_HD;
     load_images_kv(sK, sV, base + a.H, base + 2 * a.H, ld, a.Tp, tid, NB * 16);
-    int* sKV = (int*)(smem + (NB * 16 + AT_TPAD) * 256);
-    load_key_valid(sKV, a.tmask + (long long)b * a.Tp, a.Tp, tid);
+    unsigned* sbits = (unsigned*)(smem + (NB * 16 + AT_TPAD) * 256);   // [6] key-valid bits
+    if (tid < 64) {
+        const int32_t* tm = a.tmask + (long long)b * a.Tp;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const int k = 64 * w + lane;
+            const unsigned long long m = __ballot(k < a.Tp && tm[k < a.Tp ? k : 0] != 0);
+            if (lane == 0) { sbits[2 * w] = (unsigned)m; sbits[2 * w + 1] = (unsigned)(m >> 32); }
+        }
+    }
     __syncthreads();
     ASTAMP(1);
     const int nqb = (a.Tp + 15) / 16;
@@ -211,17 +231,17 @@ __global__ __launch_bounds__(640, NB == 9 ? 5 : 3) void attn_fwd_kernel(AttnArgs
         f32x4 acc[NB];
         score_block<NB>(sK, qf, acc, i16, g);
         ASTAMP(2);
-        softmax_rows<NB>(acc, a, sKV, qrow, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
+        softmax_rows<NB, FULLCTX>(acc, a, sbits, qrow, qrow >> 4, qrow & 15, g, a.lse ? a.lse + (long long)blockIdx.x * a.Tp + qrow : nullptr);
         ASTAMP(3);
         if (a.p_thr) {
             const unsigned rbase = (unsigned)(((long long)blockIdx.x * a.Tp + qrow) * a.Tp);
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb)
+            for (int kb = 0; kb < NB; ++kb) {   // (keys >= T' hold p = 0 already; their draws are never looked at)
+                float keep[4];
+                drop4_any(a.p_key, a.p_thr, rbase + (unsigned)(16 * kb + 4 * g), a.p_scale, keep);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 16 * kb + 4 * g + r;
-                    if (key < a.Tp) acc[kb][r] = drop_keep(a.p_key, a.p_thr, rbase + key) ? acc[kb][r] * a.p_scale : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) acc[kb][r] *= keep[r];
+            }
         }
         f32x4 o[8];
         ASTAMP(4);
@@ -689,8 +709,9 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse,
     static bool once = false;
     const int lds = 2 * AT_TPAD * 256 + AT_TPAD * 4, lds9 = (144 + AT_TPAD) * 256 + AT_TPAD * 4;
     if (!once) {
-        int r = set_lds((const void*)attn_fwd_kernel<10>, lds); if (r) return r;
-        r = set_lds((const void*)attn_fwd_kernel<9>, lds9); if (r) return r;
+        int r = set_lds((const void*)attn_fwd_kernel<10, true>, lds); if (r) return r;
+        r = set_lds((const void*)attn_fwd_kernel<10, false>, lds); if (r) return r;
+        r = set_lds((const void*)attn_fwd_kernel<9, true>, lds9); if (r) return r;
         once = true;
     }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
@@ -698,8 +719,13 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse,
     a.ad = (bf16_t*)ad; a.lse = lse;
     const int nblk = (Tp + 15) / 16;
     static const bool nb9 = [] { const char* e = getenv("NBCI_ATTN_NB9"); return !(e && e[0] == '0'); }();
-    if (nb9 && Tp <= 144 && nblk >= 2) hipLaunchKernelGGL(attn_fwd_kernel<9>, dim3(B * nh), dim3(64 * nblk), lds9, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<10>, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
+    const bool full = cf == -2 && cb == -2;
+    if (nb9 && full && Tp <= 144 && nblk >= 2) {   // (with a bounded context span the 96-register variant spills 53 registers: ten-block kernel)
+        hipLaunchKernelGGL((attn_fwd_kernel<9, true>), dim3(B * nh), dim3(64 * nblk), lds9, s, a);
+    } else {
+        if (full) hipLaunchKernelGGL((attn_fwd_kernel<10, true>), dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<10, false>), dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attn_fwd: ") + hipGetErrorString(e));
     return NBCI_OK;

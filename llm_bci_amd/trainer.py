@@ -34,7 +34,7 @@ def register_into(reference_trainer_module):
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
                  div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
-                 compute_per=True, blank_id=0, comm_dtype="fp32", side_stream="auto", side_stream_max_rows=4608):
+                 compute_per=True, blank_id=0, comm_dtype="fp32", side_stream="auto", side_stream_max_rows=1 << 30):
         self.model = model
         self.ga = gradient_accumulation_steps
         self.wd, self.eps, self.beta2 = wd, eps, betas[1]
@@ -62,9 +62,10 @@ class NativeTrainer:
         self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
         self._per_bufs = None
         self._mstream = None   # side stream for the per-step metric (train_step)
-        # Small batches (B x T' rows <= side_stream_max_rows) leave most CUs idle inside every launch of the backward chain, so
-        # the weight-gradient GEMMs, the fold of the bias / LayerNorm gradient sums and the optimizer update of every finished
-        # segment run on a SECOND stream beside it (nbci_ndt1_io.aux_stream). Same kernels, same bits. "auto" | True | False.
+        # One GPU: the weight-gradient GEMMs, the fold of the bias / LayerNorm gradient sums and the optimizer update (+ zero_grad) of
+        # every finished segment run on a SECOND stream beside the data-gradient chain (nbci_ndt1_io.aux_stream). Same kernels, same
+        # bits. Small batches leave most CUs idle inside every launch of the chain (B = 8: -7 % per step); at B = 64 it is still -2 %
+        # (in-box A/B, tools/ab_side_stream.py). "auto" = on when the model supports it and B x T' <= side_stream_max_rows.
         self.side_stream = side_stream
         self.side_stream_max_rows = side_stream_max_rows
         self._aux = None
@@ -154,21 +155,12 @@ class NativeTrainer:
             self._aux = torch.cuda.Stream(device=self.stats.device)
         aux = self._aux
         aux.wait_stream(main)     # (first use; afterwards every step ends with main waiting for aux)
-        import os
-        mb = int(os.environ.get("NBCI_SIDE_BLOCKS", "512"))
-        per_seg = os.environ.get("NBCI_SIDE_ADAMW", "1") == "1"
-        if per_seg:
-            for seg in range(len(m._segments) - 1, -1, -1):
-                m._run_backward(self.grads, seg, seg, aux=aux)
-                if sync:
-                    b, e = m._segments[seg]
-                    with torch.cuda.stream(aux):
-                        self._adamw(b, e, zero=True, max_blocks=mb)
-        else:
-            m._run_backward(self.grads, len(m._segments) - 1, 0, aux=aux)
+        for seg in range(len(m._segments) - 1, -1, -1):
+            m._run_backward(self.grads, seg, seg, aux=aux)
             if sync:
-                with torch.cuda.stream(aux):
-                    self._adamw(0, m._total, zero=True, max_blocks=0)
+                b, e = m._segments[seg]
+                with torch.cuda.stream(aux):   # (256 workgroups: one per CU leaves the chain's workgroups their wave slots; A/B 256 / 512 / 1024)
+                    self._adamw(b, e, zero=True, max_blocks=256)
         main.wait_stream(aux)     # the next forward reads the updated weights and reuses the activations the weight gradients read
         return sync
     def train_step(self, batch, seed=None):
