@@ -38,9 +38,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA = f32 vector peak
-KIND_NAMES = {0: "f32 TN(A^T B^T)", 1: "f32 A^T.B", 2: "f32 A.B(kn)", 3: "f32 NT",
-              4: "bf16 wgrad (A,B row-major-in-k)", 5: "bf16 (A row-major-in-k, B k-major)",
-              6: "bf16 dgrad (A k-major, B row-major-in-k)", 7: "bf16 fwd NT (both k-major)"}
 
 
 def fwd_flops_per_sample(T, N, D=256, S=32, st=4, H=1024, I=1024, L=5, V=41):
@@ -66,52 +63,226 @@ def make_batch(B, T, N, S, vocab, dev, seed, ragged=False):
     return b, {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
 
-def cpu_baseline(budget_s=12.0, T=600, N=256, S=60):
+RIDGE = PEAK_BF16_TFLOPS * 1e12 / 8e12     # FLOP per byte where the bf16 MFMA roof meets the 8 TB/s HBM roof
+
+
+def kernel_table(l, nsteps, peak_tflops=PEAK_BF16_TFLOPS):
+    """nbci_profile_collect_text -> one dict per kernel symbol, by descending time: launches per step, average launch duration (HIP
+    events on the launch's own stream), ALGORITHMIC flops / bytes per launch, achieved rates, the bound its arithmetic intensity
+    puts it under (MFMA above the ridge of 312 FLOP/B, else HBM) and the fraction of that roof; GEMMs carry both fractions."""
+    from llm_bci_amd._lib import check
+    buf = C.create_string_buffer(1 << 16)
+    check(l.nbci_profile_collect_text(buf, 1 << 16), "profile_collect_text")
+    rows = []
+    for line in buf.value.decode().splitlines():
+        sym, n, ms, fl, by = line.split("\t")
+        n, ms, fl, by = int(n), float(ms), float(fl), float(by)
+        if n == 0 or ms <= 0:
+            continue
+        us = 1e3 * ms / n
+        r = {"kernel": sym, "launches_per_step": round(n / nsteps, 2), "avg_launch_us": round(us, 2), "ms_per_step": round(ms / nsteps, 4)}
+        tf = fl / ms / 1e9 if fl > 0 else None           # TFLOP/s
+        gb = by / ms / 1e6 if by > 0 else None           # GB/s
+        if fl > 0:
+            r["gflop_per_launch"] = round(fl / n / 1e9, 3); r["tflops"] = round(tf, 1); r["frac_mfma"] = round(tf / peak_tflops, 4)
+        if by > 0:
+            r["mbytes_per_launch"] = round(by / n / 1e6, 2); r["gbytes_per_s"] = round(gb, 1); r["frac_hbm"] = round(gb / 8000.0, 4)
+        if fl > 0 and by > 0:
+            r["flop_per_byte"] = round(fl / by, 1)
+            r["bound"] = "mfma" if fl / by >= RIDGE else "hbm"
+        elif fl > 0:
+            r["bound"] = "mfma"
+        elif by > 0:
+            r["bound"] = "hbm"
+        else:
+            r["bound"] = "latency"
+        r["frac"] = r.get("frac_mfma") if r["bound"] == "mfma" else r.get("frac_hbm")
+        rows.append(r)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def pmc_traffic(symbol):
+    """HBM-side bytes per launch of `symbol` from the committed counter passes of this round (profiles/r03_pmc_kernels.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, KiB -> bytes), or None."""
+    for nm in ("r03_pmc_kernels.json",):
+        f = os.path.join(ROOT, "profiles", nm)
+        if os.path.exists(f):
+            try:
+                t = json.load(open(f)).get("hbm_bytes_per_launch", {})
+                for k, v in t.items():
+                    if k.replace(" ", "") == symbol.replace(" ", ""):
+                        return v
+            except Exception:
+                pass
+    return None
+
+
+def roofline_from_profile(l, nsteps):
+    rows = kernel_table(l, nsteps)
+    if not rows:
+        return None
+    top = rows[0]
+    tot = sum(r["ms_per_step"] for r in rows)
+    gemm = [r for r in rows if r["kernel"].startswith("gemm")]
+    mf = top["bound"] == "mfma" or "tflops" in top
+    roof = {"bound": "mfma" if mf else "hbm", "achieved": top["tflops"] if mf else top["gbytes_per_s"],
+            "peak": PEAK_BF16_TFLOPS if mf else 8000.0, "unit": "TFLOP/s" if mf else "GB/s",
+            "frac": top["frac_mfma"] if mf else top["frac_hbm"], "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"],
+            "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
+            "flop_per_launch": top.get("gflop_per_launch"), "algorithmic_mbytes_per_launch": top.get("mbytes_per_launch"),
+            "frac_hbm_of_the_same_kernel": top.get("frac_hbm"), "intensity_flop_per_byte": top.get("flop_per_byte"),
+            "ridge_flop_per_byte": round(RIDGE, 1), "share_of_kernel_time": round(top["ms_per_step"] / tot, 3),
+            "kernel_ms_per_step": round(tot, 3), "gemm_ms_per_step": round(sum(r["ms_per_step"] for r in gemm), 3),
+            "all_gemm_tflops": round(sum(r.get("gflop_per_launch", 0) * r["launches_per_step"] for r in gemm) /
+                                     max(1e-9, sum(r["ms_per_step"] for r in gemm)), 1),
+            "timing": "HIP events around every launch on its own stream, 3 steps after the timed windows, everything on ONE stream "
+                      "(the timed windows overlap the weight gradients / AdamW on a second stream: NativeTrainer side_stream)", "per_kernel": rows}
+    return roof
+
+
+def other_model_points(l, dev, steps):
+    """The other rows of BASELINE.json's configs on the same binary (not bench lines): iTransformer SSL at 668 / 1500 channels
+    (configs[2], recipe trainer_ssl_itransformer.yaml: B = 16, T = 100), PatchTST at 1024 channels x 2050 bins with fp8 q/k/v
+    (configs[4], B = 2 per GPU) and the BCI coupler at its real widths (configs[3]: projector 1024 -> 2048 -> 4096 + splice, forward
+    and backward over B = 64 x 143 encoder tokens; the LLM itself is stock and not timed here). Each: full train step (coupler:
+    forward + backward), median-free mean over `steps` steps after 2 warm-up steps, plus the launch-time share and roofline
+    fraction of its top kernel from a 2-step HIP-event pass."""
+    import gc
+    from llm_bci_amd._lib import check
+    from llm_bci_amd.trainer import NativeTrainer
+    out = {}
+    g = np.random.default_rng(0)
+
+    def timed(step_fn, n):
+        for i in range(2):
+            step_fn(10 + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step_fn(100 + i)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n
+        l.nbci_profile_collect_text(C.create_string_buffer(1 << 16), 1 << 16)
+        check(l.nbci_profile_enable(1), "profile_enable")
+        for i in range(2):
+            step_fn(200 + i)
+        torch.cuda.synchronize()
+        check(l.nbci_profile_enable(0), "profile_enable")
+        rows = kernel_table(l, 2)
+        tot = sum(r["ms_per_step"] for r in rows) or 1.0
+        top = [{k: r.get(k) for k in ("kernel", "launches_per_step", "avg_launch_us", "bound", "frac", "frac_mfma", "frac_hbm")} |
+               {"share_of_timed_kernels": round(r["ms_per_step"] / tot, 3)} for r in rows[:3]]
+        return el, top
+
+    def point(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:   # an extra point never takes the bench line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        gc.collect(); torch.cuda.empty_cache()
+
+    def itr(N):
+        from llm_bci_amd.itransformer import iTransformer
+        torch.manual_seed(1)
+        m = iTransformer({"encoder": {"embed_region": False}, "masker": {"main": {"active": True}}}, method_name="mlm", loss="poisson_nll",
+                         log_input=True, compute_dtype="bf16").to(dev)
+        tr = NativeTrainer(m, lr=1e-4, wd=0.01, eps=1e-8, scheduler="cosine", total_steps=100000, warmup_pct=0.15, div_factor=25, compute_per=False)
+        B, T = 16, 100
+        b = {"spikes": torch.from_numpy(g.poisson(0.5, (B, T, N)).astype(np.float32)).to(dev), "spikes_mask": torch.ones(B, T, dtype=torch.int64, device=dev),
+             "spikes_timestamp": torch.arange(T, device=dev).repeat(B, 1)}
+        el, top = timed(lambda sd: tr.train_step(b, seed=sd), steps)
+        S, H, L = N + 1, 768, 5
+        fwd = 2 * B * N * (T * H + H * H) + L * (2 * B * S * 12 * H * H + 4 * B * S * S * H) + 2 * B * S * (H * H + H * T)
+        return {"workload": f"iTransformer mlm, B={B}, T={T}, {N} channels -> {S} tokens, 768 x 8 heads x 5 layers, bf16, masker + AdamW in the step",
+                "ms_per_step": round(1e3 * el, 3), "samples_per_s": round(B / el, 1), "model_tflops_per_s": round(3 * fwd / el / 1e12, 1), "top_kernels": top}
+
+    def ptst():
+        from llm_bci_amd.patchtst import PatchTSTForSpikingActivity
+        torch.manual_seed(1)
+        B, Cn, T = 2, 1024, 2050
+        m = PatchTSTForSpikingActivity({"encoder": {"num_input_channels": Cn, "context_length": T, "do_mask_input": False}}, compute_dtype="fp8",
+                                       method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True).to(dev)
+        tr = NativeTrainer(m, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=100000, warmup_pct=0.0, div_factor=25)
+        b = {"spikes": torch.from_numpy(g.standard_normal((B, T, Cn)).astype(np.float32)).to(dev), "spikes_mask": torch.ones(B, T, dtype=torch.int64, device=dev),
+             "spikes_lengths": torch.full((B,), T, dtype=torch.int64, device=dev), "targets": torch.from_numpy(g.integers(1, 41, (B, 60))).to(dev),
+             "targets_lengths": torch.full((B,), 60, dtype=torch.int64, device=dev)}
+        el, top = timed(lambda sd: tr.train_step(b, seed=sd), max(3, steps // 2))
+        P, D, F, L = 205, 256, 1024, 4
+        M = B * Cn * P
+        fwd = 2 * M * 10 * D + L * (2 * M * (4 * D * D + 2 * D * F) + 4 * B * Cn * P * P * D) + 2 * B * P * D * 41
+        return {"workload": f"PatchTST ctc, B={B}, {Cn} ch x {T} bins -> 205 patches, d_model 256 x 8 heads x 4 layers, fp8 (block-scaled e4m3) q/k/v, rest bf16",
+                "ms_per_step": round(1e3 * el, 3), "samples_per_s": round(B / el, 2), "model_tflops_per_s": round(3 * fwd / el / 1e12, 1), "top_kernels": top}
+
+    def coupler():
+        from llm_bci_amd import bci as BC
+        torch.manual_seed(1)
+        B, Tk, Hn, I, Hl, Lt = 64, 143, 1024, 2048, 4096, 24
+        pj = BC.Projector(Hn, I, Hl, True, "relu").to(dev)
+        w1, b1, w2, b2 = (t.detach() for t in pj.tensors())
+        w1l, w2l = w1.bfloat16(), w2.bfloat16()
+        x = torch.from_numpy(g.standard_normal((B * Tk, Hn)).astype(np.float32)).to(dev).bfloat16()
+        text = torch.from_numpy(g.standard_normal((B, Lt, Hl)).astype(np.float32)).to(dev).bfloat16()
+        amask = torch.ones(B, Lt, dtype=torch.int64, device=dev); valid = torch.ones(B, Tk, dtype=torch.int64, device=dev)
+        split = torch.full((B,), 8, dtype=torch.int64, device=dev)
+        gw1, gb1, gw2, gb2 = (torch.zeros_like(t, dtype=torch.float32) for t in (w1, b1, w2, b2))
+
+        def step(_sd):
+            y, h, dact = BC._proj_forward(x, w1l, b1, w2l, b2, pj.act, True)
+            emb, _m, _t, sp = BC._splice_forward(text, y.view(B, Tk, Hl), amask, valid, None, split)
+            _dt, dsp = BC._splice_backward(emb, sp, B, Lt, Tk, Hl, False)          # (the embeddings stand in for their gradient: same bytes)
+            BC._proj_backward(dsp.view(B * Tk, Hl), x, h, dact, w1l, w2l, gw1, gb1, gw2, gb2, need_dx=True)
+        el, top = timed(step, steps)
+        fl = 3 * 2.0 * B * Tk * (Hn * I + I * Hl)
+        return {"workload": f"BCI coupler alone: projector {Hn} -> {I} -> {Hl} (relu) + splice into {Lt} text embeddings, forward + backward, "
+                            f"B={B} x {Tk} encoder tokens, bf16", "ms_per_step": round(1e3 * el, 3), "samples_per_s": round(B / el, 1),
+                "model_tflops_per_s": round(fl / el / 1e12, 1), "top_kernels": top}
+
+    point("iTransformer_N668_B16", lambda: itr(668))
+    point("iTransformer_N1500_B16", lambda: itr(1500))
+    point("PatchTST_C5_fp8_B2", ptst)
+    point("BCI_coupler_B64", coupler)
+    return out
+
+
+def cpu_baseline(T=600, N=256, S=60):
     """The reference's train step on the host cores: the reference itself cannot travel to this box, so the timed
     thing is oracle/torch_step.py - a PyTorch-CPU restatement of the identical step (forward -> CTC sum -> autograd backward ->
     torch.optim.AdamW + OneCycleLR, fp32, dropout / noise ON as in the recipe), pinned to the reference's outputs by
-    tests/test_oracle_torch_step.py - with torch.set_num_threads(physical cores), at B = 8 and at the recipe's B = 64, each for a
-    bounded sample (about `budget_s` of CPU work). `value` is the better of the two. The numpy oracle's rate (round 1's
-    baseline) is kept as a second field."""
+    tests/test_oracle_torch_step.py. Intra-op threads are SWEPT ({16, 32, 64, all physical cores}: one thread per core of a
+    two-socket box is oversubscribed for these GEMM sizes) on B = 8 steps (1 warm-up + 2 timed each); the recipe's B = 64 then runs
+    at the best count for 1 warm-up + 3 timed steps. `value` = the best samples/s seen, `cores` = the threads that gave it. Bounded:
+    about a minute of CPU work."""
     from oracle import torch_step as TS
     from llm_bci_amd.ndt1 import NDT1
     host = TS.host_cpu_description()
     cores = int(host["physical_cores"])
-    torch.set_num_threads(cores)
     torch.manual_seed(1)
     m = NDT1({}, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="fp32")   # CPU construction only: the reference-order init
     p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    points = {}
-    for B in (8, 64):
+
+    def run(B, threads, timed):
+        torch.set_num_threads(threads)
         tr = TS.TorchCpuTrainer(p0, total_steps=1000)
         _, batch = make_batch(B, T, N, S, 41, "cpu", 0)
         tr.step(batch, train=True)                       # warm-up (thread pool, allocator, oneDNN primitives)
-        n, t0 = 0, time.perf_counter()
-        while True:
+        t0 = time.perf_counter()
+        for _ in range(timed):
             tr.step(batch, train=True)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 12:
-                break
-        points[f"B{B}"] = {"samples_per_s": round(B * n / el, 3), "steps": n, "seconds": round(el, 2)}
-        del tr
-    best = max(points, key=lambda k: points[k]["samples_per_s"])
-    numpy_port = None
-    try:   # round 1's figure, for continuity: the numpy oracle's step (BLAS threads as configured by the environment)
-        from oracle import ndt1 as O
-        from oracle.step import CpuTrainer
-        cfg = O.make_config()
-        ct = CpuTrainer(cfg, O.init_params(cfg, 1), total_steps=1000)
-        bnp, _ = make_batch(4, T, N, S, 41, "cpu", 0)
-        ct.step(bnp, train=True, seed=1)
-        t0 = time.perf_counter(); ct.step(bnp, train=True, seed=2); ct.step(bnp, train=True, seed=3)
-        numpy_port = round(8 / (time.perf_counter() - t0), 3)
-    except Exception:
-        pass
-    return {"value": points[best]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port",
+        el = time.perf_counter() - t0
+        return {"samples_per_s": round(B * timed / el, 3), "steps": timed, "seconds": round(el, 2), "threads": threads}
+
+    cands = sorted({t for t in (16, 32, 64, cores) if 1 <= t <= cores} or {cores})
+    sweep = {f"B8_t{t}": run(8, t, 2) for t in cands}
+    best_t = max(sweep.values(), key=lambda r: r["samples_per_s"])["threads"]
+    b64 = run(64, best_t, 3)
+    points = dict(sweep, **{f"B64_t{best_t}": b64})
+    best = max(points.values(), key=lambda r: r["samples_per_s"])
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
             "sample": f"PyTorch-CPU restatement of the reference step (oracle/torch_step.py: fwd + CTC sum + autograd bwd + AdamW/OneCycle, fp32, "
-                      f"dropout/noise on), {T} bins x {N} ch, 5-layer NDT1, torch {torch.__version__} with {cores} threads; best of {points}",
-            "host_cpu": host, "points": points, "numpy_oracle_samples_per_s": numpy_port,
+                      f"dropout/noise on), {T} bins x {N} ch, 5-layer NDT1, torch {torch.__version__}; intra-op threads swept over {cands} at B=8 "
+                      f"(2 timed steps each), B=64 at the best count ({best_t}) for 3 timed steps; best of all points",
+            "host_cpu": host, "points": points, "recipe_batch_64": b64,
             "reference_eager_8vcpu_build_container": 5.2}
 
 
@@ -309,38 +480,22 @@ def main():
 
     roof = None
     if not args.no_roofline:
-        # per-launch HIP-event timing of every GEMM over 3 more steps (own pass: events perturb the step).
+        # per-launch HIP-event timing of every kernel of the step over 3 more steps (own pass: events perturb the step).
         # Every rank runs the steps (they contain collectives); only rank 0 records and reports.
         l = lib()
         if rank == 0:
+            l.nbci_profile_collect_text(C.create_string_buffer(1 << 16), 1 << 16)   # (drain anything recorded earlier)
             check(l.nbci_profile_enable(1), "profile_enable")
         nprof = 3
+        side = tr.side_stream
+        tr.side_stream = False     # one stream: a per-kernel roofline wants the kernel alone on the chip, not beside the side stream's
         for i in range(nprof):
             tr.train_step(batch, seed=5000 + i + 100003 * rank)
         torch.cuda.synchronize()
+        tr.side_stream = side
     if rank == 0 and not args.no_roofline:
-        out = (C.c_double * 24)()
-        check(l.nbci_profile_collect(out), "profile_collect")
         check(l.nbci_profile_enable(0), "profile_enable")
-        kinds = [(out[k * 3], out[k * 3 + 1], int(out[k * 3 + 2]), k) for k in range(8) if out[k * 3 + 2] > 0]
-        tot_ms = sum(k[0] for k in kinds)
-        ms, fl, cnt, kid = max(kinds)
-        peak = PEAK_BF16_TFLOPS if kid >= 4 else PEAK_F32_TFLOPS
-        ach = fl / ms / 1e9
-        traffic = None   # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/), if present
-        try:
-            for nm in ("r02_pmc_gemm.json", "r01_pmc_gemm.json"):
-                f = os.path.join(ROOT, "profiles", nm)
-                if os.path.exists(f):
-                    traffic = json.load(open(f))["kind_avg_hbm_bytes_per_launch"].get(str(kid))
-                    break
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": traffic, "kernel": f"gemm_kernel<{KIND_NAMES[kid]}>", "launches_per_step": cnt // nprof,
-                "avg_launch_us": round(1e3 * ms / cnt, 2), "flop_per_launch": round(fl / cnt / 1e9, 3),
-                "share_of_gemm_time": round(ms / tot_ms, 3), "gemm_ms_per_step": round(tot_ms / nprof, 3),
-                "all_gemm_tflops": round(sum(k[1] for k in kinds) / tot_ms / 1e9, 1)}
+        roof = roofline_from_profile(l, nprof)
     extra = None
     if world == 1 and not args.no_extra_points:
         # Two more points of the same binary (not bench lines): SURVEY's small batch B = 8 (launch-latency bound) and the recipe
@@ -362,6 +517,7 @@ def main():
         fed["vs_resident_ragged"] = round(fed["ms_per_step"] / rs, 3)
         extra[f"B{args.batch}_ragged_fed_from_host"] = fed
         tr.read_stats()
+        extra["other_models"] = other_model_points(lib(), dev, max(5, args.steps // 2))
     if world > 1:
         dist.barrier()
 

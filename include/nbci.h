@@ -286,6 +286,9 @@ int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t
 /* Frees the scratch buffers the library allocated on its own (the grouped GEMM's partial tiles). Call with the streams idle. */
 int nbci_release_scratch(void);
 int nbci_profile_collect(double* out24);
+/* every kernel a profiling scope brackets (GEMMs, LayerNorm, attention, AdamW, ...), aggregated by kernel symbol: one text line per
+ * symbol "symbol<TAB>launches<TAB>total ms<TAB>algorithmic flops<TAB>algorithmic bytes". Drains the records (as nbci_profile_collect does). */
+int nbci_profile_collect_text(char* buf, int64_t cap);
 
 /* ------------------------------------------------------------------------------------
  * NDT1-CTC model level. Replaces NeuralEncoder.forward + NDT1.forward(ctc) and their autograd

@@ -14,11 +14,11 @@ const char* nbci_last_error(void) { return nbci::g_last_error.c_str(); }
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream) {
     if (!d) return nbci::fail(NBCI_EINVAL, "nbci_gemm: null desc");
-    return nbci::gemm_launch(*d, (hipStream_t)stream);
+    return nbci::gemm_launch_timed(*d, (hipStream_t)stream);
 }
 
 int nbci_gemm_grouped(const nbci_gemm_desc* descs, int32_t n, nbci_stream_t stream) {
-    return nbci::gemm_grouped_launch(descs, n, (hipStream_t)stream);
+    return nbci::gemm_grouped_launch_timed(descs, n, (hipStream_t)stream);
 }
 int nbci_smooth_noise(const float* spikes, void* out, int32_t out_dtype, int32_t B, int32_t T, int32_t N, const float* taps,
                       int32_t ntaps, float white_sd, float offset_sd, uint32_t seed, nbci_stream_t stream) {
@@ -61,10 +61,12 @@ int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_l
 }
 int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, float bc1, float bc2, float grad_scale, nbci_stream_t stream) {
+    nbci::ProfScope ps("adamw_kernel<false>", 0.0, (double)n * (p_lp ? 30.0 : 28.0), (hipStream_t)stream);
     return nbci::adamw_launch(p, const_cast<float*>(g), m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream);
 }
 int nbci_adamw_zero(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float bc1, float bc2, float grad_scale, int32_t max_blocks, nbci_stream_t stream) {
+    nbci::ProfScope ps("adamw_kernel<true>", 0.0, (double)n * (p_lp ? 34.0 : 32.0), (hipStream_t)stream);
     return nbci::adamw_launch(p, g, m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream, true, max_blocks);
 }
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream) {
@@ -113,6 +115,10 @@ int nbci_debug_gemm_streamk(int32_t mode) {
 int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
 int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8) { return nbci::gemm_grouped_describe(descs, n, out8); }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
+int nbci_profile_collect_text(char* buf, int64_t cap) {
+    if (!buf || cap < 1) return nbci::fail(NBCI_EINVAL, "profile_collect_text: null output");
+    return nbci::prof_collect_text(buf, cap);
+}
 int nbci_profile_collect(double* out24) {
     if (!out24) return nbci::fail(NBCI_EINVAL, "profile_collect: null output");
     return nbci::gemm_profile_collect(out24);

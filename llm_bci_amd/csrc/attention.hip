@@ -720,6 +720,7 @@ int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse,
     const int nblk = (Tp + 15) / 16;
     static const bool nb9 = [] { const char* e = getenv("NBCI_ATTN_NB9"); return !(e && e[0] == '0'); }();
     const bool full = cf == -2 && cb == -2;
+    if (prof_on()) prof_note_symbol((nb9 && full && Tp <= 144 && nblk >= 2) ? "attn_fwd_kernel<9, true>" : (full ? "attn_fwd_kernel<10, true>" : "attn_fwd_kernel<10, false>"));
     if (nb9 && full && Tp <= 144 && nblk >= 2) {   // (with a bounded context span the 96-register variant spills 53 registers: ten-block kernel)
         hipLaunchKernelGGL((attn_fwd_kernel<9, true>), dim3(B * nh), dim3(64 * nblk), lds9, s, a);
     } else {
@@ -758,12 +759,14 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const
             once3 = true;
         }
         const dim3 blk(64 * (nblk < 2 ? 2 : nblk));
+        if (prof_on()) prof_note_symbol((cf == -2 && cb == -2) ? "attn_bwd_fused_kernel<true>" : "attn_bwd_fused_kernel<false>");
         if (cf == -2 && cb == -2) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(B * nh), blk, lds3, s, a);
         else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(B * nh), blk, lds3, s, a);
         hipError_t e3 = hipGetLastError();
         if (e3 != hipSuccess) return fail(NBCI_EHIP, std::string("attn_bwd (one launch): ") + hipGetErrorString(e3));
         return NBCI_OK;
     }
+    if (prof_on()) prof_note_symbol("attn_bwd_dq_kernel + attn_bwd_dkv_kernel");
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * nh), dim3(64 * (nblk < 2 ? 2 : nblk)), lds1, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * nh, 2), dim3(64 * (nblk < 2 ? 2 : nblk)), lds2, s, a);
     hipError_t e = hipGetLastError();

@@ -594,6 +594,7 @@ static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
 
 int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
     NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh), NBCI_ESHAPE, "flash attention: bf16, head size 32 / 64 / 96 / 128");
+    ProfScope ps("fa_fwd_kernel", 4.0 * S * S * H * NS, 2.0 * NS * S * 4 * H, s);   // q, k, v in; merged output out
     FAArgs a{};
     int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
     if (rc != NBCI_OK) return rc;
@@ -604,6 +605,7 @@ int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S
 int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int NS, int nh, int S, int H,
                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
     NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh), NBCI_ESHAPE, "flash attention: bf16, head size 32 / 64 / 96 / 128");
+    ProfScope ps("fa_bwd_kernels (dq + dk/dv)", 10.0 * S * S * H * NS, 2.0 * NS * S * 8 * H, s);   // q, k, v, out, d out in; dq, dk, dv out
     FAArgs a{};
     int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
     if (rc != NBCI_OK) return rc;

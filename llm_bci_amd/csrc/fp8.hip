@@ -204,6 +204,7 @@ int gemm_fp8_launch(const void* A8, const void* sA, const void* W8, const void* 
     NBCI_REQUIRE(((uintptr_t)A8) % 16 == 0 && ((uintptr_t)W8) % 16 == 0, NBCI_EALIGN, "gemm_fp8: operands must be 16-byte aligned");
     const long long tiles = (M + 127) / 128;
     NBCI_REQUIRE(tiles < (1ll << 31), NBCI_ESHAPE, "gemm_fp8: too many row tiles");
+    ProfScope ps("gemm_fp8_kernel", 2.0 * M * N * K, (double)M * K * 33.0 / 32.0 + (double)N * K * 33.0 / 32.0 + (double)M * N * (c_dtype == NBCI_BF16 ? 2 : 4), s);
     dim3 grid((unsigned)tiles);
     if (c_dtype == NBCI_BF16)
         gemm_fp8_dispatch<bf16_t>(K / 128, grid, s, (const uint8_t*)A8, (const uint8_t*)sA, (const uint8_t*)W8, (const uint8_t*)sW, bias, (bf16_t*)C, M, N, ldc);

@@ -17,6 +17,7 @@
 // 4 CONSECUTIVE n for one m: epilogue loads/stores are 16-byte (f32) / 8-byte (bf16) wide.
 #include <set>
 #include <cstdio>
+#include <cstring>
 #include "gemm_common.h"
 
 namespace nbci {
@@ -141,6 +142,10 @@ static int launch_inst(const GemmK& k, dim3 grid, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AK, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, epi);
         if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm: LDS attribute: ") + hipGetErrorString(e));
         attr_set = true;
+    }
+    if (prof_on()) {
+        static const std::string sym = std::string("gemm_kernel<") + (sizeof(T) == 2 ? "__bf16" : "float") + ", " + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ">";
+        prof_note_symbol(sym.c_str());
     }
     hipLaunchKernelGGL((gemm_kernel<T, AK, BKM>), grid, dim3(GEMM_THREADS), lds, stream, k);
     hipError_t e = hipGetLastError();
@@ -286,55 +291,105 @@ int gemm_grouped_launch(const nbci_gemm_desc* descs, int n, hipStream_t stream) 
 
 }  // namespace nbci
 
-// ---- optional per-launch timing (bench.py roofline leg): HIP events around every GEMM launch ----
+// ---- optional per-launch timing (bench.py roofline leg): HIP events around every launch a ProfScope brackets ----
+#include <map>
+#include <mutex>
 #include <vector>
 namespace nbci {
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int kind; std::string name; };
+static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static thread_local ProfRec t_open;          // the scope this thread has open (launches do not nest)
+static thread_local bool t_open_valid = false;
 
-void gemm_profile_enable(bool on) { g_prof_on = on; }
+void gemm_profile_enable(bool on) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_on = on; }
 bool gemm_profile_on() { return g_prof_on; }
+bool prof_on() { return g_prof_on; }
+
+void prof_begin(const char* name, double flops, double bytes, int kind, hipStream_t s) {
+    if (t_open_valid) return;                // (a nested scope: the outer one times the launch)
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    r.flops = flops; r.bytes = bytes; r.kind = kind; r.name = name ? name : "";
+    (void)hipEventRecord(r.a, s);
+    t_open = r; t_open_valid = true;
+}
+void prof_note_symbol(const char* sym) { if (t_open_valid && sym) t_open.name = sym; }
+void prof_end(hipStream_t s) {
+    if (!t_open_valid) return;
+    (void)hipEventRecord(t_open.b, s);
+    { std::lock_guard<std::mutex> l(g_prof_mu); g_prof.push_back(t_open); }
+    t_open_valid = false;
+}
+
+static double gemm_bytes(const nbci_gemm_desc& d) {   // operands once in, result once out (+ the residual / gate / second output the epilogue touches)
+    const double es = d.in_dtype == NBCI_BF16 ? 2 : 4, cs = d.c_dtype == NBCI_BF16 ? 2 : 4, batch = d.batch > 0 ? d.batch : 1;
+    double b = es * ((double)d.M * d.K + (double)d.N * d.K) * batch + cs * (double)d.M * d.N * batch;
+    if (d.residual && !d.residual_rows) b += 4.0 * d.M * d.N * batch;
+    if (d.gate) b += es * (double)d.M * d.N * batch;
+    if (d.C2) b += cs * (double)d.M * d.N * batch;
+    if (d.beta != 0.f) b += cs * (double)d.M * d.N * batch;
+    return b;
+}
 
 int gemm_launch_timed(const nbci_gemm_desc& d, hipStream_t stream) {
     if (!g_prof_on) return gemm_launch(d, stream);
-    ProfRec r;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return fail(NBCI_EHIP, "event create");
     const int batch = d.batch > 0 ? d.batch : 1;
-    r.flops = 2.0 * d.M * (double)d.N * d.K * batch;
-    r.kind = (d.in_dtype == NBCI_BF16 ? 4 : 0) + (d.A.kmajor ? 2 : 0) + (d.B.kmajor ? 1 : 0);
-    (void)hipEventRecord(r.a, stream);
-    const int rc = gemm_launch(d, stream);
-    (void)hipEventRecord(r.b, stream);
-    g_prof.push_back(r);
-    return rc;
+    ProfScope ps("gemm", 2.0 * d.M * (double)d.N * d.K * batch, gemm_bytes(d), stream, kind_of(d));
+    return gemm_launch(d, stream);
 }
 
-// out[kind] = {total ms, total flops, launches} for kind = dtype*4 + A.kmajor*2 + B.kmajor (8 kinds)
 int gemm_grouped_launch_timed(const nbci_gemm_desc* descs, int n, hipStream_t stream) {
     if (!g_prof_on) return gemm_grouped_launch(descs, n, stream);
-    ProfRec r;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return fail(NBCI_EHIP, "event create");
-    r.flops = 0.0;
-    for (int i = 0; i < n; ++i) r.flops += 2.0 * descs[i].M * (double)descs[i].N * descs[i].K;
-    r.kind = (descs[0].in_dtype == NBCI_BF16 ? 4 : 0) + (descs[0].A.kmajor ? 2 : 0) + (descs[0].B.kmajor ? 1 : 0);
-    (void)hipEventRecord(r.a, stream);
-    const int rc = gemm_grouped_launch(descs, n, stream);
-    (void)hipEventRecord(r.b, stream);
-    g_prof.push_back(r);
+    double fl = 0.0, by = 0.0;
+    for (int i = 0; i < n; ++i) { fl += 2.0 * descs[i].M * (double)descs[i].N * descs[i].K; by += gemm_bytes(descs[i]); }
+    ProfScope ps("gemm_grouped", fl, by, stream, kind_of(descs[0]));
+    return gemm_grouped_launch(descs, n, stream);
+}
+
+static int prof_drain(std::vector<ProfRec>& out) {
+    { std::lock_guard<std::mutex> l(g_prof_mu); out.swap(g_prof); }
+    return NBCI_OK;
+}
+
+// out[kind] = {total ms, total flops, launches} for the GEMM launches, kind = dtype*4 + A.kmajor*2 + B.kmajor (8 kinds); other
+// records are dropped. (Kept for callers of the first interface; prof_collect_text reports every kernel.)
+int gemm_profile_collect(double* out24) {
+    for (int i = 0; i < 24; ++i) out24[i] = 0.0;
+    std::vector<ProfRec> recs;
+    prof_drain(recs);
+    int rc = NBCI_OK;
+    for (auto& r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = fail(NBCI_EHIP, "profile collect");
+        else if (r.kind >= 0 && r.kind < 8) { out24[r.kind * 3 + 0] += ms; out24[r.kind * 3 + 1] += r.flops; out24[r.kind * 3 + 2] += 1.0; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
     return rc;
 }
 
-int gemm_profile_collect(double* out24) {
-    for (int i = 0; i < 24; ++i) out24[i] = 0.0;
-    for (auto& r : g_prof) {
+int prof_collect_text(char* buf, long long cap) {
+    std::vector<ProfRec> recs;
+    prof_drain(recs);
+    struct Agg { double ms = 0, flops = 0, bytes = 0; long n = 0; };
+    std::map<std::string, Agg> agg;
+    int rc = NBCI_OK;
+    for (auto& r : recs) {
         float ms = 0.f;
-        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
-            return fail(NBCI_EHIP, "profile collect");
-        out24[r.kind * 3 + 0] += ms; out24[r.kind * 3 + 1] += r.flops; out24[r.kind * 3 + 2] += 1.0;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = fail(NBCI_EHIP, "profile collect");
+        else { Agg& a = agg[r.name]; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.n += 1; }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
-    g_prof.clear();
-    return NBCI_OK;
+    std::string out;
+    char line[640];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+        out += line;
+    }
+    if ((long long)out.size() + 1 > cap) return fail(NBCI_EINVAL, "profile_collect_text: buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return rc;
 }
 }  // namespace nbci

@@ -288,6 +288,11 @@ static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
         if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms: LDS attribute: ") + hipGetErrorString(e));
         attr = true;
     }
+    if (prof_on()) {
+        static const std::string sym = std::string("gemm_glds_ms_kernel<") + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ", " + std::to_string(WM) + ", " +
+                                       std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + std::to_string(NSTAGE) + ">";
+        prof_note_symbol(sym.c_str());
+    }
     hipLaunchKernelGGL((gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>), grid, dim3(WM * WN * 64), lds, s, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms launch: ") + hipGetErrorString(e));
@@ -323,6 +328,11 @@ static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds: LDS attribute: ") + hipGetErrorString(e));
         attr_set = true;
+    }
+    if (prof_on()) {
+        static const std::string sym = std::string("gemm_glds_kernel<") + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ", " + std::to_string(WM) + ", " +
+                                       std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + (VIEW ? "true" : "false") + ">";
+        prof_note_symbol(sym.c_str());
     }
     hipLaunchKernelGGL((gemm_glds_kernel<AK, BKM, WM, WN, MI, NI, VIEW>), grid, dim3(GEMM_THREADS), lds, s, k);
     hipError_t e = hipGetLastError();
@@ -373,6 +383,7 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(NBCI_EHIP, "gemm group: LDS attribute");
         attr_set = true;
     }
+    if (prof_on()) prof_note_symbol((std::string("gemm_glds_group_kernel<") + (ak ? "true" : "false") + ", " + (bk ? "true" : "false") + ">").c_str());
     if (ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, grp);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<false, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);

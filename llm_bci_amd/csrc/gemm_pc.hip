@@ -282,6 +282,7 @@ int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         attr = true;
     }
     dim3 grid(k.tiles_m * k.tiles_n, batch);
+    if (prof_on()) prof_note_symbol(d.B.kmajor ? "gemm_pc_kernel<true>" : "gemm_pc_kernel<false>");
     if (d.B.kmajor) hipLaunchKernelGGL((gemm_pc_kernel<true>), grid, dim3(PC_THREADS), PC_LDS, stream, k);
     else hipLaunchKernelGGL((gemm_pc_kernel<false>), grid, dim3(PC_THREADS), PC_LDS, stream, k);
     hipError_t e = hipGetLastError();

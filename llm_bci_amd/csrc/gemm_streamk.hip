@@ -471,6 +471,7 @@ int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hip
         attr_set = true;
     }
     dim3 grid(slots);
+    if (prof_on()) prof_note_symbol((std::string("gemm_streamk_kernel<") + (ak ? "true" : "false") + ", " + (bk ? "true" : "false") + ">").c_str());
     if (ak && bk) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, s);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, s);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, dim3(GEMM_THREADS), lds, stream, s);

@@ -260,6 +260,7 @@ static void ln_fwd_dispatch(int nv, dim3 g, hipStream_t s, const float* x, const
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
                          int M, int H, hipStream_t s, float* y32) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "layernorm: hidden must be a multiple of 4 and <= 4096");
+    ProfScope ps("ln_fwd_kernel", 0.0, (double)M * H * (4 + (y_dtype == NBCI_BF16 ? 2 : 4) + (y32 ? 4 : 0)), s);
     const int nv = (H + 255) / 256;
     dim3 g((M + 3) / 4);
     DISPATCH_DTYPE(y_dtype, TO, ln_fwd_dispatch<TO>(nv, g, s, x, w, b, (TO*)y, mean, rstd, M, H, y32));
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
 int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz, int dy_bf16) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
+    ProfScope ps("ln_bwd_kernel", 0.0, (double)M * H * ((dy_bf16 ? 2 : 4) + 4 + 4 + (accumulate_dx ? 4 : 0) + (cz.out ? (cz.bf16 ? 2 : 4) : 0)), s);
     const int nv = (H + 255) / 256;
     const int iters = lnb_iters(M), rows = 4 * LNB_RPW * iters;
     dim3 g((M + rows - 1) / rows);

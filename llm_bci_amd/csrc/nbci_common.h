@@ -37,6 +37,20 @@ int fail(int code, const std::string& msg);
         if (!(cond)) return ::nbci::fail((code), (msg)); \
     } while (0)
 
+// Per-launch timing of ANY kernel of the library (bench.py's roofline leg; off by default, no cost beyond one branch): a scope records
+// a HIP event on the launch's stream before and after it together with the launch's ALGORITHMIC work (flops, bytes: operands read
+// once, results written once). The launcher that picks a template instantiation notes the kernel's symbol (as rocprofv3 prints it).
+bool prof_on();
+void prof_begin(const char* name, double flops, double bytes, int gemm_kind, hipStream_t s);
+void prof_end(hipStream_t s);
+void prof_note_symbol(const char* sym);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t st, int kind = -1) : s(st), on(prof_on()) { if (on) prof_begin(name, flops, bytes, kind, st); }
+    ~ProfScope() { if (on) prof_end(s); }
+};
+int prof_collect_text(char* buf, long long cap);   // one line per symbol: "symbol\tlaunches\tms\tflops\tbytes\n"
+
 // ---- bf16 <-> f32 (plain casts: hipcc emits v_cvt_pk_bf16_f32, NaN-preserving) ----
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }

@@ -293,8 +293,9 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     TRY(token_prep_launch(io->spikes_mask, io->spikes_timestamp, io->spikes_lengths, B, T, Tk, c.stack_size, c.stack_stride,
                           (int32_t*)(ws + w.tmask), (int64_t*)(ws + w.tts), (int32_t*)(ws + w.tlens), s, npre));
     const bool noise = train && c.noise;
-    TRY(smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
-                            noise ? c.constant_offset_sd : 0.f, io->seed, s));
+    TRYP("smooth_noise_kernel", 0, (double)B * T * c.n_channels * (4 + es), s,
+         smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
+                             noise ? c.constant_offset_sd : 0.f, io->seed, s));
     // 1. embed Linear + activation (ndt1.py:173-176)
     if (c.adapt_days > 0) {
         // day-specific layers: each sample's day weights gathered side by side -> ONE batched GEMM (batch = sample); the day's bias
@@ -344,8 +345,9 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         float* x_mid = (float*)(ws + lw.x_mid);
         float* x_out = (float*)(ws + (l + 1 < c.n_layers ? w.L[l + 1].x_in : w.x_last));
         // ---- attention block (ndt1.py:266-292,325)
-        TRY(layernorm_fwd_launch(x_in, params + lo.ln1w, params + lo.ln1b, ws + lw.h1, dt, (float*)(ws + lw.mean1),
-                                 (float*)(ws + lw.rstd1), M, H, s));
+        TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
+             layernorm_fwd_launch(x_in, params + lo.ln1w, params + lo.ln1b, ws + lw.h1, dt, (float*)(ws + lw.mean1),
+                                  (float*)(ws + lw.rstd1), M, H, s));
         {
             nbci_gemm_desc d = gd(M, 3 * H, H, dt, op(ws + lw.h1, es, 0, H, 1), op(x.W(lo.qw), es, 0, H, 1), ws + lw.qkv,
                                   3 * H, dt);
@@ -355,11 +357,13 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         if (c.use_rope)
             TRY(rope_launch(ws + lw.qkv, dt, (const int64_t*)(ws + w.tts), io->rope_cos, io->rope_sin, M, H, nh, 0, s));
         if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
-            TRY(attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H, c.context_forward,
-                                c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
+            TRYP("attn_fwd_kernel", 4.0 * Tp * Tp * hd * B * nh, (double)M * 4 * H * es, s,   // bytes: q, k, v in; merged output out
+                 attn_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H, c.context_forward,
+                                 c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
         } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // longer than the one-workgroup kernel holds (T' > 160), or another head size
-            TRY(fattn_masked_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H,
-                                        c.context_forward, c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
+            TRYP("fa_fwd_kernel", 4.0 * Tp * Tp * hd * B * nh, (double)M * 4 * H * es, s,
+                 fattn_masked_fwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (float*)(ws + lw.lse), B, nh, Tp, H,
+                                         c.context_forward, c.context_backward, p_lay, io->seed, 16 + 4 * l, 17 + 4 * l, s));
         } else {
             {   // scores = q k^T / sqrt(hd), batched over (b, head)
                 nbci_gemm_desc d = gd(Tp, Tp, hd, dt, op(ws + lw.qkv, es, 0, 3 * H, 1, 0, 0, (int64_t)Tp * 3 * H, hd),
@@ -386,8 +390,9 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             TRY(gemm_launch_timed(d, s));
         }
         // ---- MLP block (ndt1.py:224-227,328)
-        TRY(layernorm_fwd_launch(x_mid, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
-                                 (float*)(ws + lw.rstd2), M, H, s));
+        TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
+             layernorm_fwd_launch(x_mid, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
+                                  (float*)(ws + lw.rstd2), M, H, s));
         {
             nbci_gemm_desc d = gd(M, I, H, dt, op(ws + lw.h2, es, 0, H, 1), op(x.W(lo.upw), es, 0, H, 1), ws + lw.g, I, dt);
             d.bias = params + lo.upb; d.act = c.mlp_act; d.C2 = ws + lw.u; d.c2_grad = 1;   // lw.u holds act'(u)
@@ -401,8 +406,9 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         }
     }
     // ---- out_norm + decoder + log-softmax (+ CTC) (ndt1.py:442,494-499,545,581)
-    TRY(layernorm_fwd_launch((const float*)(ws + w.x_last), params + p.onw, params + p.onb, ws + w.xo, dt,
-                             (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
+    TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
+         layernorm_fwd_launch((const float*)(ws + w.x_last), params + p.onw, params + p.onb, ws + w.xo, dt,
+                              (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
     const int FS = c.factors_size;
     const void* enc_out = ws + w.xo;   // what the decoder (and a coupler) reads: out_norm(x), or its factors projection
     const int Kd = FS > 0 ? FS : H;
@@ -423,7 +429,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
         TRY(gemm_launch_timed(d, s));
     }
     int32_t* amax = io->argmax ? io->argmax : (int32_t*)(ws + w.argmax);
-    TRY(logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, Mk, c.vocab, s));
+    TRYP("logsoftmax_kernel", 0, (double)Mk * (w.vpad + c.vocab) * 4, s, logsoftmax_launch((const float*)(ws + w.logits), w.vpad, io->preds, amax, Mk, c.vocab, s));
     if (io->token_mask_out)   // (B,T'): the spike tokens' validity (the reference's mask also carries the prefix ones; its x does not)
         NBCI_CHECK_HIP(hipMemcpy2DAsync(io->token_mask_out, (size_t)Tk * 4, ws + w.tmask + (size_t)npre * 4, (size_t)Tp * 4, (size_t)Tk * 4, B,
                                         hipMemcpyDeviceToDevice, s));
@@ -432,9 +438,10 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
                                         (size_t)Tk * Kd * es, B, hipMemcpyDeviceToDevice, s));
     if (io->targets) {
         NBCI_REQUIRE(io->targets_lengths && io->loss && S > 0, NBCI_EINVAL, "ndt1: targets need targets_lengths, loss and S > 0");
-        TRY(ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tk, c.vocab, S, c.blank_id,
-                       c.zero_infinity, io->loss, (float*)(ws + w.alpha), io->want_grad ? ws + w.dlogits : nullptr, dt, w.vpad,
-                       io->grad_scale, s));
+        TRYP("ctc_kernel", 0, 0, s,   // (serial in T': latency-bound, no roofline)
+             ctc_launch(io->preds, io->targets, (const int32_t*)(ws + w.tlens), io->targets_lengths, B, Tk, c.vocab, S, c.blank_id,
+                        c.zero_infinity, io->loss, (float*)(ws + w.alpha), io->want_grad ? ws + w.dlogits : nullptr, dt, w.vpad,
+                        io->grad_scale, s));
     }
     return NBCI_OK;
 }
@@ -554,7 +561,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 }
             }
             if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
-            TRY(layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
+            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
+                 layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
                                      (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1),
                                      d_xo_lp));
         } else if (seg >= 1) {
@@ -584,7 +592,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + o_dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
+            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
+                 layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
                                      (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
                                      dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
                                                     : LnCast{ws + o_dA2, 1, 0u, 1.f, 0u, RG(lo.ob)},
@@ -610,9 +619,10 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             bool bias_in_attn = false;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
                 bias_in_attn = attn_bias && !c.use_rope;
-                TRY(attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + o_dqkv,
-                                    bias_in_attn ? RG(lo.qb) : nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
-                                    io->seed, 16 + 4 * l, s, rc));
+                TRYP("attn_bwd_kernel", 10.0 * Tp * Tp * hd * B * nh, (double)M * 8 * H * es, s,   // bytes: q, k, v, out, d out in; dq, dk, dv out
+                     attn_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, (const float*)(ws + lw.lse), ws + w.dB2, ws + w.dS, ws + lw.Pd, w.ldP, ws + o_dqkv,
+                                     bias_in_attn ? RG(lo.qb) : nullptr, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
+                                     io->seed, 16 + 4 * l, s, rc));
             } else if (p.flash_attn && Tp >= p.flash_min && fattn_eligible(dt, Tp, H, nh)) {   // (Dsum lives in the score buffer, unused on this path)
                 TRY(fattn_masked_bwd_launch(ws + lw.qkv, (const int32_t*)(ws + w.tmask), ws + lw.ad, ws + w.dB2, (const float*)(ws + lw.lse),
                                             (float*)(ws + w.scores), ws + o_dqkv, B, nh, Tp, H, c.context_forward, c.context_backward, p_lay,
@@ -662,7 +672,8 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
             if (two) NBCI_CHECK_HIP(hipStreamWaitEvent(s, p.ev_wg[(l + 1) & 1], 0));   // the cast below rewrites dA[(l - 1) & 1], which layer l + 1's weight gradients read
-            TRY(layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
+            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
+                 layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
                                      (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1),
                                      dt == NBCI_BF16 ? 1 : 0));
         } else {
@@ -681,7 +692,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int part = io->embed_part;
             NBCI_REQUIRE(part >= 0 && part <= 2, NBCI_EINVAL, "ndt1: embed_part must be 0, 1 or 2");
             if (part != 2) {
-            if (c.pos) TRY(posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre));
+            if (c.pos) TRYP("posgrad_kernel", 0, (double)Mk * H * 4, s, posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre));
             if (npre) {   // the prefix tokens' tables: [day, block] order as assembled in the forward
                 int k = 0;
                 if (c.day_token_days > 0) TRY(prefix_grad_launch(dx, io->day_idx, grads + p.dayemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
@@ -748,7 +759,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     if (seg_lo == 0 && io->embed_part == 2) chi = p.compact_of(p.stkb);
     if (chi > clo) {
         TRY(fork());
-        TRY(fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, aux));
+        TRYP("fold_replicas_kernel", 0, (double)(chi - clo) * (rc.n + 1) * 4, aux, fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, aux));
     }
     return NBCI_OK;
 }

@@ -97,6 +97,14 @@ struct WgradQueue {
     }
 };
 
+// TRY with a profiling scope (kernels.h ProfScope): name = the kernel's symbol (a launcher may refine it), algorithmic flops / bytes
+#define TRYP(name, flops, bytes, s, call)                              \
+    do {                                                               \
+        ::nbci::ProfScope _ps((name), (double)(flops), (double)(bytes), (s)); \
+        int _r = (call);                                               \
+        if (_r != NBCI_OK) return _r;                                  \
+    } while (0)
+
 #define TRY(x)                    \
     do {                          \
         int _r = (x);             \
