@@ -702,3 +702,163 @@ if __name__ == "__main__" and "--ptst" in sys.argv:
     ptst_case("g_ptst_tiny_mlm_rate", ptst_tiny(do_mask_input=True, random_mask_ratio=0.4), "mlm", 3, [45, 38, 30], log_input=False)
     ptst_case("g_ptst_c5", {"encoder": {"num_input_channels": 128, "context_length": 2050, "attention_dropout": 0.0, "ff_dropout": 0.0,
                                          "do_mask_input": False}}, "ctc", 2, [2050, 1500], [60, 40], vocab=41, full=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint interchange — `--ckpt`
+#   forward : the REFERENCE's save_checkpoint (ndt1.py:685-688, bci.py:250-257, itransformer.py:403-407, patchtst.py:258-262) on tiny
+#             configs -> tests/golden/ckpt_<model>/ (the files it wrote, nothing else) + expected.npz (inputs, eval outputs, checksums of
+#             every state-dict tensor). GPU / CPU tests load these directories with the native load_checkpoint / from_pt.
+#   reverse : a NATIVE model built on the CPU writes its checkpoint to a temp dir; the REFERENCE loads it (from_pt / load_checkpoint) and
+#             every state-dict tensor must be equal. Build container only (needs the reference); the outcome is recorded in
+#             tests/golden/ckpt_reverse_check.json.
+# ------------------------------------------------------------------------------------------------
+def _sd_summary(sd):
+    return {k: [list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
+
+
+def ckpt_cases():
+    import shutil
+    import tempfile
+    import types
+    REPO = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, REPO)
+    peft = types.ModuleType("peft"); peft.LoraConfig = None; peft.get_peft_model = None
+    sys.modules.setdefault("peft", peft)
+    _install_torchvision_mlp()
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from models.bci import BCI
+    from models.itransformer import iTransformer
+    from models.patchtst import PatchTSTForSpikingActivity
+    if sys.modules.get("peft") is peft:
+        del sys.modules["peft"]       # (the import stand-in: transformers' from_pretrained probes for the real package)
+    reverse = {}
+
+    def fresh(d):
+        p = os.path.join(OUT, d)
+        shutil.rmtree(p, ignore_errors=True)
+        os.makedirs(p)
+        return p
+
+    def same(a, b):
+        assert a.keys() == b.keys(), (sorted(a.keys() ^ b.keys()))
+        for k in a:
+            assert torch.equal(a[k].float().cpu(), b[k].float().cpu()), k
+        return len(a)
+
+    # ---------------- NDT1 (ctc, tiny) ----------------
+    over = det(tiny())
+    cfg = update_config("configs/ndt1.yaml", over)
+    torch.manual_seed(7)
+    ref = NDT1(cfg, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    d = fresh("ckpt_ndt1")
+    ref.save_checkpoint(d)
+    rows, batch, _ = make_batch(ref, [40, 33, 21], 16, [5, 4, 2], 11, seed=3)
+    ref.eval()
+    with torch.no_grad():
+        out = ref(**batch)
+    fx = {"in_" + k: v.numpy() for k, v in batch.items()}
+    fx.update(preds=out.preds.numpy(), loss=out.loss.numpy(), config_json=np.array(json.dumps(over)),
+              state_json=np.array(json.dumps(_sd_summary(ref.state_dict()))))
+    np.savez_compressed(os.path.join(d, "expected.npz"), **fx)
+    # reverse
+    from llm_bci_amd.ndt1 import NDT1 as NNDT1
+    torch.manual_seed(11)
+    nat = NNDT1(json.loads(json.dumps(over)), method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True, compute_dtype="fp32")
+    with tempfile.TemporaryDirectory() as td:
+        nat.save_checkpoint(td)
+        o2 = json.loads(json.dumps(over)); o2["encoder"]["from_pt"] = td
+        r2 = NDT1(update_config("configs/ndt1.yaml", o2), method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)   # ndt1.py:468-476,503-504
+        n = same(dict(nat.state_dict()), dict(r2.state_dict()))
+        r3 = NDT1(cfg, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+        r3.load_checkpoint(td)
+        same(dict(nat.state_dict()), dict(r3.state_dict()))
+    reverse["NDT1"] = {"reference_from_pt_equal_tensors": n, "reference_load_checkpoint": "equal"}
+
+    # ---------------- iTransformer (mlm, tiny) ----------------
+    iover = itr_tiny()
+    icfg = update_config("configs/itransformer.yaml", iover)
+    torch.manual_seed(7)
+    iref = iTransformer(icfg, method_name="mlm", log_input=True, loss="poisson_nll")
+    d = fresh("ckpt_itransformer")
+    iref.save_checkpoint(d)
+    np.savez_compressed(os.path.join(d, "expected.npz"), config_json=np.array(json.dumps(iover)),
+                        state_json=np.array(json.dumps(_sd_summary({k: v for k, v in iref.state_dict().items() if not k.startswith("masker")}))))
+    from llm_bci_amd.itransformer import iTransformer as NITR
+    torch.manual_seed(11)
+    inat = NITR(json.loads(json.dumps(iover)), method_name="mlm", log_input=True, loss="poisson_nll", compute_dtype="fp32")
+    with tempfile.TemporaryDirectory() as td:
+        inat.save_checkpoint(td)
+        o2 = json.loads(json.dumps(iover)); o2["encoder"]["from_pt"] = td; o2.setdefault("decoder", {})["from_pt"] = td
+        r2 = iTransformer(update_config("configs/itransformer.yaml", o2), method_name="mlm", log_input=True, loss="poisson_nll")   # itransformer.py:226-250
+        n = same({k: v for k, v in inat.state_dict().items()}, {k: v for k, v in r2.state_dict().items() if not k.startswith("masker")})
+    reverse["iTransformer"] = {"reference_from_pt_equal_tensors": n}
+
+    # ---------------- PatchTST (ctc, tiny) ----------------
+    pover = ptst_tiny()
+    pcfg = update_config("configs/patchtst.yaml", pover)
+    torch.manual_seed(7)
+    pref = PatchTSTForSpikingActivity(pcfg, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    d = fresh("ckpt_patchtst")
+    pref.save_checkpoint(d)
+    g = np.random.default_rng(5)
+    B, T, Cn = 3, 45, 6
+    spikes = g.standard_normal((B, T, Cn)).astype(np.float32); smask = np.zeros((B, T), np.int64)
+    for b, L in enumerate([45, 38, 30]):
+        spikes[b, L:] = 0; smask[b, :L] = 1
+    tg = np.zeros((B, 2), np.int64)
+    for b, n_t in enumerate([2, 2, 1]):
+        tg[b, :n_t] = g.integers(1, 11, n_t)
+    pb = {"spikes": torch.from_numpy(spikes), "spikes_mask": torch.from_numpy(smask), "spikes_lengths": torch.tensor([45, 38, 30]),
+          "targets": torch.from_numpy(tg), "targets_lengths": torch.tensor([2, 2, 1])}   # (the reference's ctc forward needs targets, patchtst.py:248)
+    pref.eval()
+    with torch.no_grad():
+        pout = pref(**pb)
+    fx = {"in_" + k: v.numpy() for k, v in pb.items()}
+    fx.update(preds=pout.preds.numpy(), loss=pout.loss.numpy(), config_json=np.array(json.dumps(pover)), state_json=np.array(json.dumps(_sd_summary(pref.state_dict()))))
+    np.savez_compressed(os.path.join(d, "expected.npz"), **fx)
+    from llm_bci_amd.patchtst import PatchTSTForSpikingActivity as NPT
+    torch.manual_seed(11)
+    pnat = NPT(json.loads(json.dumps(pover)), method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True, compute_dtype="fp32")
+    with tempfile.TemporaryDirectory() as td:
+        pnat.save_checkpoint(td)
+        r3 = PatchTSTForSpikingActivity(pcfg, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+        r3.load_checkpoint(td)                                         # patchtst.py:264-266 (its from_pt reads the pickled config as yaml and cannot work)
+        n = same(dict(pnat.state_dict()), dict(r3.state_dict()))
+    reverse["PatchTST"] = {"reference_load_checkpoint_equal_tensors": n,
+                           "note": "reference from_pt (patchtst.py:174-176) parses encoder_config.yaml as yaml although save_checkpoint pickles it: not usable in the reference itself"}
+
+    # ---------------- BCI (tiny Llama through the reference's llm= argument) ----------------
+    enc = json.loads(json.dumps(det(tiny())["encoder"]))
+    bcfg = {"projector": {"stacking": 2, "inter_size": 48, "bias": True, "act": "relu"}, "ndt1": {"encoder": enc}}
+    lcfg = dict(vocab_size=128, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                max_position_embeddings=128)
+    torch.manual_seed(7)
+    llm = AutoModelForCausalLM.from_config(LlamaConfig(**lcfg))
+    bref = BCI(json.loads(json.dumps(bcfg)), llm_path=None, llm=llm, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    d = fresh("ckpt_bci")
+    bref.save_checkpoint(d)
+    np.savez_compressed(os.path.join(d, "expected.npz"), config_json=np.array(json.dumps(bcfg)), llm_config_json=np.array(json.dumps(lcfg)),
+                        ndt1_state_json=np.array(json.dumps(_sd_summary(bref.ndt1.state_dict()))),
+                        projector_state_json=np.array(json.dumps(_sd_summary(bref.projector.state_dict()))),
+                        llm_state_json=np.array(json.dumps(_sd_summary(bref.llm.state_dict()))))
+    from llm_bci_amd.bci import BCI as NBCI
+    torch.manual_seed(11)
+    nllm = AutoModelForCausalLM.from_config(LlamaConfig(**lcfg))
+    bnat = NBCI(json.loads(json.dumps(bcfg)), llm=nllm, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True, compute_dtype="fp32")
+    with tempfile.TemporaryDirectory() as td:
+        bnat.save_checkpoint(td)
+        o2 = json.loads(json.dumps(bcfg)); o2["from_pt"] = td
+        r2 = BCI(o2, llm_path=None, method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)      # bci.py:46,57,78-80,99-104
+        n = same(dict(bnat.ndt1.state_dict()), dict(r2.ndt1.state_dict())) + same(dict(bnat.projector.state_dict()), dict(r2.projector.state_dict()))
+        n += same({k: v for k, v in bnat.llm.state_dict().items()}, {k: v for k, v in r2.llm.state_dict().items()})
+    reverse["BCI"] = {"reference_from_pt_equal_tensors": n}
+    json.dump({"made_by": "tests/golden/make_golden.py --ckpt (build container, reference imported from /root/reference)",
+               "native_checkpoint_loaded_by_reference": reverse}, open(os.path.join(OUT, "ckpt_reverse_check.json"), "w"), indent=2, sort_keys=True)
+    for dd in ("ckpt_ndt1", "ckpt_itransformer", "ckpt_patchtst", "ckpt_bci"):
+        print(dd, sorted(os.listdir(os.path.join(OUT, dd))))
+    print("reverse:", reverse)
+
+
+if __name__ == "__main__" and "--ckpt" in sys.argv:
+    ckpt_cases()
