@@ -285,6 +285,10 @@ int nbci_debug_gemm_streamk(int32_t mode);
 int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8);
 /* Frees the scratch buffers the library allocated on its own (the grouped GEMM's partial tiles). Call with the streams idle. */
 int nbci_release_scratch(void);
+/* The balanced grouped launch's owners wait for other workgroups' partial tiles with a BOUNDED spin; *out = how many gave up since the
+ * scratch buffers were created (0 in a healthy run; a non-zero count means wrong weight-gradient tiles were stored instead of a hang).
+ * Synchronises the streams that own scratch. */
+int nbci_streamk_timeouts(int64_t* out);
 int nbci_profile_collect(double* out24);
 /* every kernel a profiling scope brackets (GEMMs, LayerNorm, attention, AdamW, ...), aggregated by kernel symbol: one text line per
  * symbol "symbol<TAB>launches<TAB>total ms<TAB>algorithmic flops<TAB>algorithmic bytes". Drains the records (as nbci_profile_collect does). */

@@ -160,6 +160,7 @@ _SIGNATURES = {
                                      C.c_int32, C.c_void_p]),
     "nbci_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "nbci_streamk_timeouts": (C.c_int, [C.POINTER(C.c_int64)]),
     "nbci_profile_collect_text": (C.c_int, [C.c_char_p, C.c_int64]),
     "nbci_adamw_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),

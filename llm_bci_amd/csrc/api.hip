@@ -7,6 +7,25 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 }  // namespace nbci
 
+#include <map>
+#include <mutex>
+namespace nbci {
+int ensure_dyn_lds(const void* kernel, int bytes, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": hipGetDevice: " + hipGetErrorString(e));
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> granted;
+    std::lock_guard<std::mutex> l(mu);
+    int& g = granted[{dev, kernel}];
+    if (g >= bytes) return NBCI_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(NBCI_EHIP, std::string(what) + ": LDS attribute: " + hipGetErrorString(e));
+    g = bytes;
+    return NBCI_OK;
+}
+}  // namespace nbci
+
 extern "C" {
 
 int nbci_version(void) { return NBCI_VERSION; }
@@ -113,6 +132,13 @@ int nbci_debug_gemm_streamk(int32_t mode) {
     return NBCI_OK;
 }
 int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
+int nbci_streamk_timeouts(int64_t* out) {
+    if (!out) return nbci::fail(NBCI_EINVAL, "streamk_timeouts: null output");
+    long long n = 0;
+    const int rc = nbci::gemm_streamk_timeouts(&n);
+    *out = (int64_t)n;
+    return rc;
+}
 int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8) { return nbci::gemm_grouped_describe(descs, n, out8); }
 int nbci_profile_enable(int32_t on) { nbci::gemm_profile_enable(on != 0); return NBCI_OK; }
 int nbci_profile_collect_text(char* buf, int64_t cap) {

@@ -687,11 +687,7 @@ bool attn_fused_eligible(int dtype, int Tp, int H, int nh) {
     return dtype == NBCI_BF16 && nh > 0 && H / nh == AT_HD && Tp >= 1 && Tp <= AT_TPAD;
 }
 
-static int set_lds(const void* fn, int bytes) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return fail(NBCI_EHIP, std::string("attention: LDS attribute: ") + hipGetErrorString(e));
-    return NBCI_OK;
-}
+static int set_lds(const void* fn, int bytes) { return ensure_dyn_lds(fn, bytes, "attention"); }
 
 static AttnArgs base_args(const void* qkv, const int32_t* tmask, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
                           uint32_t seed, uint32_t site_p) {
@@ -706,19 +702,17 @@ static AttnArgs base_args(const void* qkv, const int32_t* tmask, int B, int nh, 
 int attn_fwd_launch(const void* qkv, const int32_t* tmask, void* ad, float* lse, int B, int nh, int Tp, int H, int cf, int cb, float drop_p,
                     uint32_t seed, uint32_t site_p, uint32_t site_o, hipStream_t s) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
-    static bool once = false;
     const int lds = 2 * AT_TPAD * 256 + AT_TPAD * 4, lds9 = (144 + AT_TPAD) * 256 + AT_TPAD * 4;
-    if (!once) {
+    {
         int r = set_lds((const void*)attn_fwd_kernel<10, true>, lds); if (r) return r;
         r = set_lds((const void*)attn_fwd_kernel<10, false>, lds); if (r) return r;
         r = set_lds((const void*)attn_fwd_kernel<9, true>, lds9); if (r) return r;
-        once = true;
     }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     a.o_thr = a.p_thr; a.o_scale = a.p_scale; a.o_key = drop_key(seed, site_o);
     a.ad = (bf16_t*)ad; a.lse = lse;
     const int nblk = (Tp + 15) / 16;
-    static const bool nb9 = [] { const char* e = getenv("NBCI_ATTN_NB9"); return !(e && e[0] == '0'); }();
+    static const bool nb9 = measure_env("NBCI_ATTN_NB9", 1) != 0;
     const bool full = cf == -2 && cb == -2;
     if (prof_on()) prof_note_symbol((nb9 && full && Tp <= 144 && nblk >= 2) ? "attn_fwd_kernel<9, true>" : (full ? "attn_fwd_kernel<10, true>" : "attn_fwd_kernel<10, false>"));
     if (nb9 && full && Tp <= 144 && nblk >= 2) {   // (with a bounded context span the 96-register variant spills 53 registers: ten-block kernel)
@@ -737,26 +731,22 @@ int attn_bwd_launch(const void* qkv, const int32_t* tmask, const void* ad, const
                     hipStream_t s, RepCfg rc) {
     NBCI_REQUIRE(attn_fused_eligible(NBCI_BF16, Tp, H, nh), NBCI_ESHAPE, "fused attention: needs head 128 and T' <= 160");
     NBCI_REQUIRE(ldP % 8 == 0 && ldP >= Tp && ldP <= AT_TPAD, NBCI_ESHAPE, "fused attention: bad ldP");
-    static bool once = false;
     const int lds1 = 2 * AT_TPAD * 256 + AT_HD * 4, lds2 = AT_TPAD * 256 + AT_TPAD * 320 + AT_HD * 4;
-    if (!once) {
+    {
         int r = set_lds((const void*)attn_bwd_dq_kernel, lds1); if (r) return r;
         r = set_lds((const void*)attn_bwd_dkv_kernel, lds2); if (r) return r;
-        once = true;
     }
     AttnArgs a = base_args(qkv, tmask, B, nh, Tp, H, cf, cb, drop_p, seed, site_p);
     NBCI_REQUIRE(ad && lse, NBCI_EINVAL, "fused attention backward: needs the forward output and its log-sum-exp");
     a.ad = (bf16_t*)ad; a.lse = (float*)lse; a.o_scale = a.p_scale;
     a.da = (const bf16_t*)da; a.dS = (bf16_t*)dS; a.Pd = (bf16_t*)Pd; a.ldP = ldP; a.dqkv = (bf16_t*)dqkv; a.bias_grad = bias_grad; a.rc = rc;
     const int nblk = (Tp + 15) / 16;
-    static const bool one_launch = [] { const char* e = getenv("NBCI_ATTN_BWD1"); return !(e && e[0] == '0'); }();   // A/B: 0 = the dq + dk/dv pair
+    static const bool one_launch = measure_env("NBCI_ATTN_BWD1", 1) != 0;   // A/B: 0 = the dq + dk/dv pair
     if (one_launch && Tp <= AF_ROWS) {
         constexpr int lds3 = 2 * AF_ROWS * 256 + 2 * AF_XIMG + 3 * AT_HD * 4 + 32;
-        static bool once3 = false;
-        if (!once3) {
+        {
             int r = set_lds((const void*)attn_bwd_fused_kernel<true>, lds3); if (r) return r;
             r = set_lds((const void*)attn_bwd_fused_kernel<false>, lds3); if (r) return r;
-            once3 = true;
         }
         const dim3 blk(64 * (nblk < 2 ? 2 : nblk));
         if (prof_on()) prof_note_symbol((cf == -2 && cb == -2) ? "attn_bwd_fused_kernel<true>" : "attn_bwd_fused_kernel<false>");

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn_bwd_
 }
 
 bool fattn_eligible(int dtype, int S, int H, int nh) {
-    const char* e = getenv("NBCI_FLASH_ATTN");   // (read per call, not cached: tests switch it per model)
+    const char* e = measure_env_str("NBCI_FLASH_ATTN");   // (measurement builds; the NDT1 plan has its own switch, read at plan creation)
     const bool off = e && e[0] == '0';
     if (off || dtype != NBCI_BF16 || nh <= 0 || H % nh) return false;
     const int hd = H / nh;
@@ -555,7 +555,7 @@ static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
         // kernel spills under the same bound and runs 2 x slower: left alone). Head 128 cannot fit two waves; there three tiles per
         // wave (every streamed K / V fragment used three times) are worth 5 % on long sequences (139 -> 132 us at 593 tokens), while
         // at head 96 they lose to the occupancy (495 us) and at head 32 to the softmax's VALU work (758 vs 998 us).
-        static const int env_nqf = [] { const char* e = getenv("NBCI_FA_NQF"); return e ? atoi(e) : 0; }();   // measurement: force 2 or 3
+        static const int env_nqf = measure_env("NBCI_FA_NQF", 0);   // measurement: force 2 or 3
         if (env_nqf ? env_nqf == 3 : (HD > 96 && a.S >= 400)) {
             dim3 gf(a.NS * a.nh, (a.S + 64 * 3 - 1) / (64 * 3));
             hipLaunchKernelGGL((fattn_fwd_kernel<HD, MASK, 3>), gf, dim3(256), 4 * FA_IMG, s, a);
@@ -564,7 +564,7 @@ static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
         }
     } else if (which == 1) hipLaunchKernelGGL((fattn_bwd_q_kernel<HD, MASK>), g, dim3(256), 4 * FA_IMG, s, a);
     else {
-        static const int env_nkv = [] { const char* e = getenv("NBCI_FA_NKV"); return e ? atoi(e) : 0; }();   // measurement: 1 = one key tile per wave
+        static const int env_nkv = measure_env("NBCI_FA_NKV", 0);   // measurement: 1 = one key tile per wave
         if (env_nkv == 1) {
             dim3 g1(a.NS * a.nh, (a.S + 64 - 1) / 64);
             hipLaunchKernelGGL((fattn_bwd_kv_kernel<HD, MASK, 1>), g1, dim3(256), 8 * FA_IMG, s, a);

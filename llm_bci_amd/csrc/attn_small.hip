@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void sattn_bwd_kv_kernel(SAArgs a) {
 }
 
 bool sattn_eligible(int dtype, int S, int H, int nh) {
-    static const bool off = [] { const char* e = getenv("NBCI_SMALL_ATTN"); return e && e[0] == '0'; }();
+    static const bool off = measure_env("NBCI_SMALL_ATTN", 1) == 0;
     if (off || nh <= 0 || H % nh) return false;
     const int hd = H / nh;
     (void)dtype;

@@ -113,12 +113,7 @@ int nbci_allreduce_bucket(nbci_comm comm, void* buf, int64_t n, int32_t dtype, n
 int nbci_debug_occupy_cus(int32_t n_workgroups, int32_t lds_bytes, double microseconds, nbci_stream_t stream) {
     if (n_workgroups <= 0 || n_workgroups > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 5e5)
         return nbci::fail(NBCI_EINVAL, "occupy: bad arguments");
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)nbci::occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return nbci::fail(NBCI_EHIP, "occupy: LDS attribute");
-        attr = true;
-    }
+    { const int r = nbci::ensure_dyn_lds((const void*)nbci::occupy_kernel, 160 * 1024, "occupy"); if (r != NBCI_OK) return r; }
     hipLaunchKernelGGL(nbci::occupy_kernel, dim3(n_workgroups), dim3(256), lds_bytes, (hipStream_t)stream,
                        (unsigned long long)(microseconds * 100.0), (unsigned*)nullptr);
     return nbci::check_launch("occupy");

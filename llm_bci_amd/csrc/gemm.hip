@@ -137,12 +137,7 @@ static int launch_inst(const GemmK& k, dim3 grid, hipStream_t stream) {
     constexpr int epi = GEMM_BM * EPI_LD * 4;
     const int lds = k.splitk > 1 ? (4 * GemmTile<T>::REGION < 65536 ? 65536 : 4 * GemmTile<T>::REGION)
                                  : (4 * GemmTile<T>::REGION < epi ? epi : 4 * GemmTile<T>::REGION);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AK, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, epi);
-        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm: LDS attribute: ") + hipGetErrorString(e));
-        attr_set = true;
-    }
+    TRY_(ensure_dyn_lds((const void*)gemm_kernel<T, AK, BKM>, epi, "gemm"));
     if (prof_on()) {
         static const std::string sym = std::string("gemm_kernel<") + (sizeof(T) == 2 ? "__bf16" : "float") + ", " + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ">";
         prof_note_symbol(sym.c_str());
@@ -209,16 +204,16 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     if (d.bias) cvec = cvec && (((uintptr_t)d.bias) % 16 == 0);
     if (d.residual) cvec = cvec && (d.ldr % 4 == 0) && (((uintptr_t)d.residual) % 16 == 0);
     k.cvec = cvec ? 1 : 0;
-    { static const int dbg = [] { const char* e = getenv("NBCI_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+    { static const int dbg = measure_env("NBCI_GEMM_DBG", 0); k.dbg = dbg; }
     k.epi_mode = epi_mode_of(k);
     {   // NBCI_GEMM_LOGMODE=1: print each distinct epilogue feature set once (which ones deserve a specialised row loop)
-        static const bool logm = [] { const char* e = getenv("NBCI_GEMM_LOGMODE"); return e && e[0] == '1'; }();
+        static const bool logm = measure_env("NBCI_GEMM_LOGMODE", 0) == 1;
         if (logm) {
             static std::set<int> seen;
             if (seen.insert(k.epi_mode).second) fprintf(stderr, "[nbci] gemm epilogue mode 0x%x (M %d N %d K %d)\n", k.epi_mode, d.M, d.N, d.K);
         }
     }
-    { static const bool gen = getenv("NBCI_GEMM_GENERIC_EPI") != nullptr; if (gen) k.epi_mode = EPI_GENERIC; }   // A/B: force the run-time-tested row loop
+    { static const bool gen = measure_env_str("NBCI_GEMM_GENERIC_EPI") != nullptr; if (gen) k.epi_mode = EPI_GENERIC; }   // A/B: force the run-time-tested row loop
     return NBCI_OK;
 }
 
@@ -226,7 +221,7 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
 // nbci_profile_collect; grouped launches list every problem: "G n M N K M N K ..."). Measurement aid: tools/roofline_report.py joins
 // it with a rocprofv3 kernel trace of the same run (launch i of the trace = line i), so every launch's algorithmic FLOPs are known.
 static FILE* gemm_log_file() {
-    static FILE* f = [] { const char* e = getenv("NBCI_GEMM_LOG"); return (e && e[0]) ? fopen(e, "w") : (FILE*)nullptr; }();
+    static FILE* f = [] { const char* e = measure_env_str("NBCI_GEMM_LOG"); return (e && e[0]) ? fopen(e, "w") : (FILE*)nullptr; }();
     return f;
 }
 static int kind_of(const nbci_gemm_desc& d) { return (d.in_dtype == NBCI_BF16 ? 4 : 0) + (d.A.kmajor ? 2 : 0) + (d.B.kmajor ? 1 : 0); }

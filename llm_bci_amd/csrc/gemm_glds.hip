@@ -17,6 +17,9 @@
 // need a second, 12 %-full round.
 #include <cstdlib>
 
+#include <atomic>
+#include <map>
+#include <mutex>
 #include "gemm_glds.h"
 
 namespace nbci {
@@ -281,13 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
 template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
 static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
     constexpr int lds = NSTAGE * (WM * MI * 16 * 128 + 16384);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms: LDS attribute: ") + hipGetErrorString(e));
-        attr = true;
-    }
+    TRY_(ensure_dyn_lds((const void*)gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>, lds, "gemm_glds_ms"));
     if (prof_on()) {
         static const std::string sym = std::string("gemm_glds_ms_kernel<") + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ", " + std::to_string(WM) + ", " +
                                        std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + std::to_string(NSTAGE) + ">";
@@ -322,13 +319,7 @@ template <bool AK, bool BKM, int WM, int WN, int MI, int NI, bool VIEW = false>
 static int launch_glds(const GemmK& k, dim3 grid, hipStream_t s) {
     constexpr int stage2 = 2 * (WM * MI * 16 * 128 + 16384), epi = WM * MI * 16 * EPI_LD * 4 / ((WM == 1 && MI == 10) ? 2 : 1);   // K-loop stages / epilogue tile (chunk)
     constexpr int lds = stage2 > epi ? stage2 : epi;
-    static bool attr_set = false;
-    if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI, VIEW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds: LDS attribute: ") + hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (lds > 65536) TRY_(ensure_dyn_lds((const void*)gemm_glds_kernel<AK, BKM, WM, WN, MI, NI, VIEW>, lds, "gemm_glds"));
     if (prof_on()) {
         static const std::string sym = std::string("gemm_glds_kernel<") + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ", " + std::to_string(WM) + ", " +
                                        std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + (VIEW ? "true" : "false") + ">";
@@ -374,15 +365,8 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
     if (gemm_streamk_wanted(descs, ks, n)) return gemm_streamk_launch(descs, ks, n, stream);   // tile count leaves slots idle: deal out K tiles instead
     dim3 grid(grp.start[n]);
     constexpr int lds = 128 * EPI_LD * 4;   // the epilogue tile (67.6 KB) is a little larger than the two K-loop stages
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e3 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e4 = hipFuncSetAttribute((const void*)gemm_glds_group_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(NBCI_EHIP, "gemm group: LDS attribute");
-        attr_set = true;
-    }
+    TRY_(ensure_dyn_lds(ak ? (bk ? (const void*)gemm_glds_group_kernel<true, true> : (const void*)gemm_glds_group_kernel<true, false>)
+                           : (bk ? (const void*)gemm_glds_group_kernel<false, true> : (const void*)gemm_glds_group_kernel<false, false>), lds, "gemm group"));
     if (prof_on()) prof_note_symbol((std::string("gemm_glds_group_kernel<") + (ak ? "true" : "false") + ", " + (bk ? "true" : "false") + ">").c_str());
     if (ak && bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, grp);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_glds_group_kernel<true, false>), grid, dim3(GEMM_THREADS), lds, stream, grp);
@@ -396,10 +380,29 @@ int gemm_group_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hipSt
 bool gemm_pc_eligible(const nbci_gemm_desc& d, const GemmK& k);
 int gemm_pc_mode();
 
-// CUs the tile cost model counts on (nbci_set_available_cus): fewer than 256 while an overlapped all-reduce occupies some
-static int g_avail_cus = 256;
-void set_available_cus(int cus) { g_avail_cus = cus; }
-int available_cus() { return g_avail_cus; }
+// CUs the tile cost model counts on: the current device's (hipDeviceProp.multiProcessorCount, looked up once per device), or
+// fewer when nbci_set_available_cus narrowed it (an overlapped all-reduce occupies some) - an explicit process-wide setting of the caller's
+static std::atomic<int> g_cu_override{0};
+void set_available_cus(int cus) { g_cu_override.store(cus); }
+int available_cus() {
+    const int o = g_cu_override.load();
+    static std::mutex mu;
+    static std::map<int, int> per_dev;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return o > 0 ? o : 256;
+    int n;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = per_dev.find(dev);
+        if (it == per_dev.end()) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            it = per_dev.emplace(dev, v).first;
+        }
+        n = it->second;
+    }
+    return (o > 0 && o < n) ? o : n;
+}
 long gemm_pc_tiles(const nbci_gemm_desc& d);
 int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream);
 
@@ -414,24 +417,25 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int pc_mode = gemm_pc_mode();
     if (pc_mode && gemm_pc_eligible(d, k)) {
         const long tiles = gemm_pc_tiles(d);
-        const long cus = g_avail_cus, last = tiles % cus;
+        const long cus = available_cus(), last = tiles % cus;
         if (pc_mode == 2 || (d.K >= 2048 && tiles >= 3 * cus / 4 && (last == 0 || last >= 3 * cus / 4))) return gemm_pc_launch(d, k, stream);
     }
     // tile height: minimise (rounds of 2 blocks/CU) x (rows per tile). Tall tiles need k-major A,
     // whole K tiles and no split-K.
     int bm = 128;
+    const long avail = available_cus();
     if (d.A.kmajor && d.K % 64 == 0 && splitk == 1) {
         // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel
         // runs one workgroup per CU (rounds of 256 tiles) but streams ~1.5x faster per row.
         double best = -1;
         const int cands[4] = {128, 144, 160, 288};  // (160 rows: two-chunk epilogue, 208 VGPRs; 192 rows spill accumulators with hipcc 7.2: not offered)
-        static const bool g3_off = [] { const char* e = getenv("NBCI_GEMM3"); return !(e && e[0] == '1'); }();  // opt-in: measured no faster than the 2-stage kernel
+        static const bool g3_off = measure_env("NBCI_GEMM3", 0) != 1;  // opt-in: measured no faster than the 2-stage kernel
         for (int c : cands) {
             if (c == 288 && (g3_off || d.K < 192 || glds_view(d))) continue;
             if (c == 160 && glds_view(d)) continue;   // (view launches pick their own 160-row case below)
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
             if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
-            const long s1 = g_avail_cus, s2 = 2 * g_avail_cus;   // workgroup slots per round (one / two workgroups per CU)
+            const long s1 = avail, s2 = 2 * avail;   // workgroup slots per round (one / two workgroups per CU)
             const double cost = c == 288 ? (double)((tiles + s1 - 1) / s1) * c / 2.0 / 1.5 : (double)((tiles + s2 - 1) / s2) * c;
             if (best < 0 || cost < best) { best = cost; bm = c; }
         }
@@ -445,7 +449,7 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         // where 128- / 144-row tiles need a second, mostly empty one)
         if (d.K % 64 == 0 && splitk == 1) {
             const long t160 = (long)((d.M + 159) / 160) * k.tiles_n * batch;
-            const long s2 = 2 * g_avail_cus;
+            const long s2 = 2 * avail;
             const double c160 = (double)((t160 + s2 - 1) / s2) * 160, ccur = (double)(((long)grid.x * grid.y + s2 - 1) / s2) * bm;
             if (c160 < ccur) {
                 k.tiles_m = (d.M + 159) / 160;
@@ -455,9 +459,9 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         return bm == 144 ? launch_glds<true, false, 1, 4, 9, 2, true>(k, grid, stream) : launch_glds<true, false, 2, 2, 4, 4, true>(k, grid, stream);
     }
     // small grids (at most one workgroup per CU): nothing else hides the per-tile load latency -> 4-stage pipeline
-    static const bool ms_off = [] { const char* e = getenv("NBCI_GEMM_MS"); return e && e[0] == '0'; }();
+    static const bool ms_off = measure_env("NBCI_GEMM_MS", 1) == 0;
     // very small grids (<= half the CUs at 128-row tiles): 64-row tiles double the workgroup count; 5 stages of 24 KB
-    static const bool s64_off = [] { const char* e = getenv("NBCI_GEMM_S64"); return e && e[0] == '0'; }();
+    static const bool s64_off = measure_env("NBCI_GEMM_S64", 1) == 0;
     if (!ms_off && !s64_off && bm == 128 && ak && splitk == 1 && d.K % 64 == 0 && d.K >= 256 && (long)grid.x * grid.y <= 128 && d.M > 64) {
         k.tiles_m = (d.M + 63) / 64;
         dim3 g64(k.tiles_m * k.tiles_n, batch);

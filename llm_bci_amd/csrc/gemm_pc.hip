@@ -254,7 +254,7 @@ bool glds_view(const nbci_gemm_desc& d);
 // Initialised from NBCI_GEMM_PC; nbci_debug_gemm_pc() changes it at run time.
 static int g_pc_mode = -1;
 int gemm_pc_mode() {
-    if (g_pc_mode < 0) { const char* e = getenv("NBCI_GEMM_PC"); g_pc_mode = e ? atoi(e) : 1; }
+    if (g_pc_mode < 0) g_pc_mode = measure_env("NBCI_GEMM_PC", 1);
     return g_pc_mode;
 }
 void gemm_pc_set_mode(int m) { g_pc_mode = m; }
@@ -274,13 +274,7 @@ int gemm_pc_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const int batch = d.batch > 0 ? d.batch : 1;
     k.tiles_m = (d.M + PC_BM - 1) / PC_BM;
     k.tiles_n = (d.N + PC_BN - 1) / PC_BN;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_pc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_pc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        if (e1 != hipSuccess || e2 != hipSuccess) return fail(NBCI_EHIP, "gemm_pc: LDS attribute");
-        attr = true;
-    }
+    TRY_(ensure_dyn_lds(d.B.kmajor ? (const void*)gemm_pc_kernel<true> : (const void*)gemm_pc_kernel<false>, PC_LDS, "gemm_pc"));
     dim3 grid(k.tiles_m * k.tiles_n, batch);
     if (prof_on()) prof_note_symbol(d.B.kmajor ? "gemm_pc_kernel<true>" : "gemm_pc_kernel<false>");
     if (d.B.kmajor) hipLaunchKernelGGL((gemm_pc_kernel<true>), grid, dim3(PC_THREADS), PC_LDS, stream, k);

@@ -14,9 +14,15 @@
 //     wave instruction — to its own 64 KB slot of a scratch buffer and publishes a flag (release, agent scope).
 // A workgroup has at most one contributor run (the one that does not reach its tile's end) and does it FIRST, so by the time an
 // owner has finished its own share the partials it needs have usually been there for a while. The owner spins on the
-// contributors' flags; this cannot deadlock: runs are dealt out per XCD (workgroup b is on XCD b % 8 and takes run b / 8 of that
-// XCD's tiles, so partials also stay inside one L2), contributors of a tile always have a lower block index than its owner,
-// workgroups are dispatched in block-index order and a contributor run waits for nothing.
+// contributors' flags. Progress: a contributor run waits for nothing, so an owner only ever waits for work that is running or will
+// run as soon as a slot frees - provided every workgroup of the launch gets a slot eventually, which the grid size guarantees (one
+// workgroup per slot of the CURRENT device's CUs: available_cus(), from hipDeviceProp unless the caller narrowed it). Contiguous and
+// aligned schemes put a tile's contributors at LOWER block indices than its owner (dispatched first in practice; speed, not
+// correctness). The opt-in blocked scheme (mode 4) does not: its helpers sit at HIGHER block indices than the owners they serve
+// (owner j * 8 + xcd waits for helper j * 8 + nb + xcd / per), so there the argument is residency alone.
+// Placement (b % 8 = which blocks share an XCD) is a speed assumption only: partials and flags go past every cache level.
+// Every spin is BOUNDED (SK_SPIN_LIMIT sleeps, about a second): on expiry the owner gives up, counts the event in the scratch
+// buffer's timeout word and finishes with what it has - a wrong tile instead of a hung GPU; nbci_streamk_timeouts() reads the count.
 // Flags carry the launch's epoch (a per-process counter), so they are never reset.
 #include <hip/hip_runtime.h>
 
@@ -32,6 +38,7 @@
 namespace nbci {
 
 constexpr int SK_MAX = 6;
+constexpr int SK_SPIN_LIMIT = 1 << 22;   // x s_sleep(8) ~ 0.25 us each
 constexpr int SK_MAXP = 8;   // aligned scheme: most pieces (scratch slots) one helper workgroup may produce
 struct StreamK {
     int n;
@@ -42,6 +49,7 @@ struct StreamK {
     int wpx;                       // workgroups per XCD (grid = 8 wpx)
     float* partial;                // [grid][16][256] float4
     int* flags;                    // [grid]
+    int* timeouts;                 // one word: owners that gave up waiting (see SK_SPIN_LIMIT)
     int epoch;
     int dbg;                       // measurement only: 1 = no partial exchange at all (wrong results)
     int aligned, q, lk, ex, tx, r, maxp;   // aligned scheme (see the kernel): owner K tiles, remainder, helpers and tiles per XCD, tiles per helper (0: not integral), slots per helper
@@ -157,7 +165,11 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
         const int sl = slot_of(i);
         const float4* slot = sk_uniform((float4*)s.partial + (size_t)sl * (MI * NI * GEMM_THREADS));
         if (t == 0) {
-            while (__hip_atomic_load(s.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) __builtin_amdgcn_s_sleep(8);
+            int spins = 0;
+            while (__hip_atomic_load(s.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SK_SPIN_LIMIT) { atomicAdd(s.timeouts, 1); break; }
+            }
         }
         __syncthreads();
         // the partial was never cached here (first touch) but may be on another XCD: read it past the caches as well
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(2,
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------
-struct SkScratch { float* partial; int* flags; int slots; };
+struct SkScratch { float* partial; int* flags; int slots; };   // flags[slots] = the timeout word
 static std::mutex g_sk_mu;
 static std::map<std::pair<int, hipStream_t>, SkScratch> g_sk_scratch;
 static std::atomic<int> g_sk_epoch{1};
@@ -298,12 +310,32 @@ static int g_sk_mode = -1;   // -1: read NBCI_STREAMK on first use (default 1)
 
 int gemm_streamk_mode() {
     if (g_sk_mode < 0) {
-        const char* e = getenv("NBCI_STREAMK");
-        g_sk_mode = e ? atoi(e) : 1;
+        g_sk_mode = measure_env("NBCI_STREAMK", 1);
     }
     return g_sk_mode;
 }
 void gemm_streamk_set_mode(int m) { g_sk_mode = m; }
+
+// owners that gave up waiting for a partial since the scratch buffers were created (synchronises every stream that has one)
+int gemm_streamk_timeouts(long long* out) {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    long long n = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_sk_scratch) {
+        int v = 0;
+        (void)hipSetDevice(kv.first.first);
+        if (hipStreamSynchronize(kv.first.second) != hipSuccess ||
+            hipMemcpy(&v, kv.second.flags + kv.second.slots, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipSetDevice(cur);
+            return fail(NBCI_EHIP, "stream-K timeouts: read back");
+        }
+        n += v;
+    }
+    (void)hipSetDevice(cur);
+    *out = n;
+    return NBCI_OK;
+}
 
 int gemm_streamk_release() {
     std::lock_guard<std::mutex> lk(g_sk_mu);
@@ -333,11 +365,11 @@ static int sk_scratch(hipStream_t stream, int slots, SkScratch& out) {
     s.slots = slots;
     if (hipMalloc((void**)&s.partial, (size_t)slots * 16 * GEMM_THREADS * sizeof(float4)) != hipSuccess)
         return fail(NBCI_EHIP, "stream-K scratch: hipMalloc (partials)");
-    if (hipMalloc((void**)&s.flags, (size_t)slots * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&s.flags, ((size_t)slots + 1) * sizeof(int)) != hipSuccess) {
         (void)hipFree(s.partial);
         return fail(NBCI_EHIP, "stream-K scratch: hipMalloc (flags)");
     }
-    if (hipMemsetAsync(s.flags, 0, (size_t)slots * sizeof(int), stream) != hipSuccess) return fail(NBCI_EHIP, "stream-K scratch: memset");
+    if (hipMemsetAsync(s.flags, 0, ((size_t)slots + 1) * sizeof(int), stream) != hipSuccess) return fail(NBCI_EHIP, "stream-K scratch: memset");
     g_sk_scratch[key] = s;
     out = s;
     return NBCI_OK;
@@ -385,7 +417,7 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
     {   // blocked scheme: every problem a whole number of 64-tile blocks with 8 tile columns, one K, 4 / 6 / 7 blocks on 512 slots.
         // OFF unless asked for (mode 4 or NBCI_STREAMK_BLOCKED=1): on the NDT1 layer group it halves the fabric traffic (FETCH_SIZE
         // 591 -> 279 MB per launch against 187 MB algorithmic) and is nevertheless 3 % slower inside the step (143.4 vs 138.8 us).
-        static const bool env_blocked = [] { const char* e = getenv("NBCI_STREAMK_BLOCKED"); return e && e[0] == '1'; }();
+        static const bool env_blocked = measure_env("NBCI_STREAMK_BLOCKED", 0) == 1;
         bool ok = (env_blocked || gemm_streamk_mode() == 4) && slots == 512 && tiles % 64 == 0;
         for (int i = 0; i < n && ok; ++i) ok = s.kt[i] == s.kt[0] && s.sub[i].tiles_n == 8 && s.sub[i].tiles_m % 8 == 0;
         const int nb = tiles / 64;
@@ -398,7 +430,7 @@ static bool sk_plan(const nbci_gemm_desc* descs, const GemmK* ks, int n, StreamK
             }
         }
     }
-    static const int env_aligned = [] { const char* e = getenv("NBCI_STREAMK_ALIGNED"); return e ? atoi(e) : -1; }();
+    static const int env_aligned = measure_env("NBCI_STREAMK_ALIGNED", -1);
     const bool no_aligned = env_aligned == 0;
     bool want = env_aligned == 1 || gemm_streamk_mode() == 3;
     if (!want && tiles > 0) {
@@ -458,18 +490,12 @@ int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hip
     if (rc != NBCI_OK) return rc;
     s.partial = sc.partial;
     s.flags = sc.flags;
+    s.timeouts = sc.flags + sc.slots;
     s.epoch = g_sk_epoch.fetch_add(1);
-    { const char* e = getenv("NBCI_STREAMK_DBG"); s.dbg = e ? atoi(e) : 0; }
+    s.dbg = measure_env("NBCI_STREAMK_DBG", 0);
     constexpr int lds = 128 * EPI_LD * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e3 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t e4 = hipFuncSetAttribute((const void*)gemm_streamk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(NBCI_EHIP, "gemm stream-K: LDS attribute");
-        attr_set = true;
-    }
+    TRY_(ensure_dyn_lds(ak ? (bk ? (const void*)gemm_streamk_kernel<true, true> : (const void*)gemm_streamk_kernel<true, false>)
+                           : (bk ? (const void*)gemm_streamk_kernel<false, true> : (const void*)gemm_streamk_kernel<false, false>), lds, "gemm stream-K"));
     dim3 grid(slots);
     if (prof_on()) prof_note_symbol((std::string("gemm_streamk_kernel<") + (ak ? "true" : "false") + ", " + (bk ? "true" : "false") + ">").c_str());
     if (ak && bk) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, dim3(GEMM_THREADS), lds, stream, s);

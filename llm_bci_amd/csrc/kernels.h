@@ -15,6 +15,7 @@ void gemm_profile_enable(bool on);
 void gemm_pc_set_mode(int m);
 void gemm_streamk_set_mode(int m);   // gemm_streamk.hip: 0 off, 1 where the tile count leaves slots idle, 2 always (nbci_debug_gemm_streamk)
 int gemm_streamk_release();            // frees the per-stream partial-tile scratch (nbci_release_scratch)
+int gemm_streamk_timeouts(long long* out);
 void set_available_cus(int cus);   // gemm_glds.hip: CUs the tile cost model may count on (nbci_set_available_cus)
 int available_cus();   // gemm_pc.hip: kernel-family switch (nbci_debug_gemm_pc)
 bool gemm_profile_on();

@@ -1167,16 +1167,11 @@ int ctc_launch(const float* preds, const int64_t* targets, const int32_t* in_len
     NBCI_REQUIRE(blank >= 0 && blank < V, NBCI_EINVAL, "ctc: blank id out of range");
     const size_t lds1 = fixed + (size_t)Tp * per_frame, lds2 = lds1 + (size_t)Tp * per_frame;
     const size_t lds_mid = ((size_t)2 * ((Tp + 1) / 2) * (2 * S + 1) + (size_t)2 * Tp * V + (2 * S + 1)) * sizeof(float);
-    static const bool mid_on = [] { const char* e = getenv("NBCI_CTC_MID"); return !(e && e[0] == '0'); }();
+    static const bool mid_on = measure_env("NBCI_CTC_MID", 1) != 0;
     if (mid_on && 2 * S + 1 <= 128 && lds_mid <= 160000) {   // both half lattices, the log-probabilities and the posteriors in LDS: no workspace traffic
-        static bool attr_f = false, attr_b = false;
-        bool& attr = d_dtype == NBCI_BF16 ? attr_b : attr_f;
-        if (!attr && lds_mid > 65536) {
-            hipError_t er = d_dtype == NBCI_BF16
-                                ? hipFuncSetAttribute((const void*)ctc_mid_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000)
-                                : hipFuncSetAttribute((const void*)ctc_mid_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
-            if (er != hipSuccess) return fail(NBCI_EHIP, std::string("ctc: LDS attribute: ") + hipGetErrorString(er));
-            attr = true;
+        if (lds_mid > 65536) {
+            const int r = ensure_dyn_lds(d_dtype == NBCI_BF16 ? (const void*)ctc_mid_kernel<bf16_t> : (const void*)ctc_mid_kernel<float>, 160000, "ctc");
+            if (r != NBCI_OK) return r;
         }
         DISPATCH_DTYPE(d_dtype, TD,
                        hipLaunchKernelGGL((ctc_mid_kernel<TD>), dim3(B), dim3(256), lds_mid, s, preds, targets, in_lens, tgt_lens, Tp, V, S, blank,

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 
 namespace nbci {
@@ -32,6 +33,12 @@ int fail(int code, const std::string& msg);
             return ::nbci::fail(NBCI_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+#define TRY_(x)                       \
+    do {                              \
+        int _r = (x);                 \
+        if (_r != NBCI_OK) return _r; \
+    } while (0)
+
 #define NBCI_REQUIRE(cond, code, msg)                    \
     do {                                                 \
         if (!(cond)) return ::nbci::fail((code), (msg)); \
@@ -50,6 +57,24 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(s); }
 };
 int prof_collect_text(char* buf, long long cap);   // one line per symbol: "symbol\tlaunches\tms\tflops\tbytes\n"
+
+// Measurement switches. The environment variables that pick kernel variants for in-box A/B runs exist only in a
+// MEASUREMENT build (tools/build_variant.sh measure -DNBCI_MEASURE, loaded with NBCI_LIB=...): the shipped library compiles the
+// defaults in and reads no environment on its launch paths. (What a plan reads once at creation - NBCI_FUSED_ATTN, NBCI_FLASH_ATTN,
+// NBCI_FLASH_MIN_TOKENS, the parity tests' reference paths - stays, stored in the plan.)
+#ifdef NBCI_MEASURE
+inline int measure_env(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
+inline const char* measure_env_str(const char* name) { return getenv(name); }
+#else
+constexpr int measure_env(const char*, int dflt) { return dflt; }
+constexpr const char* measure_env_str(const char*) { return nullptr; }
+#endif
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): a process that drives two devices
+// must set it on each. Remembers what was granted per (current device, kernel); thread-safe; a cheap map lookup on the launch path.
+int ensure_dyn_lds(const void* kernel, int bytes, const char* what);
+// CUs of the current device (hipDeviceProp.multiProcessorCount, cached per device) unless nbci_set_available_cus narrowed it
+int available_cus();
 
 // ---- bf16 <-> f32 (plain casts: hipcc emits v_cvt_pk_bf16_f32, NaN-preserving) ----
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }

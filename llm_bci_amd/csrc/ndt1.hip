@@ -232,7 +232,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
     w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
                   (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0 && npre == 0) ? 1 : 0;
-    { static const bool off = [] { const char* e = getenv("NBCI_PHASE_DGRAD"); return e && e[0] == '0'; }(); if (off) w.phase_ok = 0; }
+    { static const bool off = measure_env("NBCI_PHASE_DGRAD", 1) == 0; if (off) w.phase_ok = 0; }
     w.Q = T / c.stack_stride; w.npad = c.stack_size / c.stack_stride - 1; w.P = w.Q + w.npad;
     w.dAp = w.phase_ok ? bump(cur, (size_t)B * w.P * H * es) : 0;
     w.dwin = w.phase_ok ? 0 : bump(cur, M * (size_t)c.stack_size * D * es);
@@ -615,7 +615,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const size_t pd = p_lay > 0.f ? lw.Pd : lw.P;
             const int64_t pz1 = (int64_t)nh * Tp * w.ldP, pz2 = (int64_t)Tp * w.ldP;
             const int64_t qz1 = (int64_t)Tp * 3 * H, az1 = (int64_t)Tp * H;
-            static const bool attn_bias = [] { const char* e = getenv("NBCI_ATTN_BIASGRAD"); return !(e && e[0] == '0'); }();   // q/k/v bias sums inside the attention backward (DPP row sums + LDS atomics: +6 us on the two kernels, -11 us colsum launch per layer)
+            static const bool attn_bias = measure_env("NBCI_ATTN_BIASGRAD", 1) != 0;   // q/k/v bias sums inside the attention backward (DPP row sums + LDS atomics: +6 us on the two kernels, -11 us colsum launch per layer)
             bool bias_in_attn = false;
             if (p.fused_attn && attn_fused_eligible(dt, Tp, H, nh)) {
                 bias_in_attn = attn_bias && !c.use_rope;
