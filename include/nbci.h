@@ -232,6 +232,10 @@ int nbci_step_stats(double* stats, const float* loss, int32_t B, double n_exampl
 int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
                nbci_stream_t stream);
+/* the same step with the gradient in bf16 (a bucket as a bf16 all-reduce left it: no widening pass back into the f32 gradient buffer) */
+int nbci_adamw_lp(float* p, const void* g_bf16, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
+                  nbci_stream_t stream);
 /* the same step + optimizer.zero_grad() (trainer.py:340-342) in one pass: g is cleared as it is consumed. max_blocks > 0 caps
  * the launch's workgroups (a caller running it on a second stream beside other kernels leaves them wave slots); 0 = default. */
 int nbci_adamw_zero(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,

@@ -80,12 +80,17 @@ int nbci_per(const int32_t* argmax, const int64_t* targets, const int64_t* tgt_l
 }
 int nbci_adamw(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, float bc1, float bc2, float grad_scale, nbci_stream_t stream) {
-    nbci::ProfScope ps("adamw_kernel<false>", 0.0, (double)n * (p_lp ? 30.0 : 28.0), (hipStream_t)stream);
+    nbci::ProfScope ps("adamw_kernel<false, float>", 0.0, (double)n * (p_lp ? 30.0 : 28.0), (hipStream_t)stream);
     return nbci::adamw_launch(p, const_cast<float*>(g), m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream);
+}
+int nbci_adamw_lp(float* p, const void* g_bf16, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float bc1, float bc2, float grad_scale, nbci_stream_t stream) {
+    nbci::ProfScope ps("adamw_kernel<false, __bf16>", 0.0, (double)n * (p_lp ? 28.0 : 26.0), (hipStream_t)stream);
+    return nbci::adamw_launch(p, const_cast<void*>(g_bf16), m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream, false, 0, true);
 }
 int nbci_adamw_zero(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float bc1, float bc2, float grad_scale, int32_t max_blocks, nbci_stream_t stream) {
-    nbci::ProfScope ps("adamw_kernel<true>", 0.0, (double)n * (p_lp ? 34.0 : 32.0), (hipStream_t)stream);
+    nbci::ProfScope ps("adamw_kernel<true, float>", 0.0, (double)n * (p_lp ? 34.0 : 32.0), (hipStream_t)stream);
     return nbci::adamw_launch(p, g, m, v, p_lp, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, (hipStream_t)stream, true, max_blocks);
 }
 int nbci_cast(const float* in, void* out, int32_t out_dtype, int64_t n, nbci_stream_t stream) {

@@ -96,8 +96,9 @@ int per_launch(const int32_t* argmax, const int64_t* targets, const int64_t* tgt
                int blank, int32_t* decoded, int32_t* dec_lens, int32_t* errors, int32_t* scratch, hipStream_t s);
 
 // fused AdamW over a flat buffer (torch.optim.AdamW semantics; models/trainer.py:229,340)
-int adamw_launch(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
-                 float beta2, float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s, bool zero_grad = false, int max_blocks = 0);
+int adamw_launch(float* p, void* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s, bool zero_grad = false, int max_blocks = 0,
+                 bool g_bf16 = false);
 
 int cast_launch(const float* in, void* out, int out_dtype, int64_t n, hipStream_t s);
 

@@ -1479,17 +1479,19 @@ int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat
 // ------------------------------------------------------------------------------------------
 // fused AdamW over the flat parameter buffer
 // ------------------------------------------------------------------------------------------
-template <bool ZERO>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO, typename TG>   // TG = float, or bf16_t: the gradient as a bf16 all-reduce bucket left it (no widening pass)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, TG* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ plp, long long n, float lr,
                                                     float b1, float b2, float eps, float wd, float inv_bc1,
                                                     float inv_sqrt_bc2, float gscale) {
     long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * 256 * 4;
     for (; i + 3 < n; i += stride) {
-        float4 pv = *(float4*)(p + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
-        float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w},
-              v2[4] = {vv.x, vv.y, vv.z, vv.w};
+        float4 pv = *(float4*)(p + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+        float gg[4];
+        if constexpr (sizeof(TG) == 4) { const float4 gv = *(const float4*)(g + i); gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w; }
+        else { const bf16x4 gv = *(const bf16x4*)(g + i); gg[0] = bf2f(gv[0]); gg[1] = bf2f(gv[1]); gg[2] = bf2f(gv[2]); gg[3] = bf2f(gv[3]); }
+        float pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, v2[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = gg[e] * gscale;
@@ -1503,23 +1505,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *(float4*)(v + i) = make_float4(v2[0], v2[1], v2[2], v2[3]);
         if (plp) { bf16x4 o = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])}; *(bf16x4*)(plp + i) = o; }
-        if (ZERO) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // zero_grad (trainer.py:342) in the pass that consumed the gradient
+        if constexpr (ZERO && sizeof(TG) == 4) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // zero_grad (trainer.py:342) in the pass that consumed the gradient
     }
 }
 
-int adamw_launch(float* p, float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2,
-                 float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s, bool zero_grad, int max_blocks) {
+int adamw_launch(float* p, void* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float wd, float bc1, float bc2, float grad_scale, hipStream_t s, bool zero_grad, int max_blocks, bool g_bf16) {
     NBCI_REQUIRE(n % 4 == 0, NBCI_ESHAPE, "adamw: flat buffer length must be a multiple of 4");
-    NBCI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+    NBCI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % (g_bf16 ? 8 : 16) == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                  NBCI_EALIGN, "adamw: buffers must be 16-byte aligned");
     // max_blocks: a caller that runs the update beside other kernels (aux stream) keeps it to a few workgroups per CU so that
     // those kernels' workgroups still find wave slots; 2 x 256 threads per CU keep ~32 KB of loads in flight per CU
     const long long blocks = std::min<long long>(max_blocks > 0 ? max_blocks : 2048, (n / 4 + 255) / 256);
-    if (zero_grad)
-        hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
+    const dim3 grid((unsigned)std::max<long long>(1, blocks));
+    if (g_bf16)
+        hipLaunchKernelGGL((adamw_kernel<false, bf16_t>), grid, dim3(256), 0, s, p, (bf16_t*)g, m, v, (bf16_t*)p_lp,
+                           (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
+    else if (zero_grad)
+        hipLaunchKernelGGL((adamw_kernel<true, float>), grid, dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)p_lp,
                            (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
     else
-        hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp,
+        hipLaunchKernelGGL((adamw_kernel<false, float>), grid, dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)p_lp,
                            (long long)n, lr, beta1, beta2, eps, wd, 1.0f / bc1, 1.0f / sqrtf(bc2), grad_scale);
     return check_launch("adamw");
 }

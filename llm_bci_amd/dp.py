@@ -32,9 +32,13 @@ def shard_batch(batch, rank, world):
 
 class GradReducer:
     """Bucketed async all-reduce over contiguous segments of a flat gradient buffer.
-    comm_dtype="bf16": every bucket is rounded to bf16, summed on the wire in bf16 and widened back (half the xGMI bytes: 82 MB
-    instead of 164 MB per NDT1 step; SURVEY §8e allows it, f32 stays the default and the parity setting). The sum of W bf16 values
-    is exact in f32 terms up to bf16 rounding of the result: a relative error of 2^-9 per element, independent of the bucket size."""
+    comm_dtype="bf16": every bucket is rounded to bf16 into a persistent staging buffer (nbci_cast on the backward's stream: no
+    allocation, no framework kernel) and summed on the wire in bf16: half the xGMI bytes, 82 MB instead of 164 MB per NDT1 step
+    (SURVEY §8e allows it; f32 stays the default and the parity setting). Error: each rank's addend is rounded once (2^-9 relative)
+    and a ring / tree all-reduce rounds the running sum at every hop, so W ranks cost up to W roundings per element: the bound is
+    2^-9 (sum of |addends| + (W - 1) |partial sums|), growing with the world size, and a small gradient summed into a large one
+    loses its low bits (tests/test_dp_gloo.py checks that bound at W = 2). The 1/W of DDP's mean is applied afterwards, in AdamW.
+    drain(flat, widen=False) leaves the reduced bucket in `stage` (bf16) for an optimizer that reads it there (nbci_adamw_lp)."""
 
     def __init__(self, segments, group=None, min_bucket_elems=1 << 20, comm_dtype="fp32"):
         self.segments = list(segments)           # [(begin, end)] ascending by offset
@@ -46,6 +50,7 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._works = []
         self._pending = None                     # [begin, end) accumulated but not yet launched
+        self.stage = None                        # bf16 mode: persistent staging buffer, same layout as the flat gradient buffer
         self.enabled = True                      # False: measurement only (bench.py's exposed-communication leg) - buckets are formed, nothing is exchanged
         self.last_buckets = 0                    # buckets put on the wire by the last drained step
 
@@ -78,7 +83,16 @@ class GradReducer:
         if not self.enabled:
             self._works.append((b, e, None, None))
         elif self.comm_bf16:
-            lp = flat[b:e].to(torch.bfloat16)    # (on the backward's stream, before the collective is queued behind it)
+            if self.stage is None or self.stage.numel() != flat.numel() or self.stage.device != flat.device:
+                self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            lp = self.stage[b:e]                 # (cast on the backward's stream, before the collective is queued behind it)
+            if flat.is_cuda:
+                import ctypes as C
+                from ._lib import NBCI_BF16, check, lib
+                check(lib().nbci_cast(C.c_void_p(flat.data_ptr() + 4 * b), C.c_void_p(lp.data_ptr()), NBCI_BF16, e - b,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nbci_cast")
+            else:
+                lp.copy_(flat[b:e])
             self._works.append((b, e, dist.all_reduce(lp, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lp))
         else:
             self._works.append((b, e, dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
@@ -87,9 +101,10 @@ class GradReducer:
         for _ in self.drain(flat):
             pass
 
-    def drain(self, flat=None):
+    def drain(self, flat=None, widen=True):
         """Yield each reduced range (b, e) in launch order once the current stream waits on its all-reduce: the caller can
-        start consuming the early buckets (the optimizer update) while the last ones are still on the wire."""
+        start consuming the early buckets (the optimizer update) while the last ones are still on the wire. bf16 mode: the sums
+        are widened back into `flat` unless widen=False (the caller reads self.stage[b:e])."""
         if self._pending is not None and flat is not None:
             self._launch(flat)
         works, self._works = self._works, []
@@ -97,7 +112,7 @@ class GradReducer:
         for (b, e, w, lp) in works:
             if w is not None:
                 w.wait()
-            if lp is not None:
+            if lp is not None and widen:
                 if flat is None:
                     raise ValueError("drain(flat) needs the gradient buffer in bf16 communication mode")
                 flat[b:e].copy_(lp)              # widen the reduced bf16 bucket back into the f32 gradient range

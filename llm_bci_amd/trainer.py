@@ -128,8 +128,9 @@ class NativeTrainer:
             return False
         return self.side_stream is True or getattr(m, "last_rows", 1 << 30) <= self.side_stream_max_rows
 
-    def _adamw(self, b, e, zero=False, max_blocks=0):
-        """torch.optim.AdamW step (trainer.py:340) of flat range [b, e) on the current stream; zero: + zero_grad in the same pass."""
+    def _adamw(self, b, e, zero=False, max_blocks=0, g_lp=None):
+        """torch.optim.AdamW step (trainer.py:340) of flat range [b, e) on the current stream; zero: + zero_grad in the same pass;
+        g_lp: read the gradient from this bf16 buffer (a bf16 all-reduce's staging buffer) instead of the f32 one."""
         m = self.model
         lr, beta1 = self.sched.at(self.opt_step)
         t = self.opt_step + 1
@@ -139,7 +140,10 @@ class NativeTrainer:
         args = (C.c_void_p(pw + 4 * b), C.c_void_p(pg + 4 * b), C.c_void_p(pm + 4 * b), C.c_void_p(pv + 4 * b),
                 C.c_void_p(plp + 2 * b) if plp else None, e - b, lr, beta1, self.beta2, self.eps, self.wd,
                 1.0 - beta1 ** t, 1.0 - self.beta2 ** t, 1.0 / self.world)
-        if zero:
+        if g_lp is not None:
+            args = (args[0], C.c_void_p(g_lp.data_ptr() + 2 * b)) + args[2:]
+            check(lib().nbci_adamw_lp(*args, _stream()), "nbci_adamw_lp")
+        elif zero:
             check(lib().nbci_adamw_zero(*args, max_blocks, _stream()), "nbci_adamw_zero")
         else:
             check(lib().nbci_adamw(*args, _stream()), "nbci_adamw")
@@ -199,8 +203,9 @@ class NativeTrainer:
             # ranges runs while the embedder's all-reduce is still in flight (AdamW is elementwise: same bits as one launch).
             # drain() is lazy: the stream waits on bucket i only just before bucket i's update is queued.
             done = 0
-            for b, e in (self.reducer.drain(self.grads) if self.reducer.world > 1 else [(0, m._total)]):
-                self._adamw(b, e)
+            lp_grads = self.reducer.world > 1 and self.reducer.comm_bf16 and self.reducer.enabled and self.grads.is_cuda
+            for b, e in (self.reducer.drain(self.grads, widen=not lp_grads) if self.reducer.world > 1 else [(0, m._total)]):
+                self._adamw(b, e, g_lp=self.reducer.stage if lp_grads else None)   # (bf16 buckets are consumed where the all-reduce left them)
                 done += e - b
             if done != m._total:
                 raise RuntimeError("gradient buckets do not cover the flat parameter buffer")

@@ -103,6 +103,33 @@ def test_adamw_matches_oracle_and_refreshes_bf16_shadow():
     assert torch.equal(plp, pd.bfloat16())
 
 
+def test_adamw_variants_zero_grad_and_bf16_gradients():
+    """nbci_adamw_zero = nbci_adamw + a cleared gradient; nbci_adamw_lp on bf16 gradients = nbci_adamw on the same values in f32."""
+    l, check = _l()
+    g0 = np.random.default_rng(3)
+    n = 8192 + 16
+    p = g0.standard_normal(n).astype(np.float32)
+    g = torch.from_numpy(g0.standard_normal(n).astype(np.float32) * 0.1).to(DEV).bfloat16()      # bf16-representable gradients
+    args = (n, 1e-3, 0.9, 0.999, 1e-8, 5e-5, 0.1, 0.001, 0.5)
+    res = {}
+    for kind in ("plain", "zero", "lp"):
+        pd, md, vd = d(p), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        plp = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        gf = g.float().clone()
+        if kind == "plain":
+            check(l.nbci_adamw(vp(pd), vp(gf), vp(md), vp(vd), vp(plp), *args, st()), "nbci_adamw")
+        elif kind == "zero":
+            check(l.nbci_adamw_zero(vp(pd), vp(gf), vp(md), vp(vd), vp(plp), *args, 256, st()), "nbci_adamw_zero")
+            assert float(gf.abs().max()) == 0.0
+        else:
+            check(l.nbci_adamw_lp(vp(pd), vp(g), vp(md), vp(vd), vp(plp), *args, st()), "nbci_adamw_lp")
+        torch.cuda.synchronize()
+        res[kind] = (pd.clone(), md.clone(), vd.clone(), plp.clone())
+    for kind in ("zero", "lp"):
+        for a, b in zip(res["plain"], res[kind]):
+            assert torch.equal(a, b), kind
+
+
 @pytest.mark.parametrize("H", [32, 1024, 768])
 def test_layernorm_fwd_bwd(H):
     l, check = _l()

@@ -51,11 +51,11 @@ def _model(variant, dtype, dev):
     return NDT1(_over(variant), method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=dtype).to(dev)
 
 
-def run(variant, dtype, rank, world, dev):
+def run(variant, dtype, rank, world, dev, comm_dtype="fp32"):
     full = _batch(world, variant, dev)
     # --- the data-parallel run
     m = _model(variant, dtype, dev)
-    tr = NativeTrainer(m, total_steps=20)
+    tr = NativeTrainer(m, total_steps=20, comm_dtype=comm_dtype)
     assert tr.world == world
     mine = shard_batch(full, rank, world)
     for s in range(STEPS):
@@ -73,11 +73,16 @@ def run(variant, dtype, rank, world, dev):
     a, b = m._flat.float().cpu().numpy(), r._flat.float().cpu().numpy()
     d = np.abs(a - b)
     moved = np.abs(b - _model(variant, dtype, "cpu")._flat.numpy()).max()
-    ok = bool((d > 2e-5).mean() < 0.01 and d.max() < 8e-3 and moved > 1e-3 and abs(st["loss"] - rs_loss) <= 1e-4 * abs(rs_loss)
+    # bf16 buckets (staged by nbci_cast, consumed in place by nbci_adamw_lp): every gradient carries up to W roundings of 2^-9, which Adam's
+    # normalised step turns into sign flips only where the gradient is at rounding level - a wider band around the f32 exchange
+    frac = 0.05 if comm_dtype == "bf16" else 0.01
+    if comm_dtype == "bf16":
+        assert tr.reducer.stage is not None and tr.reducer.stage.dtype == torch.bfloat16 and float(tr.grads.abs().max()) == 0.0
+    ok = bool((d > 2e-5).mean() < frac and d.max() < 8e-3 and moved > 1e-3 and abs(st["loss"] - rs_loss) <= 1e-4 * abs(rs_loss)
               and st["n_examples"] == STEPS * full["spikes"].shape[0])
     if dtype == "bf16":
         ok = ok and torch.equal(m._flat_lp, m._flat.bfloat16())
-    print(f"[rank {rank}] {variant}/{dtype}: max|dp-single| {d.max():.3e}  frac>2e-5 {(d > 2e-5).mean():.2e}  moved {moved:.2e}  "
+    print(f"[rank {rank}] {variant}/{dtype}/comm {comm_dtype}: max|dp-single| {d.max():.3e}  frac>2e-5 {(d > 2e-5).mean():.2e}  moved {moved:.2e}  "
           f"loss {st['loss']:.5f} vs {rs_loss:.5f}  -> {'ok' if ok else 'MISMATCH'}", flush=True)
     return ok
 
@@ -93,8 +98,8 @@ def main():
     else:
         dist.init_process_group(backend)
     ok = True
-    for variant, dtype in (("plain", "fp32"), ("plain", "bf16"), ("adapt_tokens", "bf16")):
-        ok = run(variant, dtype, rank, world, dev) and ok
+    for variant, dtype, comm in (("plain", "fp32", "fp32"), ("plain", "bf16", "fp32"), ("adapt_tokens", "bf16", "fp32"), ("plain", "bf16", "bf16")):
+        ok = run(variant, dtype, rank, world, dev, comm) and ok
     flag = torch.tensor([0.0 if ok else 1.0], device=dev)
     dist.all_reduce(flag)
     dist.barrier()
