@@ -206,7 +206,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_glds_group_kernel(GemmGroup
 //   <.., 2,2,4,4, 4>: 128 x 128 tile, 4 waves, 4 stages (128 KB LDS): small grids (<= 1 workgroup per CU)
 //   <.., 2,4,9,2, 3>: 288 x 128 tile, 8 waves, 3 stages (156 KB LDS): opt-in (NBCI_GEMM3=1), measured no
 //                     faster than the 2-stage 144-row kernel on the full-chip shapes
-template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE, bool VIEW = false>   // VIEW: B (row-major-in-k) may be an overlapping-window view
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
@@ -253,13 +253,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
     GldsOperand<BKM, NPB, NW> gb;
     glds_setup<AK, NPA, NW>(ga, A, m0, d.M, w, lane);
     glds_setup<BKM, NPB, NW>(gb, B, n0, d.N, w, lane);
+    if constexpr (VIEW) {   // (tiles are staged strictly in K order below: the view addressing steps from tile to tile)
+        static_assert(AK && !BKM, "multi-stage view kernel: k-major A (plain or window view), row-major-in-k B view");
+        glds_view_seek<NPB, NW>(gb, B, 0);
+    }
     const int lw = (NPA - w + NW - 1) / NW + (NPB - w + NW - 1) / NW;   // LDS-DMA instructions this wave issues per tile
 
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (p < nt) {
             glds_stage<AK, NPA, NW>(ga, A, smem + p * STAGE, p, w);
-            glds_stage<BKM, NPB, NW>(gb, B, smem + p * STAGE + A_BYTES, p, w);
+            glds_stage<BKM, NPB, NW, VIEW>(gb, B, smem + p * STAGE + A_BYTES, p, w);
         }
     int cur = 0, nxt = NSTAGE - 1;   // stage holding tile kt ; stage that tile kt + NSTAGE - 1 goes to
     for (int kt = 0; kt < nt; ++kt) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
         if (kt + NSTAGE - 1 < nt) {
             char* nx = smem + nxt * STAGE;
             glds_stage<AK, NPA, NW>(ga, A, nx, kt + NSTAGE - 1, w);
-            glds_stage<BKM, NPB, NW>(gb, B, nx + A_BYTES, kt + NSTAGE - 1, w);
+            glds_stage<BKM, NPB, NW, VIEW>(gb, B, nx + A_BYTES, kt + NSTAGE - 1, w);
         }
         const char* sA = smem + cur * STAGE;
         compute_tile_g<AK, BKM, MI, NI>(sA, sA + A_BYTES, acc, wm * MI * 16, wn * NI * 16, lane);
@@ -281,16 +285,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_ms_kernel(GemmK d) {
     gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, coff, t, NW * 64, smem);
 }
 
-template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE>
+template <bool AK, bool BKM, int WM, int WN, int MI, int NI, int NSTAGE, bool VIEW = false>
 static int launch_ms(const GemmK& k, dim3 grid, hipStream_t s) {
     constexpr int lds = NSTAGE * (WM * MI * 16 * 128 + 16384);
-    TRY_(ensure_dyn_lds((const void*)gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>, lds, "gemm_glds_ms"));
+    TRY_(ensure_dyn_lds((const void*)gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE, VIEW>, lds, "gemm_glds_ms"));
     if (prof_on()) {
         static const std::string sym = std::string("gemm_glds_ms_kernel<") + (AK ? "true" : "false") + ", " + (BKM ? "true" : "false") + ", " + std::to_string(WM) + ", " +
-                                       std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + std::to_string(NSTAGE) + ">";
+                                       std::to_string(WN) + ", " + std::to_string(MI) + ", " + std::to_string(NI) + ", " + std::to_string(NSTAGE) + ", " + (VIEW ? "true" : "false") + ">";
         prof_note_symbol(sym.c_str());
     }
-    hipLaunchKernelGGL((gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE>), grid, dim3(WM * WN * 64), lds, s, k);
+    hipLaunchKernelGGL((gemm_glds_ms_kernel<AK, BKM, WM, WN, MI, NI, NSTAGE, VIEW>), grid, dim3(WM * WN * 64), lds, s, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NBCI_EHIP, std::string("gemm_glds_ms launch: ") + hipGetErrorString(e));
     return NBCI_OK;
@@ -445,6 +449,12 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
     const bool ak = d.A.kmajor != 0, bk = d.B.kmajor != 0;
     if (glds_view(d)) {   // (eligibility: B row-major-in-k)
         if (!ak) return launch_glds<false, false, 2, 2, 4, 4, true>(k, grid, stream);
+        // small grids (the embedder's phase GEMM at small batches: B = 8 -> 80 tiles of 128 rows, K = 8192, one workgroup per CU on a
+        // third of the chip, a load round trip per K tile in the 2-stage kernel: 123 us): 64-row tiles, five stages in flight
+        if (d.K % 64 == 0 && d.K >= 256 && splitk == 1 && d.M > 64 && (long)((d.M + 127) / 128) * k.tiles_n * batch <= 128 && measure_env("NBCI_GEMM_S64", 1) != 0) {
+            k.tiles_m = (d.M + 63) / 64;
+            return launch_ms<true, false, 1, 4, 4, 2, 5, true>(k, dim3(k.tiles_m * k.tiles_n, batch), stream);
+        }
         // k-major A: 160-row tiles as well (the embedder's phase GEMM has M = B * T/stride = 9600 rows: 60 x 8 = 480 tiles, one round,
         // where 128- / 144-row tiles need a second, mostly empty one)
         if (d.K % 64 == 0 && splitk == 1) {

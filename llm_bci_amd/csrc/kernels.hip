@@ -268,10 +268,20 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
 }
 
 constexpr int LNB_RPW = 1;                          // rows per wave and pass (their loads are in flight together)
-// passes per block (`iters`; the column partial sums stay in registers across them): 4 when the rows fill the chip (fewer atomic
-// tails), fewer for small row counts so that every CU gets a block (B = 8: 1144 rows -> 286 blocks of one pass instead of 72 of four,
-// 14 -> 8 us per launch, eleven launches per step)
-static inline int lnb_iters(int M) { return M >= 8192 ? 4 : (M >= 3072 ? 2 : 1); }
+// passes per block (`iters`; the column partial sums stay in registers across them, so more passes = fewer LDS / atomic tails). A block is
+// 4 waves x `iters` rows; three blocks fit a CU (142 VGPRs). What matters is the most loaded CU: ceil(blocks / CUs) x iters row passes.
+// M = 9152 (B = 64): iters = 4 gives 572 blocks = 2.23 per CU, i.e. three on some CUs = 12 row passes against an average of 8.9; iters = 3
+// gives 763 blocks = 2.98 per CU = 9 row passes on every CU. B = 8 (1144 rows): one pass per block, 286 blocks, every CU busy.
+static inline int lnb_iters(int M) {
+    const int cus = std::max(1, available_cus());
+    int best = 1, best_cost = 1 << 30;
+    for (int it = 1; it <= 4; ++it) {
+        const int blocks = (M + 4 * it - 1) / (4 * it);
+        const int cost = ((blocks + cus - 1) / cus) * it;
+        if (cost <= best_cost) { best_cost = cost; best = it; }   // ties: the larger block (fewer tails)
+    }
+    return best;
+}
 
 template <int NV, typename DY>   // DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const float* __restrict__ x,
