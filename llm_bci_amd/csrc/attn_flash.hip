@@ -122,7 +122,7 @@ __device__ __forceinline__ void fa_to_image(char* img, const bf16x8 (&f)[2][HD /
 #endif
 constexpr int NQ = FA_NQ;
 
-template <int HD, bool TAIL, bool MASK, int NQ>
+template <int HD, bool TAIL, bool MASK, int NQ, bool SHARED = false>
 __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
                                             f32x4 (&o)[NQ][HD / 16], float (&m)[NQ], float (&l)[NQ], const unsigned (&rbase)[NQ],
                                             const int (&qidx)[NQ], int sq, int lane) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void fa_fwd_step(const FAArgs& a, char* img, const Fa
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) sc[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.x[t][ks], qf[qi][ks], sc[qi][t], 0, 0, 0);
         }
-    fa_to_image<HD>(img, b.y, i16, g);   // V rows of this step, for the transposed read below
+    if constexpr (!SHARED) fa_to_image<HD>(img, b.y, i16, g);   // V rows of this step, for the transposed read below (SHARED: img IS the workgroup's V stage)
     bf16x8 pf[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, (HD <= 96 && NQ == 2) ? 2 : 1) void fattn_fwd_
     }
 }
 
-template <int HD, bool TAIL, bool MASK>
+template <int HD, bool TAIL, bool MASK, bool SHARED = false>
 __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const FaBuf<HD>& b, int k0, const bf16x8 (&qf)[NQ][HD / 32],
                                              const bf16x8 (&df)[NQ][HD / 32], f32x4 (&dq)[NQ][HD / 16], const float (&Li)[NQ], const float (&D)[NQ],
                                              const unsigned (&rbase)[NQ], const int (&qidx)[NQ], int sq, int lane) {
@@ -307,7 +307,7 @@ __device__ __forceinline__ void fa_bwdq_step(const FAArgs& a, char* img, const F
                 dp[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], df[qi][ks], dp[qi][t], 0, 0, 0);   // dPd[query][key] = dO . v
             }
         }
-    fa_to_image<HD>(img, b.x, i16, g);   // K rows of this step, for the transposed read
+    if constexpr (!SHARED) fa_to_image<HD>(img, b.x, i16, g);   // K rows of this step, for the transposed read
     bf16x8 sf[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
@@ -401,10 +401,11 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn_bwd_q_kernel(FAAr
         }
 }
 
-template <int HD, bool TAIL, bool MASK, int NQ>
+template <int HD, bool TAIL, bool MASK, int NQ, bool SHARED = false>
 __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char* imgD, const FaBuf<HD>& b, int q0, const bf16x8 (&kf)[NQ][HD / 32],
                                               const bf16x8 (&vf)[NQ][HD / 32], f32x4 (&dk)[NQ][HD / 16], f32x4 (&dv)[NQ][HD / 16], const float* Lu,
-                                              const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], const bool (&key_valid)[NQ], int lane) {
+                                              const float* Du, unsigned ubase, const int (&krow)[NQ], const bool (&key_ok)[NQ], const bool (&key_valid)[NQ], int lane,
+                                              const float* ld_stage = nullptr) {
     constexpr int KS = HD / 32, NDB = HD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     f32x4 st[NQ][2], dpt[NQ][2];
@@ -420,9 +421,16 @@ __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char*
                 dpt[ki][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.y[t][ks], vf[ki][ks], dpt[ki][t], 0, 0, 0);  // dPd^T[key][query]
             }
         }
-    fa_to_image<HD>(imgQ, b.x, i16, g);
-    fa_to_image<HD>(imgD, b.y, i16, g);
+    if constexpr (!SHARED) { fa_to_image<HD>(imgQ, b.x, i16, g); fa_to_image<HD>(imgD, b.y, i16, g); }
     float Lq[2][4], Dq[2][4];
+    if constexpr (SHARED) {   // staged beside the images: [32 L | 32 D] of this step's queries (clamped rows; those only meet p = 0)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 lv = *(const float4*)(ld_stage + 16 * t + 4 * g), dvv = *(const float4*)(ld_stage + 32 + 16 * t + 4 * g);
+            Lq[t][0] = lv.x; Lq[t][1] = lv.y; Lq[t][2] = lv.z; Lq[t][3] = lv.w;
+            Dq[t][0] = dvv.x; Dq[t][1] = dvv.y; Dq[t][2] = dvv.z; Dq[t][3] = dvv.w;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -431,6 +439,7 @@ __device__ __forceinline__ void fa_bwdkv_step(const FAArgs& a, char* imgQ, char*
             const int qc = (TAIL && q >= a.S) ? a.S - 1 : q;
             Lq[t][r] = Lu[qc]; Dq[t][r] = Du[qc];
         }
+    }
     bf16x8 pf[NQ], sf[NQ];
 #pragma unroll
     for (int ki = 0; ki < NQ; ++ki) {
@@ -527,6 +536,241 @@ __global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn_bwd_
         }
 }
 
+
+// =================================================================================================================================
+// Shared-stage variants (round 3). Above, every wave streams the WHOLE other axis of its (sequence, head) from L2 into registers: at
+// 1501 tokens x head 96 that is 3.5 GB of L2 -> register traffic per backward launch and the kernels sit on that path (8.7 TB/s), not
+// on MFMA or VALU. Here the four waves of a workgroup - four (x NQ) 16-row tiles of the stationary axis of ONE (sequence, head) - share
+// each 32-row step of the streamed operands: the workgroup brings the two 32 x HD tiles into LDS ONCE (LDS-DMA, 16 bytes per lane,
+// lane-linear destination, the image's XOR swizzle applied to the per-lane SOURCE chunk), one step ahead in a second stage; every wave
+// takes its row fragments (ds_read_b128) and its transposed fragments (ds_read_b64_tr_b16) from the same image. One barrier per step.
+// L2 traffic per workgroup-step is one tile pair instead of four; the wave-private images and their copies disappear.
+// Waves whose tiles lie past the sequence end keep loading and meeting the barriers; they skip the arithmetic and the stores.
+constexpr int FA2_STAGE = 2 * FA_IMG + 256;   // X image + Y image + (dk/dv kernel) the step's 32 row log-sum-exps and 32 dO.O sums
+
+typedef __attribute__((address_space(1))) void fa_gvoid;
+typedef __attribute__((address_space(3))) void fa_lvoid;
+
+// this wave's share of one step's tiles: pieces w and w + 4 (4 rows x 256 B each) of the X image and of the Y image.
+// xp / yp: first column of the head in row 0 of the sequence; rows clamped to S - 1 (they only ever meet zero probabilities)
+template <int HD>
+__device__ __forceinline__ void fa2_stage(char* stage, const bf16_t* xp, long long ldx, const bf16_t* yp, long long ldy, int r0, int S, int w, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = w + 4 * j;
+        const int row = 4 * p + (lane >> 4), slot = lane & 15;
+        int ch = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));      // the chunk whose home is this 16-byte slot (fa_off is an involution per row)
+        if (ch >= HD / 8) ch = 0;                                   // (slots no fragment read touches: any valid address)
+        int gr = r0 + row;
+        if (gr > S - 1) gr = S - 1;
+        __builtin_amdgcn_global_load_lds((fa_gvoid*)(xp + (long long)gr * ldx + ch * 8), (fa_lvoid*)(stage + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((fa_gvoid*)(yp + (long long)gr * ldy + ch * 8), (fa_lvoid*)(stage + FA_IMG + p * 1024), 16, 0, 0);
+    }
+}
+
+// row fragments of a step out of the shared images (what fa_load fetched from global memory)
+template <int HD>
+__device__ __forceinline__ void fa2_frags(FaBuf<HD>& b, const char* stage, int i16, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            b.x[t][ks] = *(const bf16x8*)(stage + fa_off(16 * t + i16, 4 * ks + g));
+            b.y[t][ks] = *(const bf16x8*)(stage + FA_IMG + fa_off(16 * t + i16, 4 * ks + g));
+        }
+}
+
+#define FA2_PIPELINE(XP, LDX, YP, LDY, STEP, EXTRA)                                                \
+    {                                                                                              \
+        const int nsteps = (a.S + 31) / 32;                                                        \
+        const bool ragged = (a.S & 31) != 0;                                                       \
+        fa2_stage<HD>(smem, XP, LDX, YP, LDY, 0, a.S, wave, lane);                                 \
+        EXTRA(smem, 0);                                                                            \
+        __syncthreads();                                                                           \
+        for (int st = 0; st < nsteps; ++st) {                                                      \
+            char* cur = smem + (st & 1) * FA2_STAGE;                                               \
+            if (st + 1 < nsteps) { fa2_stage<HD>(smem + ((st + 1) & 1) * FA2_STAGE, XP, LDX, YP, LDY, 32 * (st + 1), a.S, wave, lane); EXTRA(smem + ((st + 1) & 1) * FA2_STAGE, 32 * (st + 1)); } \
+            if (active) {                                                                          \
+                FaBuf<HD> buf;                                                                     \
+                fa2_frags<HD>(buf, cur, i16, g);                                                   \
+                if (ragged && st == nsteps - 1) STEP(true, buf, cur, 32 * st); else STEP(false, buf, cur, 32 * st); \
+            }                                                                                      \
+            __syncthreads();   /* next stage landed (hipcc drains the LDS-DMA ahead of the barrier); everyone is done with `cur` */ \
+        }                                                                                          \
+    }
+
+template <int HD, bool MASK, int NQ>
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn2_fwd_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int qb0 = (blockIdx.y * 4 + wave) * NQ;
+    const bool active = 16 * qb0 < a.S;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    bf16x8 qf[NQ][KS];
+    f32x4 o[NQ][NDB];
+    float m[NQ], l[NQ];
+    unsigned rbase[NQ];
+    int query[NQ], qidx[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        query[qi] = 16 * (qb0 + qi) + i16;
+        const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
+        qidx[qi] = qrow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[qi][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[qi] = -INFINITY; l[qi] = 0.f;
+        rbase[qi] = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    }
+#define FWD2_STEP(T, B, ST, R0) fa_fwd_step<HD, T, MASK, NQ, true>(a, (ST) + FA_IMG, B, R0, qf, o, m, l, rbase, qidx, sq, lane)
+#define FA2_NOEXTRA(ST, R0) do { } while (0)
+    FA2_PIPELINE(base + a.H, ld, base + 2 * a.H, ld, FWD2_STEP, FA2_NOEXTRA)
+#undef FWD2_STEP
+    if (!active) return;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        float lt = l[qi];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        if (query[qi] < a.S) {
+            const float inv = 1.0f / lt;
+            const long long obase = ((long long)sq * a.S + query[qi]) * a.H + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                float v[4] = {o[qi][db][0] * inv, o[qi][db][1] * inv, o[qi][db][2] * inv, o[qi][db][3] * inv};
+                if (MASK && a.thr_out) drop4(a.key_out, a.thr_out, (unsigned)(obase + 16 * db + 4 * g), a.oscale, v);   // ndt1.py:292
+                bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)(a.out + obase + 16 * db + 4 * g) = ov;
+            }
+            if (g == 0) a.L[(long long)unit * a.S + query[qi]] = m[qi] + __logf(lt);
+        }
+    }
+}
+
+template <int HD, bool MASK>
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn2_bwd_q_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int qb0 = (blockIdx.y * 4 + wave) * NQ;
+    const bool active = 16 * qb0 < a.S;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    bf16x8 qf[NQ][KS], df[NQ][KS];
+    f32x4 dq[NQ][NDB];
+    float D[NQ], Li[NQ];
+    unsigned rbase[NQ];
+    int query[NQ], qidx[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        query[qi] = 16 * (qb0 + qi) + i16;
+        const int qrow = query[qi] < a.S ? query[qi] : a.S - 1;
+        qidx[qi] = qrow;
+        const bf16_t* dop = a.dout + ((long long)sq * a.S + qrow) * a.H + h * HD;
+        const bf16_t* op = a.out + ((long long)sq * a.S + qrow) * a.H + h * HD;
+        float d = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qi][ks] = *(const bf16x8*)(base + (long long)qrow * ld + 32 * ks + 8 * g);
+            df[qi][ks] = *(const bf16x8*)(dop + 32 * ks + 8 * g);
+            const bf16x8 of = *(const bf16x8*)(op + 32 * ks + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += bf2f(df[qi][ks][e]) * bf2f(of[e]);
+        }
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (MASK && a.thr_out) d *= 1.0f / a.oscale;
+        D[qi] = d;
+        Li[qi] = a.L[(long long)unit * a.S + qrow];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) dq[qi][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        rbase[qi] = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    }
+#define BQ2_STEP(T, B, ST, R0) fa_bwdq_step<HD, T, MASK, true>(a, (ST), B, R0, qf, df, dq, Li, D, rbase, qidx, sq, lane)
+    FA2_PIPELINE(base + a.H, ld, base + 2 * a.H, ld, BQ2_STEP, FA2_NOEXTRA)
+#undef BQ2_STEP
+    if (!active) return;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+        if (query[qi] < a.S) {
+            const long long obase = ((long long)sq * a.S + query[qi]) * ld + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                bf16x4 ov = {f2bf(dq[qi][db][0]), f2bf(dq[qi][db][1]), f2bf(dq[qi][db][2]), f2bf(dq[qi][db][3])};
+                *(bf16x4*)(a.dqkv + obase + 16 * db + 4 * g) = ov;
+            }
+            if (g == 0) a.Dsum[(long long)unit * a.S + query[qi]] = D[qi];
+        }
+}
+
+template <int HD, bool MASK, int NQ>
+__global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn2_bwd_kv_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 32, NDB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int kb0 = (blockIdx.y * 4 + wave) * NQ;
+    const bool active = 16 * kb0 < a.S;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const bf16_t* dob = a.dout + (long long)sq * a.S * a.H + h * HD;
+    bf16x8 kf[NQ][KS], vf[NQ][KS];
+    f32x4 dk[NQ][NDB], dv[NQ][NDB];
+    int key[NQ], krow[NQ];
+    bool key_ok[NQ], key_valid[NQ];
+#pragma unroll
+    for (int ki = 0; ki < NQ; ++ki) {
+        key[ki] = 16 * (kb0 + ki) + i16;
+        key_ok[ki] = key[ki] < a.S;
+        krow[ki] = key_ok[ki] ? key[ki] : a.S - 1;
+        key_valid[ki] = MASK ? a.tmask[(long long)sq * a.S + krow[ki]] != 0 : true;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ki][ks] = *(const bf16x8*)(base + a.H + (long long)krow[ki] * ld + 32 * ks + 8 * g);
+            vf[ki][ks] = *(const bf16x8*)(base + 2 * a.H + (long long)krow[ki] * ld + 32 * ks + 8 * g);
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { dk[ki][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ki][db] = dk[ki][db]; }
+    }
+    const float* Lu = a.L + (long long)unit * a.S;
+    const float* Du = a.Dsum + (long long)unit * a.S;
+    const unsigned ubase = (unsigned)((long long)unit * a.S * a.S);
+#define BK2_STEP(T, B, ST, R0) fa_bwdkv_step<HD, T, MASK, NQ, true>(a, (ST), (ST) + FA_IMG, B, R0, kf, vf, dk, dv, Lu, Du, ubase, krow, key_ok, key_valid, lane, (const float*)((ST) + 2 * FA_IMG))
+    // wave 0, one 4-byte LDS-DMA instruction per step: lanes 0..31 the row log-sum-exps, lanes 32..63 the dO.O sums of queries R0 .. R0 + 31
+#define BK2_EXTRA(ST, R0)                                                                                                  \
+    do {                                                                                                                   \
+        if (wave == 0) {                                                                                                   \
+            int qq = (R0) + (lane & 31);                                                                                   \
+            if (qq > a.S - 1) qq = a.S - 1;                                                                                \
+            __builtin_amdgcn_global_load_lds((fa_gvoid*)((lane < 32 ? Lu : Du) + qq), (fa_lvoid*)((ST) + 2 * FA_IMG), 4, 0, 0); \
+        }                                                                                                                  \
+    } while (0)
+    FA2_PIPELINE(base, ld, dob, (long long)a.H, BK2_STEP, BK2_EXTRA)
+#undef BK2_EXTRA
+#undef BK2_STEP
+    if (!active) return;
+#pragma unroll
+    for (int ki = 0; ki < NQ; ++ki)
+        if (key_ok[ki]) {
+            const long long obase = ((long long)sq * a.S + key[ki]) * ld + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                bf16x4 kv = {f2bf(dk[ki][db][0]), f2bf(dk[ki][db][1]), f2bf(dk[ki][db][2]), f2bf(dk[ki][db][3])};
+                bf16x4 vv = {f2bf(dv[ki][db][0]), f2bf(dv[ki][db][1]), f2bf(dv[ki][db][2]), f2bf(dv[ki][db][3])};
+                *(bf16x4*)(a.dqkv + obase + a.H + 16 * db + 4 * g) = kv;
+                *(bf16x4*)(a.dqkv + obase + 2 * a.H + 16 * db + 4 * g) = vv;
+            }
+        }
+}
+
 bool fattn_eligible(int dtype, int S, int H, int nh) {
     const char* e = measure_env_str("NBCI_FLASH_ATTN");   // (measurement builds; the NDT1 plan has its own switch, read at plan creation)
     const bool off = e && e[0] == '0';
@@ -548,6 +792,19 @@ static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32
 template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
+    static const int shared = measure_env("NBCI_FA_SHARED", 1);   // measurement: 0 = the wave-private streaming kernels above
+    if (shared && (HD < 128 || which == 0)) {   // the four waves of a workgroup share every streamed tile through LDS (two stages of two 8 KB images);
+                                                  // head 128 backward: the shared dk/dv kernel spills (35 registers) and runs 27 % slower: wave-private kernels
+        if (prof_on()) prof_note_symbol(which == 0 ? "fattn2_fwd_kernel" : which == 1 ? "fattn2_bwd_q_kernel" : "fattn2_bwd_kv_kernel");
+        // dk/dv: ONE 16-key tile per wave at two waves per SIMD (with the streamed tiles shared, halving a wave's keys no longer doubles the L2
+        // traffic that mattered): 1063 -> 853 us at 16 x 8 x 1501 x 96, 1877 -> 1669 us at 2048 x 8 x 205 x 32 (NBCI_FA_NKV=2: two tiles, one wave per SIMD)
+        static const int nkv1 = measure_env("NBCI_FA_NKV", 1);
+        if (which == 0) hipLaunchKernelGGL((fattn2_fwd_kernel<HD, MASK, 2>), g, dim3(256), 2 * FA2_STAGE, s, a);
+        else if (which == 1) hipLaunchKernelGGL((fattn2_bwd_q_kernel<HD, MASK>), g, dim3(256), 2 * FA2_STAGE, s, a);
+        else if (nkv1 == 1) hipLaunchKernelGGL((fattn2_bwd_kv_kernel<HD, MASK, 1>), dim3(a.NS * a.nh, (a.S + 63) / 64), dim3(256), 2 * FA2_STAGE, s, a);
+        else hipLaunchKernelGGL((fattn2_bwd_kv_kernel<HD, MASK, 2>), g, dim3(256), 2 * FA2_STAGE, s, a);
+        return check_launch("flash attention (shared stages)");
+    }
     if (which == 0) {
         // forward: two 16-query tiles per wave. Up to head 96 the kernel (and the dq kernel) is told to fit two waves per SIMD
         // (__launch_bounds__(256, 2)): left alone the compiler spread 180 + 92 registers over VGPRs and AGPRs for ONE wave per SIMD;
