@@ -542,6 +542,8 @@ int nbci_ptst_plan_create(const nbci_ptst_config* cfg, nbci_ptst_plan* out) {
     NBCI_REQUIRE(c.method == NBCI_PTST_CTC || c.method == NBCI_PTST_MLM, NBCI_EINVAL, "Method not implemented yet for PatchTST");
     NBCI_REQUIRE(c.method != NBCI_PTST_CTC || (c.vocab > 0 && c.blank_id >= 0 && c.blank_id < c.vocab), NBCI_EINVAL, "bad vocab / blank_id");
     NBCI_REQUIRE(c.method != NBCI_PTST_MLM || c.do_mask_input, NBCI_EINVAL, "Can't pretrain with inactive masking");
+    NBCI_REQUIRE(!c.fp8_qkv || (c.dtype == NBCI_BF16 && c.d_model % 128 == 0 && c.d_model <= 512), NBCI_ESHAPE,
+                 "patchtst: fp8 q/k/v needs the bf16 path and d_model = 128, 256, 384 or 512 (the fp8 GEMM keeps a row block's K in registers)");
     PtPlan* p = new PtPlan();
     p->c = c;
     p->P = (std::max(c.context_length, c.patch_length) - c.patch_length) / c.patch_stride + 1;

@@ -131,6 +131,8 @@ class PatchTSTForSpikingActivity(FlatParamModule):
         dtype_name = kwargs.get("compute_dtype", "bf16")
         self.compute_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32, "fp8": NBCI_BF16}[dtype_name]
         self.fp8_qkv = dtype_name == "fp8"
+        if self.fp8_qkv and (enc.d_model % 128 != 0 or enc.d_model > 512):   # (nbci_gemm_fp8: K = d_model in {128, 256, 384, 512})
+            raise Exception(f"compute_dtype fp8 needs d_model in (128, 256, 384, 512), got {enc.d_model}")
         c = PtstConfig()
         c.num_input_channels, c.context_length = enc.num_input_channels, enc.context_length
         c.patch_length, c.patch_stride = enc.patch_length, enc.patch_stride

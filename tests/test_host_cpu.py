@@ -323,3 +323,11 @@ def test_fp8_oracle_rounding_is_ocp_e4m3():
     base = np.floor(np.log2(amax)).astype(np.int64) - 8
     assert ((E == base) | (E == base + 1)).all() and (amax / np.exp2(E) <= 448.0).all() and (amax / np.exp2(E) > 224.0).all()
     assert (np.abs(d - x) <= 2.0 ** -4 * np.abs(x) + 2.0 ** -9 * np.exp2(E).repeat(32, -1).reshape(x.shape) + 1e-12).all()   # 3 mantissa bits, no saturation
+
+
+def test_patchtst_fp8_rejects_widths_the_fp8_gemm_cannot_take():
+    """d_model > 512 with compute_dtype fp8 used to fail in the middle of the first layer's forward; now at construction."""
+    from llm_bci_amd.patchtst import PatchTSTForSpikingActivity
+    with pytest.raises(Exception, match="fp8 needs d_model"):
+        PatchTSTForSpikingActivity({"encoder": {"d_model": 640, "num_attention_heads": 8}}, method_name="ctc", vocab_size=11, blank_id=0,
+                                   zero_infinity=True, compute_dtype="fp8")
