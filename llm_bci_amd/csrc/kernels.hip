@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
-                                                     int accumulate, RepCfg rc, LnCast cz, int iters) {
+                                                     int accumulate, RepCfg rc, LnCast cz, int iters, int dbg_notail) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][NV*256]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float invH = 1.0f / (float)H;
@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
   }
     // cross-wave reduce through LDS, then thread t owns columns t, t+256, ...: one CONTIGUOUS 256-B
     // atomic wave-instruction per 64 columns (float atomics run at full rate only in that shape)
+    if (dbg_notail) return;   // (measurement builds only: what the tail costs; wrong column sums)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         *(float4*)(red + (wv * 3 + 0) * W + (k * 64 + lane) * 4) = gw[k];
@@ -388,11 +389,13 @@ int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const f
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
     ProfScope ps("ln_bwd_kernel", 0.0, (double)M * H * ((dy_bf16 ? 2 : 4) + 4 + 4 + (accumulate_dx ? 4 : 0) + (cz.out ? (cz.bf16 ? 2 : 4) : 0)), s);
     const int nv = (H + 255) / 256;
-    const int iters = lnb_iters(M), rows = 4 * LNB_RPW * iters;
+    static const int notail = measure_env("NBCI_LNB_NOTAIL", 0);
+    static const int force_it = measure_env("NBCI_LNB_ITERS", 0);
+    const int iters = force_it > 0 ? force_it : lnb_iters(M), rows = 4 * LNB_RPW * iters;
     dim3 g((M + rows - 1) / rows);
 #define LNB(NVV, DYT)                                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, x, w, mean, \
-                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz, iters)
+                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz, iters, notail)
     if (dy_bf16) {
         if (nv <= 1) LNB(1, bf16_t);
         else if (nv <= 4) LNB(4, bf16_t);

@@ -111,6 +111,27 @@ class NativeTrainer:
             m._run_backward(self.grads, nseg - 1, 0)
             return False
         split = getattr(m, "_embed_split", None)
+        if self._use_side_stream():
+            # data parallel AND two streams: a segment's gradients are complete on the side stream (weight gradients, fold), so its
+            # bucket goes on the wire from there; train_step then drains the buckets and updates them on the side stream as well
+            main = torch.cuda.current_stream()
+            if self._aux is None:
+                self._aux = torch.cuda.Stream(device=self.stats.device)
+            aux = self._aux
+            aux.wait_stream(main)
+            for seg in range(nseg - 1, 0 if split is not None else -1, -1):
+                m._run_backward(self.grads, seg, seg, aux=aux)
+                with torch.cuda.stream(aux):
+                    self.reducer.segment_done(self.grads, seg)
+            if split is not None:
+                b0, e0 = m._segments[0]
+                m._run_backward(self.grads, 0, 0, embed_part=1, aux=aux)
+                with torch.cuda.stream(aux):
+                    self.reducer.range_done(self.grads, split, e0)
+                m._run_backward(self.grads, 0, 0, embed_part=2, aux=aux)
+                with torch.cuda.stream(aux):
+                    self.reducer.range_done(self.grads, b0, split)
+            return "aux"
         for seg in range(nseg - 1, 0 if split is not None else -1, -1):
             m._run_backward(self.grads, seg, seg)
             self.reducer.segment_done(self.grads, seg)
@@ -196,7 +217,25 @@ class NativeTrainer:
                     self.stats[2] += self._per_ratio(err)
                     self.stats[3] += 1
         stepped = self._backward_and_reduce(sync)
-        if sync and stepped:
+        if sync and stepped == "aux":
+            # the buckets were put on the wire from the side stream: it waits for each all-reduce in turn and updates (+ clears) that
+            # range, beside nothing on the main stream - which then waits for it before the next forward
+            lp_grads = self.reducer.comm_bf16 and self.reducer.enabled
+            done = 0
+            with torch.cuda.stream(self._aux):
+                for b, e in self.reducer.drain(self.grads, widen=not lp_grads):
+                    if lp_grads:
+                        self._adamw(b, e, g_lp=self.reducer.stage)
+                    else:
+                        self._adamw(b, e, zero=True)
+                    done += e - b
+                if lp_grads:
+                    self.grads.zero_()
+            if done != m._total:
+                raise RuntimeError("gradient buckets do not cover the flat parameter buffer")
+            main.wait_stream(self._aux)
+            self.opt_step += 1
+        elif sync and stepped:
             self.opt_step += 1
         elif sync:
             # One launch per reduced bucket, in the order the buckets were put on the wire: the update of the head / layer
