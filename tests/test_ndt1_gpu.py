@@ -530,6 +530,41 @@ def test_c2_at_the_benched_batch_64_against_the_cpu_restatement():
     print(f"[C2 @ B=64] bf16 argmax flips {res['bf16'][1]} / {int(valid.sum())} frames; PER errors bf16 {int(e16[:, 0].sum())} vs fp32 {int(e32[:, 0].sum())} / {int(e32[:, 1].sum())}")
 
 
+def test_maximum_length_max_F_tokens_against_the_cpu_restatement():
+    """The longest sequence the reference's position table allows (embedder.max_F = 1024 tokens, configs/ndt1.yaml:39 -> 32 + 4 * 1023 =
+    4124 bins), default widths, ragged: eval log-probs of the fp32 HIP path <= 1e-3 and of the bf16 path (masked streaming attention,
+    chunked CTC) <= 0.08 against oracle/torch_step.py; greedy paths equal where the top-2 margin > 0.1; the CTC sum-loss; and one bin
+    more is refused (ndt1.py:181-189 would index the position table out of range)."""
+    from oracle import torch_step as TS
+    B, T, N, S = 2, 4124, 256, 120
+    batch = _rand_batch(B, T, N, S, 41, [T, 3301], [S, 77], seed=21)
+    m32 = _model(_det_over("{}"), 41, dtype="fp32").to(DEV)
+    p = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref_loss, ref_lp, tok = TS.forward(p, cb, TS.default_hparams(), train=False)
+    ref_lp = ref_lp.numpy()
+    assert ref_lp.shape[1] == 1024 and list(tok.numpy()) == [1024, 1 + (3301 - 32) // 4]
+    valid = np.arange(1024)[None, :] < tok.numpy()[:, None]
+    top2 = np.sort(ref_lp, -1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    dev = _to_dev(batch)
+    for dt, m in (("fp32", m32), ("bf16", _model(_det_over("{}"), 41, dtype="bf16").to(DEV))):
+        m.eval()
+        with torch.no_grad():
+            loss, preds = m._run_forward(dev, want_grad=False)
+        torch.cuda.synchronize()
+        lp = preds.cpu().numpy()
+        assert np.abs(lp - ref_lp)[valid].max() <= (1e-3 if dt == "fp32" else 0.08), dt
+        np.testing.assert_allclose(float(loss.sum()), float(ref_loss), rtol=2e-4 if dt == "fp32" else 1e-2)
+        flips = (m.last_argmax.cpu().numpy() != ref_lp.argmax(-1)) & valid
+        assert margin[flips].max(initial=0.0) < (2e-3 if dt == "fp32" else 0.1), dt
+    too_long = _to_dev(_rand_batch(1, T + 4, N, 4, 41, [T + 4], [4], seed=1))
+    with pytest.raises(Exception):
+        m32._run_forward(too_long, want_grad=False)
+
+
 def _tiny_over():
     return {"encoder": {"smooth_and_noise": {"noise": False},
                         "embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}, "dropout": 0.0},
