@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="which mode `value` reports (N > 1 measures both)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce dtype (fp32 = the reference's DDP)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--residual-dtype", default="bf16", choices=["fp32", "bf16"], help="NDT1(residual_dtype=...): storage of the residual / gradient streams between kernels")
     ap.add_argument("--bins", type=int, default=600)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--target-len", type=int, default=60)
@@ -405,7 +406,7 @@ def main():
 
     torch.manual_seed(1)  # trainer.py:122
     over = {"encoder": {"embedder": {"n_channels": args.channels}}}
-    model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype).to(dev)
+    model = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype=args.dtype, residual_dtype=args.residual_dtype).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
     # OneCycle horizon: far beyond anything this script runs (the schedule only sets lr / beta1 scalars of the fused AdamW)
     tr = NativeTrainer(model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0,
@@ -517,6 +518,19 @@ def main():
         fed["vs_resident_ragged"] = round(fed["ms_per_step"] / rs, 3)
         extra[f"B{args.batch}_ragged_fed_from_host"] = fed
         tr.read_stats()
+        if args.dtype == "bf16":   # the same step with the OTHER storage of the residual / gradient streams (NDT1(residual_dtype=...))
+            other_rd = "fp32" if args.residual_dtype == "bf16" else "bf16"
+            torch.manual_seed(1)
+            m2 = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="bf16", residual_dtype=other_rd).to(dev)
+            tr_main, tr = tr, NativeTrainer(m2, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0, div_factor=25,
+                                            side_stream={"auto": "auto", "on": True, "off": False}[args.side_stream])
+            for i in range(3):
+                tr.train_step(batch, seed=i)
+            w = measure(batch, 12000, 5)[2]
+            extra[f"B{args.batch}_{other_rd}_streams"] = {"ms_per_step": round(1e3 * w / args.steps, 3), "samples_per_s": round(args.batch * args.steps / w, 1)}
+            tr.read_stats()
+            tr = tr_main
+            del m2
         extra["other_models"] = other_model_points(lib(), dev, max(5, args.steps // 2))
     if world > 1:
         dist.barrier()
@@ -534,7 +548,7 @@ def main():
                                    f"{args.channels} ch x {args.bins} bins -> {Tp} tokens, target len {args.target_len}, "
                                    "recipe trainer_ctc_ndt1.yaml (dropout 0.2/0.4 + noise on, AdamW lr 1e-3 wd 5e-5, OneCycle cosine)",
                        "global_batch": gb, "per_gpu_batch": per_gpu[args.scaling], "params": n_params, "params_padded": int(model._total),
-                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "parallelism": f"dp{world}" if world > 1 else "single", "residual_dtype": args.residual_dtype,
                        "step": "fwd + CTC + bwd + grad all-reduce(mean) + fused AdamW + on-device PER"},
             "model_tflops_per_s": round(3 * fps * value / 1e12, 1),
             "train_loss_per_example": round(stats["loss"], 4), "train_PER": stats["PER"],

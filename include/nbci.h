@@ -95,7 +95,7 @@ typedef struct nbci_gemm_desc {
     int32_t act;           /* NBCI_ACT_* */
     float drop_p;          /* 0 = off; keep-scale 1/(1-p) */
     uint32_t seed, site;   /* dropout stream id */
-    const float* residual; /* f32 [M][ldr] or NULL */
+    const void* residual;  /* [M][ldr] or NULL: f32, or bf16 when residual_dtype = NBCI_BF16 (last field) */
     int64_t ldr;
     const int64_t* residual_rows; /* optional gather: residual row index per output row (nn.Embedding add, ndt1.py:189);
                                      batched: indexed by the global row (batch offset czs / ldc + m) */
@@ -111,6 +111,8 @@ typedef struct nbci_gemm_desc {
     int64_t colsum_rep_stride;    /* colsum replicas (to spread same-address atomics): replica r at colsum + r*stride */
     int32_t colsum_nrep;          /* 0/1 = no replication */
     int32_t gate_follows_c;       /* 1: batched GEMM whose gate has C's layout: the batch offset (czs1/czs2) applies to it too */
+    int32_t residual_dtype;       /* storage type of `residual`: NBCI_F32 (0, default) or NBCI_BF16 (a bf16 residual stream: widened,
+                                     added in f32, the sum rounded once when C is stored) */
 } nbci_gemm_desc;
 
 int nbci_gemm(const nbci_gemm_desc* d, nbci_stream_t stream);
@@ -136,6 +138,17 @@ int nbci_layernorm_fwd(const float* x, const float* w, const float* b, void* y, 
 int nbci_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                        float* dx, float* dw, float* db, int32_t M, int32_t H, int32_t accumulate_dx,
                        nbci_stream_t stream);
+/* The general forms the NDT1 train step launches. x: f32, or bf16 (a bf16 residual stream, nbci_ndt1_config.residual_dtype: statistics
+ * and normalisation in f32 from the widened row; y must then be bf16). Backward: dy f32 or bf16 (dy_dtype); the gradient stream
+ * dx_out = dx_in (NULL: nothing) + LN'(dy) in x's dtype (one buffer or two), summed in f32 and rounded once at the store; optionally the
+ * dropout-masked operand copy of dx_out for the next GEMMs (cast_out in cast_dtype; mask keyed by (seed, site, element offset), keep
+ * scale 1 / (1 - p)) and the column sums of that copy (cast_colsum f32 [H] +=: the bias gradient of the Linear below). dw / db +=. */
+int nbci_layernorm_fwd_ex(const void* x, int32_t x_dtype, const float* w, const float* b, void* y, int32_t y_dtype, float* mean,
+                          float* rstd, int32_t M, int32_t H, nbci_stream_t stream);
+int nbci_layernorm_bwd_ex(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w, const float* mean,
+                          const float* rstd, const void* dx_in, void* dx_out, float* dw, float* db, int32_t M, int32_t H,
+                          void* cast_out, int32_t cast_dtype, float drop_p, uint32_t seed, uint32_t site, float* cast_colsum,
+                          nbci_stream_t stream);
 
 /* masked softmax + attention-prob dropout of F.scaled_dot_product_attention (ndt1.py:289) with the
  * mask of ndt1.py:435-437 computed from token validity + context span instead of a (B,T',T') tensor */
@@ -326,6 +339,11 @@ typedef struct nbci_ndt1_config { /* configs/ndt1.yaml, flattened */
      * front of the spike tokens ([day, block, tokens...]), always attendable, dropped again after out_norm. Table sizes (n_days /
      * n_blocks); 0 = off. io.day_idx / io.block_idx pick the rows. Not with use_rope (the reference fails there). */
     int32_t day_token_days, block_token_blocks;
+    /* storage of the residual stream x (the saved LayerNorm inputs) and of its gradient stream between kernels. NBCI_F32 (0, default):
+     * what bf16 autocast keeps in f32 in the reference (ndt1.py:325,328: x = x + branch). NBCI_BF16 (dtype bf16 only): both streams are
+     * stored in bf16, every kernel widens them, adds / normalises in f32 and rounds ONCE at its store: half the bytes of the
+     * HBM-bound kernels (LayerNorm forward / backward, the residual epilogues of out_proj and down_proj). */
+    int32_t residual_dtype;
 } nbci_ndt1_config;
 
 typedef struct nbci_ndt1_io {

@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
                 ("residual_rows", C.c_void_p), ("residual_first", C.c_int32),
                 ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_act", C.c_int32), ("c2_grad", C.c_int32),
                 ("colsum", C.c_void_p), ("colsum_rep_stride", C.c_int64), ("colsum_nrep", C.c_int32),
-                ("gate_follows_c", C.c_int32)]
+                ("gate_follows_c", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
 class NDT1Config(C.Structure):
@@ -54,7 +54,7 @@ class NDT1Config(C.Structure):
         ("use_rope", C.c_int32), ("rope_theta", C.c_float), ("context_forward", C.c_int32), ("context_backward", C.c_int32),
         ("pos", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32), ("dtype", C.c_int32),
         ("factors_size", C.c_int32), ("factors_act", C.c_int32), ("factors_bias", C.c_int32), ("adapt_days", C.c_int32),
-        ("day_token_days", C.c_int32), ("block_token_blocks", C.c_int32)]
+        ("day_token_days", C.c_int32), ("block_token_blocks", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
 class NDT1IO(C.Structure):
@@ -170,6 +170,10 @@ _SIGNATURES = {
                                     C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "nbci_layernorm_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "nbci_layernorm_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "nbci_layernorm_fwd_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_int32, C.c_void_p]),
+    "nbci_layernorm_bwd_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                        C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "nbci_softmax_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 7 +
                          [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nbci_softmax_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +

@@ -51,6 +51,20 @@ int nbci_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
                        float* dw, float* db, int32_t M, int32_t H, int32_t accumulate_dx, nbci_stream_t stream) {
     return nbci::layernorm_bwd_launch(dy, x, w, mean, rstd, dx, dw, db, M, H, accumulate_dx, (hipStream_t)stream);
 }
+int nbci_layernorm_fwd_ex(const void* x, int32_t x_dtype, const float* w, const float* b, void* y, int32_t y_dtype, float* mean, float* rstd,
+                          int32_t M, int32_t H, nbci_stream_t stream) {
+    return nbci::layernorm_fwd_launch(x, x_dtype, w, b, y, y_dtype, mean, rstd, M, H, (hipStream_t)stream);
+}
+int nbci_layernorm_bwd_ex(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w, const float* mean, const float* rstd,
+                          const void* dx_in, void* dx_out, float* dw, float* db, int32_t M, int32_t H, void* cast_out, int32_t cast_dtype,
+                          float drop_p, uint32_t seed, uint32_t site, float* cast_colsum, nbci_stream_t stream) {
+    if (!cast_out && drop_p > 0.f && !cast_colsum) return nbci::fail(NBCI_EINVAL, "layernorm_bwd_ex: dropout without a cast output or its column sums");
+    const nbci::LnCast cz{cast_out, cast_dtype == NBCI_BF16 ? 1 : 0, nbci::drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
+                          nbci::drop_key(seed, site), cast_colsum, 0, 0, 0, 0};
+    return nbci::layernorm_bwd_launch(dy, dy_dtype == NBCI_BF16 ? 1 : 0, x, w, mean, rstd,
+                                      nbci::LnStreams{x_dtype == NBCI_BF16 ? 1 : 0, dx_in, dx_out, x_dtype == NBCI_BF16 ? 1 : 0}, dw, db, M, H,
+                                      (hipStream_t)stream, nbci::RepCfg{0, 1}, cz);
+}
 int nbci_softmax_fwd(const float* S, void* P, void* Pd, int32_t p_dtype, const int32_t* token_mask, int32_t B, int32_t n_heads,
                      int32_t Tp, int32_t ldS, int32_t ldP, int32_t ctx_forward, int32_t ctx_backward, float drop_p,
                      uint32_t seed, uint32_t site, nbci_stream_t stream) {

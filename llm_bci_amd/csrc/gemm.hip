@@ -194,7 +194,7 @@ static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
     k.colsum = d.colsum;
     k.colsum_rc = RepCfg{d.colsum_rep_stride, d.colsum_nrep > 1 ? d.colsum_nrep : 1};
     k.tile_row = 0;
-    k.residual = d.residual; k.ldr = d.ldr;
+    k.residual = (const float*)d.residual; k.ldr = d.ldr; k.residual_bf16 = (d.residual && d.residual_dtype == NBCI_BF16) ? 1 : 0;
     k.residual_rows = (const long long*)d.residual_rows; k.residual_first = d.residual_first;
     k.gate = d.gate; k.ldg = d.ldg; k.gate_act = d.gate_act; k.gate_bf16 = d.in_dtype == NBCI_BF16; k.gate_coff = d.gate_follows_c ? 1 : 0;
     k.c2_grad = d.c2_grad;
@@ -322,7 +322,7 @@ void prof_end(hipStream_t s) {
 static double gemm_bytes(const nbci_gemm_desc& d) {   // operands once in, result once out (+ the residual / gate / second output the epilogue touches)
     const double es = d.in_dtype == NBCI_BF16 ? 2 : 4, cs = d.c_dtype == NBCI_BF16 ? 2 : 4, batch = d.batch > 0 ? d.batch : 1;
     double b = es * ((double)d.M * d.K + (double)d.N * d.K) * batch + cs * (double)d.M * d.N * batch;
-    if (d.residual && !d.residual_rows) b += 4.0 * d.M * d.N * batch;
+    if (d.residual && !d.residual_rows) b += (d.residual_dtype == NBCI_BF16 ? 2.0 : 4.0) * d.M * d.N * batch;
     if (d.gate) b += es * (double)d.M * d.N * batch;
     if (d.C2) b += cs * (double)d.M * d.N * batch;
     if (d.beta != 0.f) b += cs * (double)d.M * d.N * batch;

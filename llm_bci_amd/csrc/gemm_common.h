@@ -75,7 +75,8 @@ struct GemmK {
     float drop_scale; unsigned drop_thr; unsigned drop_key;
     float* colsum;  // optional: colsum[(coff % ldc) + n] += sum over rows of the stored value
     RepCfg colsum_rc; int tile_row;  // replica config; tile_row = replica selector (set by the kernel)
-    const float* residual; long long ldr;
+    const float* residual; long long ldr;   // (bf16 storage when residual_bf16: the pointer is then a bf16_t*)
+    int residual_bf16;
     const long long* residual_rows;  // optional gather: residual row for output row m
     int residual_first;              // add residual before act/dropout (embed: proj + pos, then dropout)
     const void* gate; long long ldg; int gate_act;  // v *= act'(gate[m][n]) (gate in the input dtype)
@@ -275,7 +276,7 @@ __device__ __forceinline__ void act_bwd_mul4(int act, const float (&g)[4], float
 // cost 6 us of a 24 us K = 1024 tile after the first clean-up (7.2 before).
 enum : int {
     EPI_BIAS = 1, EPI_C2GRAD = 2, EPI_RES_FIRST = 4, EPI_RES_LAST = 8, EPI_RES_ROWS = 16, EPI_ACT = 32, EPI_GATE_MUL = 64,
-    EPI_GATE_OUT = 128, EPI_DROP = 256, EPI_COLSUM = 512, EPI_CBF16 = 1024, EPI_BETA = 2048, EPI_GATE_PRE = 4096, EPI_GENERIC = 1 << 30
+    EPI_GATE_OUT = 128, EPI_DROP = 256, EPI_COLSUM = 512, EPI_CBF16 = 1024, EPI_BETA = 2048, EPI_GATE_PRE = 4096, EPI_RESBF16 = 8192, EPI_GENERIC = 1 << 30
 };
 __host__ __device__ inline int epi_mode_of(const GemmK& d) {
     int m = 0;
@@ -283,6 +284,7 @@ __host__ __device__ inline int epi_mode_of(const GemmK& d) {
     if (d.C2) m |= d.c2_grad ? EPI_C2GRAD : EPI_GENERIC;
     if (d.residual) m |= d.residual_first ? EPI_RES_FIRST : EPI_RES_LAST;
     if (d.residual && d.residual_rows) m |= EPI_RES_ROWS;
+    if (d.residual && d.residual_bf16) m |= EPI_RESBF16;
     if (d.act != 0 && !(d.C2 && d.c2_grad)) m |= EPI_ACT;
     if (d.gate) {
         const bool fast = d.gate_bf16 && (d.ldg & 3) == 0;   // one 8-byte load per 4 outputs
@@ -335,6 +337,15 @@ __device__ __forceinline__ void epi_apply_t(const GemmK& d, float (&v)[4], int m
     }
     auto add_residual = [&]() {
         const long long rr = EPI_HAS(EPI_RES_ROWS, d.residual_rows) ? d.residual_rows[(coff ? coff / d.ldc : 0) + m] : (long long)m;   // gather index: the GLOBAL output row (batched GEMMs: coff = batch offset)
+        if (EPI_HAS(EPI_RESBF16, d.residual_bf16)) {   // a bf16 residual stream: widened here, the sum is rounded once at the store
+            const bf16_t* r = (const bf16_t*)d.residual + rr * d.ldr + n;
+            if constexpr (FULL) { const bf16x4 r4 = *(const bf16x4*)r; v[0] += bf2f(r4[0]); v[1] += bf2f(r4[1]); v[2] += bf2f(r4[2]); v[3] += bf2f(r4[3]); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < d.N) v[e] += bf2f(r[e]);
+            }
+            return;
+        }
         const float* r = d.residual + rr * d.ldr + n;
         if constexpr (FULL) { const float4 r4 = *(const float4*)r; v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
         else {
@@ -524,6 +535,10 @@ __device__ __forceinline__ void epi_tile_rows(const GemmK& d, const float* tile,
                     NBCI_EPI_CASE(EPI_BIAS | EPI_RES_LAST)
                     NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS | EPI_DROP)
                     NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS | EPI_DROP | EPI_CBF16)              // bf16 residual stream (NDT1)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_DROP | EPI_RES_LAST | EPI_RESBF16 | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_BIAS | EPI_RES_LAST | EPI_RESBF16 | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_DROP | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_COLSUM | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_GATE_MUL | EPI_COLSUM | EPI_CBF16)

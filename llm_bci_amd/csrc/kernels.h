@@ -29,12 +29,15 @@ int smooth_noise_launch(const float* spikes, void* out, int out_dtype, int B, in
 int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* lens, int B, int T, int Tp,
                       int size, int stride, int32_t* tmask, int64_t* tts, int32_t* tlens, hipStream_t s, int npre = 0);
 // learned prefix tokens (day / block, ndt1.py:192-203): assemble [prefix rows | spike tokens] + embedder dropout; table gradients
-int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, float* x,
-                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
-int prefix_grad_launch(const float* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
-                       uint32_t site, hipStream_t s);
+int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, void* x,
+                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, int x_dtype = NBCI_F32);
+int prefix_grad_launch(const void* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
+                       uint32_t site, hipStream_t s, int dx_dtype = NBCI_F32);
 
-// nn.LayerNorm (eps 1e-5, affine) forward: x f32 (M,H) -> y act dtype, saves mean/rstd
+// nn.LayerNorm (eps 1e-5, affine) forward: x f32 (M,H) -> y act dtype, saves mean/rstd. First form: x f32, or bf16 (a bf16 residual
+// stream: statistics and the normalisation in f32 from the widened row; y bf16)
+int layernorm_fwd_launch(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, float* mean,
+                         float* rstd, int M, int H, hipStream_t s, float* y32 = nullptr);
 int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean,
                          float* rstd, int M, int H, hipStream_t s, float* y32 = nullptr);  // y32: optional f32 copy of y
 // backward: dx (f32, M,H) += LN'(dy); dw += sum dy*xhat; db += sum dy
@@ -42,6 +45,12 @@ int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y
 int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s,
                          RepCfg rc = RepCfg{0, 1}, LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}, int dy_bf16 = 0);
+// general form: the saved input x and the gradient stream in f32 or (both) bf16; dx_out = dx_in (NULL: nothing) + LN'(dy), two buffers
+// or one. All arithmetic in f32; a bf16 stream is rounded once, at the store.
+struct LnStreams { int x_bf16; const void* dx_in; void* dx_out; int dx_bf16; };
+int layernorm_bwd_launch(const void* dy, int dy_bf16, const void* x, const float* w, const float* mean, const float* rstd, LnStreams st,
+                         float* dw, float* db, int M, int H, hipStream_t s, RepCfg rc = RepCfg{0, 1},
+                         LnCast cz = LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr});
 
 // masked softmax over scores (B,nh,Tp,ldS f32): mask = eye | (ctx & key_valid) (ndt1.py:435-437; tmask NULL = all valid),
 // writes P (pre-dropout) and Pd (post attention-prob dropout, ndt1.py:289) in act dtype, ld = ldP
@@ -69,8 +78,8 @@ int fold_replicas_launch(float* rep, long long stride, int nrep, const int* flat
 int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype, int B, int T, int Tp, int D,
                           int size, int stride, int act, hipStream_t s);
 // dpos[tts[row]][:] += dx[row][:] * keepmask  (nn.Embedding backward + embed dropout)
-int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
-                   uint32_t site, hipStream_t s, int Tp = 0, int npre = 0);
+int posgrad_launch(const void* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
+                   uint32_t site, hipStream_t s, int Tp = 0, int npre = 0, int dx_dtype = NBCI_F32);
 
 // RoPE on the q and k thirds of a packed (M, 3H) qkv buffer, in place (ndt1.py:62-71); inverse = backward
 int rope_launch(void* qkv, int dtype, const int64_t* tts, const float* cos_t, const float* sin_t, int M, int H,

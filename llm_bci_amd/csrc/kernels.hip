@@ -151,11 +151,32 @@ int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* len
     return check_launch("token_prep");
 }
 
+// four consecutive elements of a row as f32: an f32 row, or a bf16 one (a bf16 residual stream: half the bytes, widened here)
+template <typename T>
+__device__ __forceinline__ float4 ld4f(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *(const float4*)p;
+    } else {
+        const bf16x4 t = *(const bf16x4*)p;
+        return make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3]));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4f(T* p, const float4& v) {
+    if constexpr (sizeof(T) == 4) {
+        *(float4*)p = v;
+    } else {
+        const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+        *(bf16x4*)p = o;
+    }
+}
+
 // prefix tokens, forward: x (B, npre + Tp, H) = [table0[idx0[b]], (table1[idx1[b]]), xtok[b, :]] then the embedder dropout over ALL of
 // it (ndt1.py:192-203), dropout stream index = element offset in x
+template <typename T>   // T: storage type of x (f32, or a bf16 residual stream)
 __global__ __launch_bounds__(256) void prefix_assemble_kernel(const float* __restrict__ xtok, const float* __restrict__ tab0,
                                                               const int64_t* __restrict__ idx0, const float* __restrict__ tab1,
-                                                              const int64_t* __restrict__ idx1, float* __restrict__ x, int B, int Tp, int npre,
+                                                              const int64_t* __restrict__ idx1, T* __restrict__ x, int B, int Tp, int npre,
                                                               int H, unsigned thr, float dscale, uint32_t key) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long long total = (long long)B * (Tp + npre) * H;
@@ -170,56 +191,59 @@ __global__ __launch_bounds__(256) void prefix_assemble_kernel(const float* __res
     const float4 a = *(const float4*)src;
     float v[4] = {a.x, a.y, a.z, a.w};
     if (thr) drop4(key, thr, (unsigned)i, dscale, v);
-    *(float4*)(x + i) = make_float4(v[0], v[1], v[2], v[3]);
+    st4f(x + i, make_float4(v[0], v[1], v[2], v[3]));
 }
 
-int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, float* x,
-                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+int prefix_assemble_launch(const float* xtok, const float* tab0, const int64_t* idx0, const float* tab1, const int64_t* idx1, void* x,
+                           int B, int Tp, int npre, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, int x_dtype) {
     NBCI_REQUIRE(xtok && tab0 && idx0 && x && npre >= 1 && npre <= 2 && H % 4 == 0 && (npre == 1 || (tab1 && idx1)), NBCI_EINVAL,
                  "prefix_assemble: bad argument");
     const long long n4 = (long long)B * (Tp + npre) * H / 4;
-    hipLaunchKernelGGL(prefix_assemble_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, xtok, tab0, idx0, tab1, idx1, x, B, Tp,
-                       npre, H, drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site));
+    DISPATCH_DTYPE(x_dtype, T, hipLaunchKernelGGL((prefix_assemble_kernel<T>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, xtok, tab0, idx0, tab1, idx1,
+                                                  (T*)x, B, Tp, npre, H, drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site)));
     return check_launch("prefix_assemble");
 }
 
 // prefix tokens, backward: table[idx[b]] += dropout-masked dx[b, k, :] for the k-th prefix position
-__global__ __launch_bounds__(256) void prefix_grad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ idx, float* __restrict__ dtab,
+template <typename T>
+__global__ __launch_bounds__(256) void prefix_grad_kernel(const T* __restrict__ dx, const int64_t* __restrict__ idx, float* __restrict__ dtab,
                                                           int B, int Tt, int k, int H, unsigned thr, float dscale, uint32_t key) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, c = i % H;
     const long long o = ((long long)b * Tt + k) * H + c;
-    float v = dx[o];
+    float v = ldf<T>(dx, o);
     if (thr) v = drop_keep(key, thr, (unsigned)o) ? v * dscale : 0.f;
     if (v != 0.f) atomicAdd(dtab + idx[b] * H + c, v);
 }
 
-int prefix_grad_launch(const float* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
-                       uint32_t site, hipStream_t s) {
-    hipLaunchKernelGGL(prefix_grad_kernel, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, dx, idx, dtab, B, Tt, k, H,
-                       drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site));
+int prefix_grad_launch(const void* dx, const int64_t* idx, float* dtab, int B, int Tt, int k, int H, float drop_p, uint32_t seed,
+                       uint32_t site, hipStream_t s, int dx_dtype) {
+    DISPATCH_DTYPE(dx_dtype, T, hipLaunchKernelGGL((prefix_grad_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, (const T*)dx, idx, dtab, B, Tt, k, H,
+                                                   drop_threshold(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, drop_key(seed, site)));
     return check_launch("prefix_grad");
 }
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm
 // ------------------------------------------------------------------------------------------
-template <int NV, typename TO>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// One wave per row. (Two rows per wave, so that M = 9152 rows fit one round of 8192 resident waves, measured slower: 12.7 vs 11.3 us alone;
+// the kernel is a latency chain - load, two wave reductions, store - not a bandwidth one: 1144 rows take 8.3 us, 9152 rows 11.3.)
+template <int NV, typename TO, typename TX>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, TO* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int H,
                                                      float* __restrict__ y32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (long long)row * H;
+    const TX* xr = x + (long long)row * H;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = (k * 64 + lane) * 4;
-        v[k] = (c < H) ? *(const float4*)(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k] = (c < H) ? ld4f(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += v[k].x + v[k].y + v[k].z + v[k].w;
     }
     const float mu = wave_sum(s) / (float)H;
@@ -242,128 +266,169 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const long long o = (long long)row * H + c;
             const float4 r = make_float4((v[k].x - mu) * rs * ww.x + bv.x, (v[k].y - mu) * rs * ww.y + bv.y,
                                          (v[k].z - mu) * rs * ww.z + bv.z, (v[k].w - mu) * rs * ww.w + bv.w);
-            stf<TO>(y, o + 0, r.x); stf<TO>(y, o + 1, r.y); stf<TO>(y, o + 2, r.z); stf<TO>(y, o + 3, r.w);
+            st4f(y + o, r);
             if (y32) *(float4*)(y32 + o) = r;   // f32 copy for a following residual add (post-norm layers)
         }
     }
 }
 
-template <typename TO>
-static void ln_fwd_dispatch(int nv, dim3 g, hipStream_t s, const float* x, const float* w, const float* b, TO* y,
+template <typename TO, typename TX>
+static void ln_fwd_dispatch(int nv, hipStream_t s, const TX* x, const float* w, const float* b, TO* y,
                             float* mean, float* rstd, int M, int H, float* y32) {
-    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
-    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
-    else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
-    else hipLaunchKernelGGL((ln_fwd_kernel<16, TO>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    const dim3 g((unsigned)((M + 3) / 4));
+    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else hipLaunchKernelGGL((ln_fwd_kernel<16, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
 }
 
-int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
+int layernorm_fwd_launch(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
                          int M, int H, hipStream_t s, float* y32) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "layernorm: hidden must be a multiple of 4 and <= 4096");
-    ProfScope ps("ln_fwd_kernel", 0.0, (double)M * H * (4 + (y_dtype == NBCI_BF16 ? 2 : 4) + (y32 ? 4 : 0)), s);
+    NBCI_REQUIRE(x_dtype == NBCI_F32 || y_dtype == NBCI_BF16, NBCI_EINVAL, "layernorm: a bf16 input row goes with a bf16 output");
+    ProfScope ps("ln_fwd_kernel", 0.0, (double)M * H * ((x_dtype == NBCI_BF16 ? 2 : 4) + (y_dtype == NBCI_BF16 ? 2 : 4) + (y32 ? 4 : 0)), s);
     const int nv = (H + 255) / 256;
-    dim3 g((M + 3) / 4);
-    DISPATCH_DTYPE(y_dtype, TO, ln_fwd_dispatch<TO>(nv, g, s, x, w, b, (TO*)y, mean, rstd, M, H, y32));
+    if (x_dtype == NBCI_BF16) {
+        ln_fwd_dispatch<bf16_t, bf16_t>(nv, s, (const bf16_t*)x, w, b, (bf16_t*)y, mean, rstd, M, H, y32);
+    } else {
+        DISPATCH_DTYPE(y_dtype, TO, (ln_fwd_dispatch<TO, float>(nv, s, (const float*)x, w, b, (TO*)y, mean, rstd, M, H, y32)));
+    }
     return check_launch("layernorm_fwd");
 }
+int layernorm_fwd_launch(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd,
+                         int M, int H, hipStream_t s, float* y32) {
+    return layernorm_fwd_launch(x, NBCI_F32, w, b, y, y_dtype, mean, rstd, M, H, s, y32);
+}
 
-constexpr int LNB_RPW = 1;                          // rows per wave and pass (their loads are in flight together)
-// passes per block (`iters`; the column partial sums stay in registers across them, so more passes = fewer LDS / atomic tails). A block is
-// 4 waves x `iters` rows; three blocks fit a CU (142 VGPRs). What matters is the most loaded CU: ceil(blocks / CUs) x iters row passes.
-// M = 9152 (B = 64): iters = 4 gives 572 blocks = 2.23 per CU, i.e. three on some CUs = 12 row passes against an average of 8.9; iters = 3
-// gives 763 blocks = 2.98 per CU = 9 row passes on every CU. B = 8 (1144 rows): one pass per block, 286 blocks, every CU busy.
+// rows per wave (`iters`; the column partial sums stay in registers across them, so more rows = fewer LDS / atomic tails, and the next
+// row's loads run under the current row's arithmetic). A block is 4 waves x `iters` rows; two blocks fit a CU (182 - 240 VGPRs). What
+// matters is the most loaded CU: ceil(blocks / (2 CUs)) x iters rows per wave. M = 9152 (B = 64): iters = 5 gives 458 blocks, one round;
+// B = 8 (1144 rows): one row per wave, 286 blocks, every CU busy.
 static inline int lnb_iters(int M) {
-    const int cus = std::max(1, available_cus());
+    const int slots = 2 * std::max(1, available_cus());
     int best = 1, best_cost = 1 << 30;
-    for (int it = 1; it <= 4; ++it) {
+    for (int it = 1; it <= 12; ++it) {
         const int blocks = (M + 4 * it - 1) / (4 * it);
-        const int cost = ((blocks + cus - 1) / cus) * it;
+        const int cost = ((blocks + slots - 1) / slots) * it;
         if (cost <= best_cost) { best_cost = cost; best = it; }   // ties: the larger block (fewer tails)
     }
     return best;
 }
 
-template <int NV, typename DY>   // DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const float* __restrict__ x,
+// DY = float, or bf16_t: the incoming gradient as a bf16 GEMM wrote it (half the bytes). TX: the saved LayerNorm input (f32, or a bf16
+// residual stream). TD: the gradient stream, read from dx_in (NULL = nothing to add to) and written to dx_out (the two may be one buffer).
+// FULL: H == NV * 256, no column predicates.
+// A wave owns rows row0, row0 + 4, ... of its block's 4 * iters rows and keeps TWO rows in registers: the loads of the next row are
+// issued (as stored: 8 bytes per bf16x4) before the arithmetic of the current one, so the ~1 us of VALU work per row (statistics,
+// dropout hash, packing) runs under the next row's memory latency instead of after it (measured alone, M = 9152, H = 1024, bf16
+// streams: tools/time_ln.py).
+template <typename T> struct Raw4 { using type = float4; };
+template <> struct Raw4<bf16_t> { using type = bf16x4; };
+template <typename T>
+__device__ __forceinline__ typename Raw4<T>::type ldraw(const T* p, bool ok) {
+    using R = typename Raw4<T>::type;
+    if constexpr (sizeof(T) == 4) {
+        return ok ? *(const R*)p : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const R z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        return ok ? *(const R*)p : z;
+    }
+}
+__device__ __forceinline__ float4 widen4(const float4& v) { return v; }
+__device__ __forceinline__ float4 widen4(const bf16x4& t) { return make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])); }
+
+template <int NV, typename DY, typename TX, typename TD, bool FULL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     const float* __restrict__ rstd, const TD* dx_in, TD* dx_out,
                                                      float* __restrict__ dw, float* __restrict__ db, int M, int H,
-                                                     int accumulate, RepCfg rc, LnCast cz, int iters, int dbg_notail) {
+                                                     RepCfg rc, LnCast cz, int iters, int dbg_notail) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][NV*256]
+    using RX = typename Raw4<TX>::type;
+    using RY = typename Raw4<DY>::type;
+    using RD = typename Raw4<TD>::type;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float invH = 1.0f / (float)H;
     const int W = NV * 256;
+    const bool want_cast = cz.out != nullptr || cz.colsum != nullptr;
     float4 gw[NV], gb[NV], gc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) { gw[k] = make_float4(0.f, 0.f, 0.f, 0.f); gb[k] = gw[k]; gc[k] = gw[k]; }
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-    const int ra = (blockIdx.x * iters + it) * 4 * LNB_RPW + wv * LNB_RPW;
-    float4 xv[LNB_RPW][NV], dv[LNB_RPW][NV], od[LNB_RPW][NV];
-    float mu[LNB_RPW], rs[LNB_RPW];
-#pragma unroll
-    for (int j = 0; j < LNB_RPW; ++j) {
-        const int r = ra + j;
-        mu[j] = r < M ? mean[r] : 0.f; rs[j] = r < M ? rstd[r] : 0.f;
+    const int row0 = blockIdx.x * iters * 4 + wv;
+
+    auto load_row = [&](int r, RX (&xa)[NV], RY (&da)[NV], RD (&oa)[NV], float& mu, float& rs) {
+        const bool rok = r < M;
+        mu = rok ? mean[r] : 0.f; rs = rok ? rstd[r] : 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * 64 + lane) * 4;
-            const bool ok = r < M && c < H;
-            xv[j][k] = ok ? *(const float4*)(x + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (sizeof(DY) == 4) {
-                dv[j][k] = ok ? *(const float4*)((const float*)dy + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                bf16x4 t = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                if (ok) t = *(const bf16x4*)((const bf16_t*)dy + (long long)r * H + c);
-                dv[j][k] = make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3]));
-            }
-            od[j][k] = (ok && accumulate) ? *(const float4*)(dx + (long long)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = rok && (FULL || c < H);
+            const long long o = (long long)r * H + c;
+            xa[k] = ldraw(x + o, ok);
+            da[k] = ldraw(dy + o, ok);
+            oa[k] = ldraw(dx_in + o, ok && dx_in != nullptr);
         }
-    }
-#pragma unroll
-    for (int j = 0; j < LNB_RPW; ++j) {
-        const int r = ra + j;
+    };
+    auto compute_row = [&](int r, const RX (&xa)[NV], const RY (&da)[NV], const RD (&oa)[NV], float mu, float rs) {
+        if (r >= M) return;   // (wave-uniform)
         float4 xh[NV], dh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * 64 + lane) * 4;
-            const float4 ww = (c < H) ? *(const float4*)(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            xh[k] = make_float4((xv[j][k].x - mu[j]) * rs[j], (xv[j][k].y - mu[j]) * rs[j], (xv[j][k].z - mu[j]) * rs[j],
-                                (xv[j][k].w - mu[j]) * rs[j]);
-            dh[k] = make_float4(dv[j][k].x * ww.x, dv[j][k].y * ww.y, dv[j][k].z * ww.z, dv[j][k].w * ww.w);
-            if (c < H && r < M) {
-                s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
-                s2 += dh[k].x * xh[k].x + dh[k].y * xh[k].y + dh[k].z * xh[k].z + dh[k].w * xh[k].w;
-                gw[k].x += dv[j][k].x * xh[k].x; gw[k].y += dv[j][k].y * xh[k].y; gw[k].z += dv[j][k].z * xh[k].z; gw[k].w += dv[j][k].w * xh[k].w;
-                gb[k].x += dv[j][k].x; gb[k].y += dv[j][k].y; gb[k].z += dv[j][k].z; gb[k].w += dv[j][k].w;
-            }
+            const float4 ww = (FULL || c < H) ? *(const float4*)(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 xv = widen4(xa[k]), dv = widen4(da[k]);   // (columns past H: dv = 0, so nothing below accumulates there)
+            xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            dh[k] = make_float4(dv.x * ww.x, dv.y * ww.y, dv.z * ww.z, dv.w * ww.w);
+            s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
+            s2 += dh[k].x * xh[k].x + dh[k].y * xh[k].y + dh[k].z * xh[k].z + dh[k].w * xh[k].w;
+            gw[k].x += dv.x * xh[k].x; gw[k].y += dv.y * xh[k].y; gw[k].z += dv.z * xh[k].z; gw[k].w += dv.w * xh[k].w;
+            gb[k].x += dv.x; gb[k].y += dv.y; gb[k].z += dv.z; gb[k].w += dv.w;
         }
         s1 = wave_sum(s1) * invH;
         s2 = wave_sum(s2) * invH;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = (k * 64 + lane) * 4;
-            if (c < H && r < M) {
-                const float4 o = make_float4(od[j][k].x + rs[j] * (dh[k].x - s1 - xh[k].x * s2), od[j][k].y + rs[j] * (dh[k].y - s1 - xh[k].y * s2),
-                                             od[j][k].z + rs[j] * (dh[k].z - s1 - xh[k].z * s2), od[j][k].w + rs[j] * (dh[k].w - s1 - xh[k].w * s2));
-                *(float4*)(dx + (long long)r * H + c) = o;
-                if (cz.out) {  // fused "dropcast" of the updated gradient stream for the next GEMMs (+ bias-grad sums)
+            if (FULL || c < H) {
+                const float4 od = widen4(oa[k]);
+                const float4 o = make_float4(od.x + rs * (dh[k].x - s1 - xh[k].x * s2), od.y + rs * (dh[k].y - s1 - xh[k].y * s2),
+                                             od.z + rs * (dh[k].z - s1 - xh[k].z * s2), od.w + rs * (dh[k].w - s1 - xh[k].w * s2));
+                st4f(dx_out + (long long)r * H + c, o);
+                if (want_cast) {  // fused "dropcast" of the updated gradient stream for the next GEMMs (+ bias-grad sums)
                     const long long i = (long long)r * H + c;   // dropout stream index: the unpadded position
                     float v[4] = {o.x, o.y, o.z, o.w};
                     if (cz.thr) drop4(cz.key, cz.thr, (unsigned)i, cz.scale, v);
-                    // optional row remap: groups of rpg rows land gpitch rows apart, goff rows in (zero-padded sample blocks)
-                    const long long io = cz.rpg > 0 ? ((long long)(r / cz.rpg) * cz.gpitch + cz.goff + r % cz.rpg) * H + c : i;
-                    if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + io) = ov; }
-                    else *(float4*)((float*)cz.out + io) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (cz.out) {
+                        // optional row remap: groups of rpg rows land gpitch rows apart, goff rows in (zero-padded sample blocks)
+                        const long long io = cz.rpg > 0 ? ((long long)(r / cz.rpg) * cz.gpitch + cz.goff + r % cz.rpg) * H + c : i;
+                        if (cz.bf16) { bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16_t*)cz.out + io) = ov; }
+                        else *(float4*)((float*)cz.out + io) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                     if (cz.nskip == 0 || (r % cz.rpg) >= cz.nskip) {   // (prefix-token rows do not feed the consumer's bias gradient)
                         gc[k].x += v[0]; gc[k].y += v[1]; gc[k].z += v[2]; gc[k].w += v[3];
                     }
                 }
             }
         }
+    };
+
+    {
+        RX xa[NV], xb[NV]; RY da[NV], db2[NV]; RD oa[NV], ob[NV];
+        float mua, rsa, mub, rsb;
+        load_row(row0, xa, da, oa, mua, rsa);
+#pragma unroll 1
+        for (int it = 0; it < iters; it += 2) {
+            const int r = row0 + it * 4;
+            const bool more = it + 1 < iters;
+            if (more) load_row(r + 4, xb, db2, ob, mub, rsb);
+            compute_row(r, xa, da, oa, mua, rsa);
+            if (more) {
+                if (it + 2 < iters) load_row(r + 8, xa, da, oa, mua, rsa);
+                compute_row(r + 4, xb, db2, ob, mub, rsb);
+            }
+        }
     }
-  }
     // cross-wave reduce through LDS, then thread t owns columns t, t+256, ...: one CONTIGUOUS 256-B
     // atomic wave-instruction per 64 columns (float atomics run at full rate only in that shape)
     if (dbg_notail) return;   // (measurement builds only: what the tail costs; wrong column sums)
@@ -384,29 +449,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
     }
 }
 
-int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz, int dy_bf16) {
+template <typename DYT, typename TX, typename TD>
+static void ln_bwd_dispatch(int nv, dim3 g, hipStream_t s, const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                            const void* dx_in, void* dx_out, float* dw, float* db, int M, int H, RepCfg rc, LnCast cz, int iters, int notail) {
+#define LNB(NVV)                                                                                                                        \
+    do {                                                                                                                                \
+        if (H == NVV * 256)                                                                                                             \
+            hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT, TX, TD, true>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, \
+                               (const TX*)x, w, mean, rstd, (const TD*)dx_in, (TD*)dx_out, dw, db, M, H, rc, cz, iters, notail);        \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT, TX, TD, false>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, \
+                               (const TX*)x, w, mean, rstd, (const TD*)dx_in, (TD*)dx_out, dw, db, M, H, rc, cz, iters, notail);        \
+    } while (0)
+    if (nv <= 1) LNB(1);
+    else if (nv <= 4) LNB(4);
+    else LNB(8);
+#undef LNB
+}
+
+int layernorm_bwd_launch(const void* dy, int dy_bf16, const void* x, const float* w, const float* mean, const float* rstd, LnStreams st,
+                         float* dw, float* db, int M, int H, hipStream_t s, RepCfg rc, LnCast cz) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 2048, NBCI_ESHAPE, "layernorm backward: hidden must be a multiple of 4 and <= 2048");
-    ProfScope ps("ln_bwd_kernel", 0.0, (double)M * H * ((dy_bf16 ? 2 : 4) + 4 + 4 + (accumulate_dx ? 4 : 0) + (cz.out ? (cz.bf16 ? 2 : 4) : 0)), s);
+    NBCI_REQUIRE(st.dx_out, NBCI_EINVAL, "layernorm backward: null dx");
+    NBCI_REQUIRE((st.x_bf16 != 0) == (st.dx_bf16 != 0), NBCI_EINVAL, "layernorm backward: a bf16 residual stream goes with a bf16 gradient stream");
+    const double xs = st.x_bf16 ? 2 : 4, ds = st.dx_bf16 ? 2 : 4;
+    ProfScope ps("ln_bwd_kernel", 0.0, (double)M * H * ((dy_bf16 ? 2 : 4) + xs + ds + (st.dx_in ? ds : 0) + (cz.out ? (cz.bf16 ? 2 : 4) : 0)), s);
     const int nv = (H + 255) / 256;
     static const int notail = measure_env("NBCI_LNB_NOTAIL", 0);
     static const int force_it = measure_env("NBCI_LNB_ITERS", 0);
-    const int iters = force_it > 0 ? force_it : lnb_iters(M), rows = 4 * LNB_RPW * iters;
+    const int iters = force_it > 0 ? force_it : lnb_iters(M), rows = 4 * iters;
     dim3 g((M + rows - 1) / rows);
-#define LNB(NVV, DYT)                                                                                                       \
-    hipLaunchKernelGGL((ln_bwd_kernel<NVV, DYT>), g, dim3(256), 4 * 3 * NVV * 256 * sizeof(float), s, (const DYT*)dy, x, w, mean, \
-                       rstd, dx, dw, db, M, H, accumulate_dx, rc, cz, iters, notail)
-    if (dy_bf16) {
-        if (nv <= 1) LNB(1, bf16_t);
-        else if (nv <= 4) LNB(4, bf16_t);
-        else LNB(8, bf16_t);
+    if (st.x_bf16) {
+        if (dy_bf16) ln_bwd_dispatch<bf16_t, bf16_t, bf16_t>(nv, g, s, dy, x, w, mean, rstd, st.dx_in, st.dx_out, dw, db, M, H, rc, cz, iters, notail);
+        else ln_bwd_dispatch<float, bf16_t, bf16_t>(nv, g, s, dy, x, w, mean, rstd, st.dx_in, st.dx_out, dw, db, M, H, rc, cz, iters, notail);
     } else {
-        if (nv <= 1) LNB(1, float);
-        else if (nv <= 4) LNB(4, float);
-        else LNB(8, float);
+        if (dy_bf16) ln_bwd_dispatch<bf16_t, float, float>(nv, g, s, dy, x, w, mean, rstd, st.dx_in, st.dx_out, dw, db, M, H, rc, cz, iters, notail);
+        else ln_bwd_dispatch<float, float, float>(nv, g, s, dy, x, w, mean, rstd, st.dx_in, st.dx_out, dw, db, M, H, rc, cz, iters, notail);
     }
-#undef LNB
     return check_launch("layernorm_bwd");
+}
+int layernorm_bwd_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                         float* dx, float* dw, float* db, int M, int H, int accumulate_dx, hipStream_t s, RepCfg rc, LnCast cz, int dy_bf16) {
+    return layernorm_bwd_launch(dy, dy_bf16, x, w, mean, rstd, LnStreams{0, accumulate_dx ? dx : nullptr, dx, 0}, dw, db, M, H, s, rc, cz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,7 +783,8 @@ int col2im_actgrad_launch(const void* dwin, const void* y, void* dpre, int dtype
 // One thread per (token position j, column) walks the batch: with the usual arange timestamps every sample hits the SAME table
 // row at position j, so the run is summed in a register and leaves as ONE atomic (f32 atomics run at ~1.3 TB/s chip-wide: one per
 // element was 30 us of a 32 us kernel); a differing timestamp just flushes the run.
-__global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tts,
+template <typename T>   // T: the gradient stream's storage type (f32, or bf16)
+__global__ __launch_bounds__(256) void posgrad_kernel(const T* __restrict__ dx, const int64_t* __restrict__ tts,
                                                       float* __restrict__ dpos, int B, int H, unsigned thr, float dscale,
                                                       uint32_t key, int Tp, int npre) {
     const int c = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
@@ -714,7 +799,7 @@ __global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ 
         for (int k = 0; k < 8; ++k) {
             const int b = b0 + k < bend ? b0 + k : bend - 1;
             const long long o = ((long long)b * (Tp + npre) + npre + j) * H + c;
-            v[k] = dx[o];
+            v[k] = ldf<T>(dx, o);
             if (thr) v[k] = drop_keep(key, thr, (unsigned)o) ? v[k] * dscale : 0.f;
             t[k] = tts[(long long)b * Tp + j];
         }
@@ -731,15 +816,15 @@ __global__ __launch_bounds__(256) void posgrad_kernel(const float* __restrict__ 
     if (acc != 0.f) atomicAdd(dpos + cur * H + c, acc);
 }
 
-int posgrad_launch(const float* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
-                   uint32_t site, hipStream_t s, int Tp, int npre) {
+int posgrad_launch(const void* dx, const int64_t* tts, float* dpos, int M, int H, float drop_p, uint32_t seed,
+                   uint32_t site, hipStream_t s, int Tp, int npre, int dx_dtype) {
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (Tp <= 0) Tp = M;   // (callers without a batch structure: one "sample" of M positions)
     NBCI_REQUIRE(M % Tp == 0, NBCI_ESHAPE, "posgrad: rows must be a whole number of samples");
     const int Bn = M / Tp, zs = Bn >= 32 ? 4 : (Bn >= 16 ? 2 : 1);   // batch slices: enough loads in flight, still 16 x fewer atomics at B = 64
-    hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)Tp, (unsigned)zs), dim3(256), 0, s, dx, tts, dpos, Bn, H, thr,
-                       dscale, drop_key(seed, site), Tp, npre);
+    DISPATCH_DTYPE(dx_dtype, T, hipLaunchKernelGGL((posgrad_kernel<T>), dim3((unsigned)((H + 255) / 256), (unsigned)Tp, (unsigned)zs), dim3(256), 0, s,
+                                                   (const T*)dx, tts, dpos, Bn, H, thr, dscale, drop_key(seed, site), Tp, npre));
     return check_launch("posgrad");
 }
 

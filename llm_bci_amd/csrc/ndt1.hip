@@ -170,6 +170,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     const int Tp = 1 + (T - c.stack_size) / c.stack_stride;
     NBCI_REQUIRE(Tp <= c.max_F && Tp <= 1024, NBCI_ESHAPE, "ndt1: more tokens than max_F / 1024");
     const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
+    const size_t rs = c.residual_dtype == NBCI_BF16 ? 2 : 4;   // the residual stream x and its gradient stream dx
     const int npre = (c.day_token_days > 0 ? 1 : 0) + (c.block_token_blocks > 0 ? 1 : 0), Tt = Tp + npre;
     const size_t M = (size_t)B * Tt, Mk = (size_t)B * Tp, H = c.hidden, I = c.inter, D = c.input_dim;
     w.Tp = Tp; w.M = (int)M; w.npre = npre; w.Tt = Tt; w.Mk = (int)Mk;
@@ -192,7 +193,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.L.resize(c.n_layers);
     const size_t nP = (size_t)B * c.n_heads * Tt * w.ldP;
     for (auto& l : w.L) {
-        l.x_in = bump(cur, M * H * 4);
+        l.x_in = bump(cur, M * H * rs);
         l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
         l.h1 = bump(cur, M * H * es);
         l.qkv = bump(cur, M * 3 * H * es);
@@ -200,13 +201,13 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * H * es);
         l.lse = bump(cur, (size_t)B * c.n_heads * Tt * 4);
-        l.x_mid = bump(cur, M * H * 4);
+        l.x_mid = bump(cur, M * H * rs);
         l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
         l.h2 = bump(cur, M * H * es);
         l.u = bump(cur, M * I * es);
         l.g = bump(cur, M * I * es);
     }
-    w.x_last = bump(cur, M * H * 4);
+    w.x_last = bump(cur, M * H * rs);
     w.mean_o = bump(cur, M * 4); w.rstd_o = bump(cur, M * 4);
     w.xo = bump(cur, M * H * es);
     if (c.factors_size > 0) {
@@ -219,7 +220,7 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.dlogits = bump(cur, M * w.vpad * es);
     w.argmax = bump(cur, M * 4);
     w.scores = bump(cur, (size_t)B * c.n_heads * Tt * w.ldS * 4);
-    w.dx = bump(cur, M * H * 4);
+    w.dx = bump(cur, M * H * rs);
     w.dtmp = bump(cur, M * H * 4);
     for (int p2 = 0; p2 < 2; ++p2) {
         w.dA[p2] = bump(cur, M * H * es);
@@ -280,7 +281,8 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     // Tk spike tokens per sample; Tp = npre + Tk tokens in the transformer once the learned prefix tokens (day / block) are in front
     const int Tk = w.Tp, Tp = w.Tt, npre = w.npre, M = w.M, Mk = w.Mk, H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh;
     const int dt = c.dtype;
-    const size_t es = x.es;
+    const int xdt = c.residual_dtype;   // storage of the residual stream between kernels (every kernel widens it and computes in f32)
+    const size_t es = x.es, rs = xdt == NBCI_BF16 ? 2 : 4;
     const bool train = io->train != 0;
     const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
     char* ws = x.ws;
@@ -317,13 +319,13 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     }
     // 2. Unfold + stack_projection as a GEMM over the overlapping-window view, + pos-emb gather,
     //    + embed dropout (ndt1.py:138-140,180,188-189,203)
-    float* x_cur = (float*)(ws + (c.n_layers ? w.L[0].x_in : w.x_last));
+    void* x_cur = ws + (c.n_layers ? w.L[0].x_in : w.x_last);
     {
         const int KS = c.stack_size * D;
         // with prefix tokens the spike tokens go to a side buffer first: the prefix rows are put in front and the embedder dropout is
         // drawn over the whole (B, npre + T', H) block afterwards
         nbci_gemm_desc d = gd(Mk, H, KS, dt, op(ws + w.y, es, 0, (int64_t)c.stack_stride * D, 1, Tk, (int64_t)T * D),
-                              op(x.W(p.stkw), es, 0, KS, 1), npre ? (float*)(ws + w.xtok) : x_cur, H, NBCI_F32);
+                              op(x.W(p.stkw), es, 0, KS, 1), npre ? (void*)(ws + w.xtok) : x_cur, H, npre ? NBCI_F32 : xdt);
         d.bias = params + p.stkb;
         if (c.pos) {
             d.residual = params + p.pos; d.ldr = H; d.residual_rows = (const int64_t*)(ws + w.tts); d.residual_first = 1;
@@ -334,19 +336,19 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             const float* tab0 = params + (c.day_token_days > 0 ? p.dayemb : p.blkemb);
             const int64_t* idx0 = c.day_token_days > 0 ? io->day_idx : io->block_idx;
             TRY(prefix_assemble_launch((const float*)(ws + w.xtok), tab0, idx0, npre == 2 ? params + p.blkemb : nullptr,
-                                       npre == 2 ? io->block_idx : nullptr, x_cur, B, Tk, npre, H, p_emb, io->seed, 3, s));
+                                       npre == 2 ? io->block_idx : nullptr, x_cur, B, Tk, npre, H, p_emb, io->seed, 3, s, xdt));
         }
     }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < c.n_layers; ++l) {
         const LayerWS& lw = w.L[l];
         const LayerOff& lo = p.L[l];
-        float* x_in = (float*)(ws + lw.x_in);
-        float* x_mid = (float*)(ws + lw.x_mid);
-        float* x_out = (float*)(ws + (l + 1 < c.n_layers ? w.L[l + 1].x_in : w.x_last));
+        void* x_in = ws + lw.x_in;
+        void* x_mid = ws + lw.x_mid;
+        void* x_out = ws + (l + 1 < c.n_layers ? w.L[l + 1].x_in : w.x_last);
         // ---- attention block (ndt1.py:266-292,325)
-        TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
-             layernorm_fwd_launch(x_in, params + lo.ln1w, params + lo.ln1b, ws + lw.h1, dt, (float*)(ws + lw.mean1),
+        TRYP("ln_fwd_kernel", 0, (double)M * H * (rs + es), s,
+             layernorm_fwd_launch(x_in, xdt, params + lo.ln1w, params + lo.ln1b, ws + lw.h1, dt, (float*)(ws + lw.mean1),
                                   (float*)(ws + lw.rstd1), M, H, s));
         {
             nbci_gemm_desc d = gd(M, 3 * H, H, dt, op(ws + lw.h1, es, 0, H, 1), op(x.W(lo.qw), es, 0, H, 1), ws + lw.qkv,
@@ -385,13 +387,13 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             }
         }
         {   // x_mid = x_in + out_proj(a)
-            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), x_mid, H, NBCI_F32);
-            d.bias = params + lo.ob; d.residual = x_in; d.ldr = H;
+            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), x_mid, H, xdt);
+            d.bias = params + lo.ob; d.residual = x_in; d.ldr = H; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
         // ---- MLP block (ndt1.py:224-227,328)
-        TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
-             layernorm_fwd_launch(x_mid, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
+        TRYP("ln_fwd_kernel", 0, (double)M * H * (rs + es), s,
+             layernorm_fwd_launch(x_mid, xdt, params + lo.ln2w, params + lo.ln2b, ws + lw.h2, dt, (float*)(ws + lw.mean2),
                                   (float*)(ws + lw.rstd2), M, H, s));
         {
             nbci_gemm_desc d = gd(M, I, H, dt, op(ws + lw.h2, es, 0, H, 1), op(x.W(lo.upw), es, 0, H, 1), ws + lw.g, I, dt);
@@ -399,15 +401,15 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
             TRY(gemm_launch_timed(d, s));
         }
         {
-            nbci_gemm_desc d = gd(M, H, I, dt, op(ws + lw.g, es, 0, I, 1), op(x.W(lo.dnw), es, 0, I, 1), x_out, H, NBCI_F32);
+            nbci_gemm_desc d = gd(M, H, I, dt, op(ws + lw.g, es, 0, I, 1), op(x.W(lo.dnw), es, 0, I, 1), x_out, H, xdt);
             d.bias = params + lo.dnb; d.drop_p = p_lay; d.seed = io->seed; d.site = 18 + 4 * l;
-            d.residual = x_mid; d.ldr = H;
+            d.residual = x_mid; d.ldr = H; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
     }
     // ---- out_norm + decoder + log-softmax (+ CTC) (ndt1.py:442,494-499,545,581)
-    TRYP("ln_fwd_kernel", 0, (double)M * H * (4 + es), s,
-         layernorm_fwd_launch((const float*)(ws + w.x_last), params + p.onw, params + p.onb, ws + w.xo, dt,
+    TRYP("ln_fwd_kernel", 0, (double)M * H * (rs + es), s,
+         layernorm_fwd_launch(ws + w.x_last, xdt, params + p.onw, params + p.onb, ws + w.xo, dt,
                               (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
     const int FS = c.factors_size;
     const void* enc_out = ws + w.xo;   // what the decoder (and a coupler) reads: out_norm(x), or its factors projection
@@ -464,11 +466,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     const int Tk = w.Tp, Tp = w.Tt, npre = w.npre, M = w.M, Mk = w.Mk;   // (see ndt1_forward)
     const int H = c.hidden, I = c.inter, D = c.input_dim, nh = c.n_heads, hd = H / nh, V = c.vocab;
     const int dt = c.dtype;
-    const size_t es = x.es;
+    const int xdt = c.residual_dtype;   // storage of the residual stream AND of its gradient stream dx (bf16: rounded once per store, summed in f32)
+    const bool rb = xdt == NBCI_BF16;
+    const size_t es = x.es, rs = rb ? 2 : 4;
     const bool train = io->train != 0;
     const float p_emb = train ? c.embed_dropout : 0.f, p_lay = train ? c.dropout : 0.f;
     char* ws = x.ws;
-    float* dx = (float*)(ws + w.dx);
+    float* dx = (float*)(ws + w.dx);   // (bf16 elements when rb)
     float* dtmp = (float*)(ws + w.dtmp);
     const float scale = 1.0f / sqrtf((float)hd);
     float* rep = (float*)(ws + w.rep);
@@ -561,10 +565,9 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 }
             }
             if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
-            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
-                 layernorm_bwd_launch(d_xo, (const float*)(ws + w.x_last), params + p.onw, (const float*)(ws + w.mean_o),
-                                     (const float*)(ws + w.rstd_o), dx, RG(p.onw), RG(p.onb), M, H, 0, s, rc, cast_for(c.n_layers - 1),
-                                     d_xo_lp));
+            TRYP("ln_bwd_kernel", 0, (double)M * H * ((d_xo_lp ? 2 : 4) + 2 * rs + es), s,   // dy, x, dx out, cast out
+                 layernorm_bwd_launch(d_xo, d_xo_lp, ws + w.x_last, params + p.onw, (const float*)(ws + w.mean_o), (const float*)(ws + w.rstd_o),
+                                     LnStreams{rb, nullptr, dx, rb}, RG(p.onw), RG(p.onb), M, H, s, rc, cast_for(c.n_layers - 1)));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const LayerWS& lw = w.L[l];
@@ -592,12 +595,14 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(M, H, I, dt, op(ws + o_dB, es, 0, I, 1), op(x.W(lo.upw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
-                 layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), params + lo.ln2w, (const float*)(ws + lw.mean2),
-                                     (const float*)(ws + lw.rstd2), dx, RG(lo.ln2w), RG(lo.ln2b), M, H, 1, s, rc,
+            // bf16 gradient stream: the updated stream IS the operand the out_proj gradients read -> it is written to dA2 (this layer's
+            // parity) instead of a separate cast copy, and the attention block's LayerNorm backward below reads it from there
+            TRYP("ln_bwd_kernel", 0, (double)M * H * (es + 3 * rs + (rb ? 0 : es)), s,   // dy (operand dtype), x, dx in / out, cast out
+                 layernorm_bwd_launch(dtmp, dt == NBCI_BF16 ? 1 : 0, ws + lw.x_mid, params + lo.ln2w, (const float*)(ws + lw.mean2),
+                                     (const float*)(ws + lw.rstd2), LnStreams{rb, dx, rb ? (void*)(ws + o_dA2) : (void*)dx, rb}, RG(lo.ln2w),
+                                     RG(lo.ln2b), M, H, s, rc,
                                      dt == NBCI_F32 ? LnCast{nullptr, 0, 0u, 1.f, 0u, nullptr}
-                                                    : LnCast{ws + o_dA2, 1, 0u, 1.f, 0u, RG(lo.ob)},
-                                     dt == NBCI_BF16 ? 1 : 0));
+                                                    : LnCast{rb ? nullptr : ws + o_dA2, 1, 0u, 1.f, 0u, RG(lo.ob)}));
             // ---- attention backward: x_mid = x_in + out_proj(dropout(merge(Pd v)))
             const void* dxc;
             if (dt == NBCI_F32) {
@@ -672,10 +677,10 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             }
             if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
             if (two) NBCI_CHECK_HIP(hipStreamWaitEvent(s, p.ev_wg[(l + 1) & 1], 0));   // the cast below rewrites dA[(l - 1) & 1], which layer l + 1's weight gradients read
-            TRYP("ln_bwd_kernel", 0, (double)M * H * (4 + 4 + 4 + 2 * es), s,   // dy (operand dtype), x, dx in / out, cast out
-                 layernorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), params + lo.ln1w, (const float*)(ws + lw.mean1),
-                                     (const float*)(ws + lw.rstd1), dx, RG(lo.ln1w), RG(lo.ln1b), M, H, 1, s, rc, cast_for(l - 1),
-                                     dt == NBCI_BF16 ? 1 : 0));
+            TRYP("ln_bwd_kernel", 0, (double)M * H * (es + 3 * rs + es), s,   // dy (operand dtype), x, dx in / out, cast out
+                 layernorm_bwd_launch(dtmp, dt == NBCI_BF16 ? 1 : 0, ws + lw.x_in, params + lo.ln1w, (const float*)(ws + lw.mean1),
+                                     (const float*)(ws + lw.rstd1), LnStreams{rb, rb ? (const void*)(ws + o_dA2) : (const void*)dx, dx, rb},
+                                     RG(lo.ln1w), RG(lo.ln1b), M, H, s, rc, cast_for(l - 1)));
         } else {
             // ---- embedder backward (ndt1.py:160-203)
             const int KS = c.stack_size * D;
@@ -692,11 +697,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const int part = io->embed_part;
             NBCI_REQUIRE(part >= 0 && part <= 2, NBCI_EINVAL, "ndt1: embed_part must be 0, 1 or 2");
             if (part != 2) {
-            if (c.pos) TRYP("posgrad_kernel", 0, (double)Mk * H * 4, s, posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre));
+            if (c.pos) TRYP("posgrad_kernel", 0, (double)Mk * H * rs, s, posgrad_launch(dx, (const int64_t*)(ws + w.tts), grads + p.pos, Mk, H, p_emb, io->seed, 3, s, Tk, npre, xdt));
             if (npre) {   // the prefix tokens' tables: [day, block] order as assembled in the forward
                 int k = 0;
-                if (c.day_token_days > 0) TRY(prefix_grad_launch(dx, io->day_idx, grads + p.dayemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
-                if (c.block_token_blocks > 0) TRY(prefix_grad_launch(dx, io->block_idx, grads + p.blkemb, B, Tp, k++, H, p_emb, io->seed, 3, s));
+                if (c.day_token_days > 0) TRY(prefix_grad_launch(dx, io->day_idx, grads + p.dayemb, B, Tp, k++, H, p_emb, io->seed, 3, s, xdt));
+                if (c.block_token_blocks > 0) TRY(prefix_grad_launch(dx, io->block_idx, grads + p.blkemb, B, Tp, k++, H, p_emb, io->seed, 3, s, xdt));
             }
             }
             // the spike-token rows of dx0: all of it, or (prefix tokens) a view that skips the first npre rows of every sample block
@@ -782,6 +787,8 @@ int nbci_ndt1_plan_create(const nbci_ndt1_config* cfg, nbci_ndt1_plan* out) {
     NBCI_REQUIRE(c.n_channels > 0 && c.stack_size > 0 && c.stack_stride > 0 && c.vocab > 0 && c.n_layers >= 0, NBCI_ESHAPE,
                  "bad NDT1 shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.residual_dtype == NBCI_F32 || (c.residual_dtype == NBCI_BF16 && c.dtype == NBCI_BF16), NBCI_EINVAL,
+                 "residual_dtype must be f32, or bf16 together with dtype bf16");
     NBCI_REQUIRE(c.adapt_days >= 0 && c.adapt_days <= 4096, NBCI_EINVAL, "adapt_days out of range");
     NBCI_REQUIRE(c.day_token_days >= 0 && c.block_token_blocks >= 0, NBCI_EINVAL, "token table sizes must be >= 0");
     NBCI_REQUIRE(!(c.use_rope && (c.day_token_days > 0 || c.block_token_blocks > 0)), NBCI_EINVAL,

@@ -64,7 +64,8 @@ class _NDT1Function(torch.autograd.Function):
 
 class NDT1(nn.Module):
     """See module docstring. kwargs: method_name ("ctc"), vocab_size, blank_id, zero_infinity
-    (reference ndt1.py:465,489,517); extra: compute_dtype ("bf16" | "fp32", default bf16)."""
+    (reference ndt1.py:465,489,517); extra: compute_dtype ("bf16" | "fp32", default bf16), residual_dtype ("bf16" | "fp32": storage
+    of the residual stream and its gradient stream between kernels; default = compute_dtype, bf16 with compute_dtype bf16 only)."""
 
     _supports_aux_stream = True   # _run_backward(aux=...): weight gradients / fold on a second stream (NativeTrainer, small batches)
 
@@ -115,6 +116,14 @@ class NDT1(nn.Module):
         c.pos = 1 if emb.pos else 0
         c.blank_id, c.zero_infinity = kwargs["blank_id"], 1 if kwargs["zero_infinity"] else 0
         c.dtype = self.compute_dtype
+        # storage of the residual stream / its gradient stream between kernels: "bf16" (the default of the bf16 path: every kernel still
+        # adds / normalises in f32 and rounds once at its store) or "fp32" (what bf16 autocast keeps in f32 in the reference; always
+        # for compute_dtype fp32)
+        res_name = kwargs.get("residual_dtype", None) or ("bf16" if self.compute_dtype == NBCI_BF16 else "fp32")
+        self.residual_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[res_name]
+        if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
+            raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16'")
+        c.residual_dtype = self.residual_dtype
         # NeuralFactorsProjection (ndt1.py:348-373): encoder output = act(Linear(hidden -> size)) when active
         c.factors_size = int(fac.size) if fac.active else 0
         c.factors_act = ACT[fac.act] if fac.active else 0

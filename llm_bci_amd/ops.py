@@ -49,6 +49,7 @@ def gemm(M, N, K, A, B, Cout, ldc, *, in_dtype, c_dtype, C2=None, czs1=0, czs2=0
     d.act, d.drop_p, d.seed, d.site = act, drop_p, seed, site
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldr = ldr
+    d.residual_dtype = 1 if (residual is not None and residual.dtype == torch.bfloat16) else 0   # NBCI_BF16 / NBCI_F32
     d.c2_grad = c2_grad
     if gate is not None:    # result *= act'(gate); gate_act < 0: `gate` already holds act' (the forward's C2 with c2_grad=1)
         d.gate, d.ldg, d.gate_act = gate.data_ptr(), ldg, gate_act

@@ -331,3 +331,15 @@ def test_patchtst_fp8_rejects_widths_the_fp8_gemm_cannot_take():
     with pytest.raises(Exception, match="fp8 needs d_model"):
         PatchTSTForSpikingActivity({"encoder": {"d_model": 640, "num_attention_heads": 8}}, method_name="ctc", vocab_size=11, blank_id=0,
                                    zero_infinity=True, compute_dtype="fp8")
+
+
+def test_ndt1_residual_dtype_needs_the_bf16_path():
+    """NDT1(residual_dtype="bf16") stores the residual / gradient streams in bf16 between kernels: only with compute_dtype bf16
+    (the fp32 parity path keeps everything in f32); the choice reaches the plan config."""
+    from llm_bci_amd.ndt1 import NDT1
+    kw = dict(method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    with pytest.raises(Exception, match="residual_dtype 'bf16' needs compute_dtype 'bf16'"):
+        NDT1({}, compute_dtype="fp32", residual_dtype="bf16", **kw)
+    assert NDT1({}, compute_dtype="bf16", **kw)._ccfg.residual_dtype == 1            # default of the bf16 path
+    assert NDT1({}, compute_dtype="bf16", residual_dtype="fp32", **kw)._ccfg.residual_dtype == 0
+    assert NDT1({}, compute_dtype="fp32", **kw)._ccfg.residual_dtype == 0

@@ -154,6 +154,57 @@ def test_layernorm_fwd_bwd(H):
     np.testing.assert_allclose(dbd.cpu().numpy(), db, atol=2e-4)
 
 
+def _bf(a):
+    """float64 value of the bf16 rounding of a (round to nearest even, as the kernels store)"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().double().numpy()
+
+
+@pytest.mark.parametrize("H,M,streams", [(1024, 77, "bf16"), (1024, 77, "f32"), (768, 41, "bf16"), (32, 9, "bf16"), (1024, 2300, "bf16")])
+def test_layernorm_general_forms_against_f64(H, M, streams):
+    """nbci_layernorm_fwd_ex / _bwd_ex (what the NDT1 step launches; residual_dtype f32 / bf16): x, dy, dx_in as STORED (bf16-rounded
+    where the stream is bf16) against float64 numpy. Every output is computed in f32 and rounded once, so the bound per element is
+    half a bf16 ulp of the exact value (2^-9 relative) for the bf16 outputs plus f32 accumulation noise; the dropout mask of the cast
+    copy is the oracle's keep_mask bit for bit; M = 2300 runs several rows per wave (the prefetch loop) and more than one block."""
+    l, check = _l()
+    g0 = np.random.default_rng(5)
+    lp = streams == "bf16"
+    x = g0.standard_normal((M, H)) * 2 + 0.5
+    dy = g0.standard_normal((M, H)); dxi = g0.standard_normal((M, H))
+    w = g0.standard_normal(H).astype(np.float32); b = g0.standard_normal(H).astype(np.float32)
+    xs = _bf(x) if lp else x.astype(np.float32).astype(np.float64)
+    dys, dxs = _bf(dy), (_bf(dxi) if lp else dxi.astype(np.float32).astype(np.float64))
+    y, xhat, rstd = O.layer_norm(xs, w, b)
+    dx, dw, db = O.layer_norm_bwd(dys, xhat, rstd, w)
+    dx = dx + dxs
+    tdt = torch.bfloat16 if lp else torch.float32
+    xd, dyd, dxd = d(xs.astype(np.float32)).to(tdt), d(dys.astype(np.float32)).bfloat16(), d(dxs.astype(np.float32)).to(tdt)
+    wd, bd = d(w), d(b)
+    yd = torch.zeros(M, H, device=DEV, dtype=torch.bfloat16); mean = torch.zeros(M, device=DEV); rs = torch.zeros(M, device=DEV)
+    check(l.nbci_layernorm_fwd_ex(vp(xd), int(lp), vp(wd), vp(bd), vp(yd), 1, vp(mean), vp(rs), M, H, st()), "ln_fwd_ex")
+    torch.cuda.synchronize()
+    yy = yd.double().cpu().numpy()
+    assert np.all(np.abs(yy - y) <= 2.0 ** -8 * np.abs(y) + 1e-5)
+    np.testing.assert_allclose(rs.cpu().numpy(), rstd.reshape(-1), rtol=2e-5)
+    p, seed, site = 0.4, 11, 18
+    keep = R.keep_mask(seed, site, M * H, p).reshape(M, H).astype(np.float64)   # multipliers: 1 / (1 - p) or 0
+    for dx_in in (dxd, None):
+        out = torch.zeros(M, H, device=DEV, dtype=tdt); cast = torch.zeros(M, H, device=DEV, dtype=torch.bfloat16)
+        dwd = torch.zeros(H, device=DEV); dbd = torch.zeros(H, device=DEV); cs = torch.zeros(H, device=DEV)
+        check(l.nbci_layernorm_bwd_ex(vp(dyd), 1, vp(xd), int(lp), vp(wd), vp(mean), vp(rs), vp(dx_in), vp(out), vp(dwd), vp(dbd), M, H,
+                                      vp(cast), 1, p, seed, site, vp(cs), st()), "ln_bwd_ex")
+        torch.cuda.synchronize()
+        ref = dx if dx_in is not None else dx - dxs
+        tol = (2.0 ** -8 * np.abs(ref) if lp else 0) + 2e-4   # (mean / rstd come from the f32 kernel: a few 1e-5 on values of order 1 - 10)
+        assert np.all(np.abs(out.double().cpu().numpy() - ref) <= tol)
+        masked = ref * keep
+        assert np.all(np.abs(cast.double().cpu().numpy() - masked) <= 2.0 ** -8 * np.abs(masked) + 4e-4)
+        assert np.array_equal(cast.cpu().float().numpy() != 0, (keep > 0) & (np.abs(out.double().cpu().numpy()) > 1e-30))
+        scale = np.sqrt(M)
+        np.testing.assert_allclose(dwd.cpu().numpy(), dw, atol=3e-4 * scale)
+        np.testing.assert_allclose(dbd.cpu().numpy(), db, atol=3e-4 * scale)
+        np.testing.assert_allclose(cs.cpu().numpy(), masked.sum(0), atol=3e-4 * scale)
+
+
 @pytest.mark.parametrize("Tp,ctx", [(143, (-2, -2)), (37, (3, 2)), (300, (0, -2)), (18, (-1, -1))])
 def test_softmax_fwd_bwd_mask_and_dropout(Tp, ctx):
     l, check = _l()

@@ -145,12 +145,15 @@ def test_host_fed_batches_equal_reference_collate_and_survive_buffer_recycling()
     assert n == 24 and pool.allocated <= 5 * 6          # buffers are recycled: a handful per key, not one per batch
 
 
-@pytest.mark.parametrize("size", ["small", "default"])
+@pytest.mark.parametrize("size", ["small", "default", "default_bf16_streams"])
 def test_side_stream_backward_gives_the_same_gradients_and_training(size):
     """nbci_ndt1_io.aux_stream: weight gradients + fold on a second stream, per-segment AdamW + zero_grad behind them. Same kernels,
     same operands: gradients equal the one-stream backward's up to the order of the f32 atomic sums, and so does training.
-    "small": split-K weight gradients (few output tiles); "default": configs/ndt1.yaml's widths, the grouped launch."""
+    "small": split-K weight gradients (few output tiles); "default": configs/ndt1.yaml's widths, the grouped launch;
+    "..._bf16_streams": NDT1(residual_dtype="bf16"), where the out_proj gradients read the gradient stream itself (double-buffered
+    by layer parity) instead of a cast copy."""
     from llm_bci_amd.trainer import NativeTrainer
+    streams = "bf16" if size.endswith("bf16_streams") else "fp32"
     if size == "small":
         over = {"encoder": {"embedder": {"n_channels": 16, "input_dim": 16, "max_F": 64, "stack": {"size": 4, "stride": 2}},
                             "transformer": {"n_layers": 3, "hidden_size": 128, "n_heads": 1, "inter_size": 128}}}
@@ -158,7 +161,7 @@ def test_side_stream_backward_gives_the_same_gradients_and_training(size):
     else:
         over = {"encoder": {"embedder": {"n_channels": 32}}}
         bd = _to_dev(_rand_batch(3, 200, 32, 6, 11, [200, 150, 97], [6, 4, 3]))
-    m = _model(over, 11, dtype="bf16").to(DEV)
+    m = _model(over, 11, dtype="bf16", streams=streams).to(DEV)
     m.train()
     g1 = torch.zeros(m._total, device=DEV); g2 = torch.zeros(m._total, device=DEV)
     m._run_forward(bd, want_grad=True, seed=5)
@@ -178,7 +181,7 @@ def test_side_stream_backward_gives_the_same_gradients_and_training(size):
     assert (g1 - g3).abs().max().item() <= 1e-5 * max(1.0, g1.abs().max().item())
 
     def run(side):
-        mm = _model(over, 11, dtype="bf16").to(DEV)
+        mm = _model(over, 11, dtype="bf16", streams=streams).to(DEV)
         tr = NativeTrainer(mm, total_steps=30, side_stream=side, gradient_accumulation_steps=2)
         for s in range(7):                      # micro-steps 1, 3, 5, 7 synchronise (trainer.py:335), the others accumulate
             tr.train_step(bd, seed=s)
