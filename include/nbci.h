@@ -58,7 +58,8 @@ const char* nbci_last_error(void);
  * Operand storage: a row-major matrix of "storage rows". kmajor=1: storage row = m (or n)
  * index, columns = k. kmajor=0: storage row = k index, columns = m (or n).
  * Storage row r starts at element offset
- *     rpb ? (r / rpb) * gstride + (r % rpb) * ld : r * ld
+ *     rpb > 0 ? (r / rpb) * gstride + (r % rpb) * ld : r * ld
+ * (rpb < 0: uniform rows that OVERLAP by design, ld smaller than a row's extent - the windows of a signal at a fixed hop)
  * so overlapping sliding windows (nn.Unfold, ndt1.py:138) are a view, never materialised.
  * Batch z (0 <= z < batch) adds (z / zdiv) * zs1 + (z % zdiv) * zs2.
  * Epilogue order: acc*alpha (+bias[n]) -> [store C2 = pre-activation] -> (+residual if

@@ -158,7 +158,8 @@ struct WS {
     size_t dx, dtmp, dA[2], dA2[2], dB[2], dB2, dqkv[2], dS, dwin, dpre, rep;   // [layer parity]: what a layer's weight gradients read (see ndt1_backward, aux stream)
     size_t xtok;                       // (prefix tokens) stack-projection output of the spike tokens before the prefix rows are put in front
     size_t dAp;                        // (phase-GEMM embedder backward) dx0 with every sample's tokens zero-padded: (B, P, H)
-    int phase_ok, Q, P, npad;          // Q = T / stride output groups, P = Q + size/stride - 1 padded rows, npad = size/stride - 1
+    int phase_ok, Q, P, npad;          // Q = T / stride output groups = rows per sample block of dAp (P = Q), npad = size/stride - 1 zero rows in front
+    size_t dAp_rows, y_slack;          // rows of dAp (npad + B * Q); bytes of zeroed slack behind y
     size_t bytes;
     int Tp, M, ldS, ldP, vpad;
     int npre, Tt, Mk;                  // learned prefix tokens per sequence (day / block), Tt = npre + Tp tokens in the transformer (M = B*Tt rows), Mk = B*Tp
@@ -178,8 +179,16 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     w.ldP = (Tt + 7) / 8 * 8;
     w.vpad = (c.vocab + 7) / 8 * 8;
     size_t cur = 0;
+    // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
+    w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
+                  (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0 && npre == 0) ? 1 : 0;
+    { static const bool off = measure_env("NBCI_PHASE_DGRAD", 1) == 0; if (off) w.phase_ok = 0; }
+    w.Q = T / c.stack_stride; w.npad = c.stack_size / c.stack_stride - 1; w.P = w.Q;
     w.xs = bump(cur, (size_t)B * T * c.n_channels * es);
-    w.y = bump(cur, (size_t)B * T * D * es);
+    // (phase layout: the stack-projection weight gradient reads window rows j = T' .. Q - 1 of every sample against ZERO rows of dx0; the
+    // last sample's run (size - stride) bins past the end of y: that slack is part of y and zeroed in the forward)
+    w.y_slack = w.phase_ok ? (size_t)(c.stack_size - c.stack_stride) * D * es : 0;
+    w.y = bump(cur, (size_t)B * T * D * es + w.y_slack);
     if (c.adapt_days > 0) {
         w.wsel = bump(cur, (size_t)B * D * c.n_channels * es);
         w.rsel = bump(cur, (size_t)B * T * 8);
@@ -230,12 +239,11 @@ static int carve(const Plan& p, int B, int T, int S, WS& w) {
     }
     w.dB2 = bump(cur, M * H * es);
     w.dS = bump(cur, nP * es);
-    // embedder backward without the (B,T',size*D) window-gradient tensor: possible when the windows tile the bins evenly
-    w.phase_ok = (c.dtype == NBCI_BF16 && c.stack_size % c.stack_stride == 0 && T % c.stack_stride == 0 && c.embed_act != NBCI_ACT_GELU &&
-                  (c.stack_size / c.stack_stride) * (int)H % 64 == 0 && D % 8 == 0 && npre == 0) ? 1 : 0;
-    { static const bool off = measure_env("NBCI_PHASE_DGRAD", 1) == 0; if (off) w.phase_ok = 0; }
-    w.Q = T / c.stack_stride; w.npad = c.stack_size / c.stack_stride - 1; w.P = w.Q + w.npad;
-    w.dAp = w.phase_ok ? bump(cur, (size_t)B * w.P * H * es) : 0;
+    // phase layout of dx0: npad zero rows, then per sample Q rows = its T' token rows + npad zero rows (Q - T' = npad when the windows tile
+    // the bins evenly). Every sample's tokens are preceded by npad zero rows (what the phase GEMM's windows reach back into) and ALL rows
+    // are one stride apart: the phase GEMM's A and both operands of the stack-projection weight gradient are plain (non-view) operands.
+    w.dAp_rows = (size_t)w.npad + (size_t)B * w.Q;
+    w.dAp = w.phase_ok ? bump(cur, w.dAp_rows * H * es) : 0;
     w.dwin = w.phase_ok ? 0 : bump(cur, M * (size_t)c.stack_size * D * es);
     w.dpre = bump(cur, (size_t)B * T * D * es);
     w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
@@ -298,6 +306,7 @@ int ndt1_forward(const Plan& p, const float* params, const void* params_lp, cons
     TRYP("smooth_noise_kernel", 0, (double)B * T * c.n_channels * (4 + es), s,
          smooth_noise_launch(io->spikes, ws + w.xs, dt, B, T, c.n_channels, p.d_taps, p.ntaps, noise ? c.white_noise_sd : 0.f,
                              noise ? c.constant_offset_sd : 0.f, io->seed, s));
+    if (w.y_slack) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.y + (size_t)B * T * D * es, 0, w.y_slack, s));   // (see carve)
     // 1. embed Linear + activation (ndt1.py:173-176)
     if (c.adapt_days > 0) {
         // day-specific layers: each sample's day weights gathered side by side -> ONE batched GEMM (batch = sample); the day's bias
@@ -564,7 +573,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                     TRY(gemm_launch_timed(d, s));
                 }
             }
-            if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
+            if (c.n_layers == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, w.dAp_rows * H * es, s));   // zero pad rows
             TRYP("ln_bwd_kernel", 0, (double)M * H * ((d_xo_lp ? 2 : 4) + 2 * rs + es), s,   // dy, x, dx out, cast out
                  layernorm_bwd_launch(d_xo, d_xo_lp, ws + w.x_last, params + p.onw, (const float*)(ws + w.mean_o), (const float*)(ws + w.rstd_o),
                                      LnStreams{rb, nullptr, dx, rb}, RG(p.onw), RG(p.onb), M, H, s, rc, cast_for(c.n_layers - 1)));
@@ -675,7 +684,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + o_dqkv, es, 0, 3 * H, 1), op(x.W(lo.qw), es, 0, H, 0), dtmp, H, dt);
                 TRY(gemm_launch_timed(d, s));
             }
-            if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, (size_t)B * w.P * H * es, s));   // zero pad rows
+            if (l == 0 && w.phase_ok) NBCI_CHECK_HIP(hipMemsetAsync(ws + w.dAp, 0, w.dAp_rows * H * es, s));   // zero pad rows
             if (two) NBCI_CHECK_HIP(hipStreamWaitEvent(s, p.ev_wg[(l + 1) & 1], 0));   // the cast below rewrites dA[(l - 1) & 1], which layer l + 1's weight gradients read
             TRYP("ln_bwd_kernel", 0, (double)M * H * (es + 3 * rs + es), s,   // dy (operand dtype), x, dx in / out, cast out
                  layernorm_bwd_launch(dtmp, dt == NBCI_BF16 ? 1 : 0, ws + lw.x_in, params + lo.ln1w, (const float*)(ws + lw.mean1),
@@ -708,12 +717,13 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
             const nbci_operand dx0_km = npre ? op(dx0, es, (int64_t)npre * H, H, 1, Tk, (int64_t)Tp * H) : op(dx0, es, 0, H, 1);
             const nbci_operand dx0_rm = npre ? op(dx0, es, (int64_t)npre * H, H, 0, Tk, (int64_t)Tp * H) : op(dx0, es, 0, H, 0);
             if (w.phase_ok) {
-                // dx0 sits in zero-padded sample blocks (B, P, H): token j of sample b at row b*P + npad + j.
+                // dx0 sits in the phase layout (carve): token j of sample b at row npad + b*Q + j, zero rows in between.
                 const int st = c.stack_stride, nwin = c.stack_size / st;
                 if (part != 2) TRY(fork());
-                if (part != 2)
-                    TRY(wgrad(wgs, dt, H, KS, Mk, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0, Tk, (int64_t)w.P * H),
-                              op(ws + w.y, es, 0, (int64_t)st * D, 0, Tk, (int64_t)T * D), grads + p.stkw, KS));
+                if (part != 2)   // K = all B*Q rows (the zero rows add nothing): row r of dx0 against the window starting at bin st*r of y, both
+                                 // operands plain (the window rows overlap: rpb = -1) - no view stepping in the K loop (187 -> 14x us)
+                    TRY(wgrad(wgs, dt, H, KS, B * w.Q, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0),
+                              op(ws + w.y, es, 0, (int64_t)st * D, 0, -1), grads + p.stkw, KS));
                 if (part != 1) {
                 // d pre-activation WITHOUT the (M, size*D) window-gradient tensor and its col2im pass. The st bins t = st*q + ph of
                 // group q collect  sum_{i < nwin} dx0[q - i] . W_s[:, D*(st*i + ph) .. + D]; with n = D*ph + c and i' = nwin-1-i that
@@ -721,7 +731,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 // (an overlapping-row view, K = nwin*H contiguous) against the weight slices taken in reverse order (a row-major-in-k
                 // view with a negative group stride). Output row (b, q) IS bins st*q .. st*q+st-1 of d pre-activation; the
                 // activation gradient (from the stored output y, same layout) is the gate.
-                nbci_gemm_desc d = gd(B * w.Q, st * D, nwin * H, dt, op(ws + w.dAp, es, 0, H, 1, w.Q, (int64_t)w.P * H),
+                nbci_gemm_desc d = gd(B * w.Q, st * D, nwin * H, dt, op(ws + w.dAp, es, 0, H, 1),   // (rows b*Q + q .. + nwin - 1: every row one H apart)
                                       op(x.W(p.stkw), es, (int64_t)D * st * (nwin - 1), KS, 0, H, -(int64_t)D * st), ws + w.dpre,
                                       (int64_t)st * D, dt);
                 d.gate = ws + w.y; d.ldg = (int64_t)st * D; d.gate_act = 64 + c.embed_act;

@@ -325,3 +325,50 @@ def test_phase_gemm_views_match_col2im(shape):
         check(lib().nbci_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "phase gemm")
     torch.cuda.synchronize()
     assert torch.equal(out.reshape(B, T, D).double().cpu(), ref.double().cpu())
+
+
+@pytest.mark.parametrize("shape", [(3, 21, 64, 16), (16, 143, 1024, 256)])   # (B, T', H, D)
+def test_phase_layout_plain_operands_match_the_views(shape):
+    """The step's embedder backward since round 3 (ndt1.hip, carve): dx0 as npad zero rows + per sample Q rows (T' tokens + npad zero
+    rows), every row one H apart -> the phase GEMM's A is a PLAIN k-major operand whose rows overlap (ld < K), and the stack-projection
+    weight gradient runs over ALL B * Q rows with two plain operands (the window rows of y overlap: rpb = -1; the zero rows of dx0 meet
+    window rows that run into the next sample / the zeroed slack behind y). Exact integer data against the explicit windows."""
+    ops = _ops()
+    import ctypes as C
+    from llm_bci_amd._lib import GemmDesc, check, lib
+    B, Tp, H, D = shape
+    st, nwin = 4, 8
+    size = st * nwin
+    T = st * (Tp - 1) + size
+    Q, npad = T // st, nwin - 1
+    assert Q - Tp == npad
+    dx0 = _ints((B, Tp, H), lo=-3, hi=4, seed=61).to(DEV)
+    W = _ints((H, size * D), lo=-2, hi=3, seed=62).to(DEV)
+    y = (_ints((B, T, D), lo=-7, hi=8, seed=63) / 8.0).to(DEV)
+    lay = torch.zeros(npad + B * Q, H, device=DEV, dtype=torch.bfloat16)
+    lay[npad:].view(B, Q, H)[:, :Tp] = dx0.bfloat16()
+    ybuf = torch.zeros(B * T * D + (size - st) * D, device=DEV, dtype=torch.bfloat16)   # y + its zeroed slack
+    ybuf[:B * T * D] = y.bfloat16().reshape(-1)
+    Wb = W.bfloat16().contiguous()
+    # (1) phase GEMM: d pre-activation rows (b, q) = bins st*q .. of sample b
+    dwin = (dx0.reshape(B * Tp, H) @ W).reshape(B, Tp, size * D)
+    dpre = torch.zeros(B, T, D, device=DEV)
+    for r in range(size):
+        dpre[:, r: r + st * Tp: st, :] += dwin[:, :, r * D:(r + 1) * D]
+    out = torch.full((B * Q, st * D), -7.0, device=DEV)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.in_dtype = B * Q, st * D, nwin * H, ops.NBCI_BF16
+    d.A = ops.operand(lay, H, True)
+    d.B = ops.operand(Wb, size * D, False, rpb=H, gstride=-D * st, offset=D * st * (nwin - 1))
+    d.C, d.ldc, d.c_dtype, d.batch, d.zdiv, d.splitk, d.alpha, d.beta = out.data_ptr(), st * D, ops.NBCI_F32, 1, 1, 1, 1.0, 0.0
+    check(lib().nbci_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "phase gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(B, T, D).double().cpu(), dpre.double().cpu())
+    # (2) stack-projection weight gradient: dW[h][k] = sum over tokens dx0[b, j, h] * window(b, j)[k]
+    win = torch.stack([y[:, j * st:j * st + size, :].reshape(B, size * D) for j in range(Tp)], 1)
+    refw = dx0.reshape(B * Tp, H).double().t() @ win.reshape(B * Tp, size * D).double()
+    dW = torch.zeros(H, size * D, device=DEV)
+    ops.gemm(H, size * D, B * Q, ops.operand(lay, H, False, offset=npad * H), ops.operand(ybuf, st * D, False, rpb=-1), dW, size * D,
+             in_dtype=ops.NBCI_BF16, c_dtype=ops.NBCI_F32, beta=1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(dW.double().cpu(), refw.cpu())
