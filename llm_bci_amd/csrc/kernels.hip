@@ -3,6 +3,7 @@
 // beyond small cross-wave reductions. See kernels.h for the reference lines each replaces.
 #include "kernels.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace nbci {
 
@@ -1177,10 +1178,12 @@ __global__ __launch_bounds__(256) void ctc_mid_kernel(const float* __restrict__ 
     float v0 = -INFINITY, v1 = -INFINITY;
     const float* lpb = lpl + blank;
     const float* lpe = lpl + e;
-    // one frame of the recursion for this wave's lattice (states past L need no masking: see ctc_kernel)
-    auto frame = [&](int t, float pb, float pe) {
-        if (alpha) {
-            if (t == 0) { v0 = (i == 0) ? pb : -INFINITY; v1 = (i == 0 && live1) ? pe : -INFINITY; }
+    // one frame of the recursion for this wave's lattice (states past L need no masking: see ctc_kernel). ALPHA is a compile-time constant:
+    // the loop body is straight-line code for one direction
+    auto step = [&](auto alpha_c, bool init, float pb, float pe) {
+        constexpr bool ALPHA = decltype(alpha_c)::value;
+        if constexpr (ALPHA) {
+            if (init) { v0 = (i == 0) ? pb : -INFINITY; v1 = (i == 0 && live1) ? pe : -INFINITY; }
             else {
                 const float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x138, 0xF, 0xF, false));   // wave_shr:1
                 const float n0 = lse2(v0, pl) + pb;
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(256) void ctc_mid_kernel(const float* __restrict__ 
                 v0 = n0;
             }
         } else {
-            if (t == Tb - 1) { v0 = (2 * i == L - 1) ? pb : -INFINITY; v1 = (live1 && 2 * i + 1 == L - 2) ? pe : -INFINITY; }
+            if (init) { v0 = (2 * i == L - 1) ? pb : -INFINITY; v1 = (live1 && 2 * i + 1 == L - 2) ? pe : -INFINITY; }
             else {
                 const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v0), 0x130, 0xF, 0xF, false));   // wave_shl:1
                 const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v1), 0x130, 0xF, 0xF, false));
@@ -1197,49 +1200,51 @@ __global__ __launch_bounds__(256) void ctc_mid_kernel(const float* __restrict__ 
             }
         }
     };
-    if (wv < 2 && Tb > 0) {
-        // ---- first half: rows to LDS
-        const int t_first = alpha ? 0 : Tb - 1, n1 = alpha ? m : Tb - m, dt = alpha ? 1 : -1;
-        float* lat = alpha ? latA : latB - (long long)m * Lmax;   // row t of the wave's own lattice
-        int t = t_first;
-        float pb = lpb[t * V], pe = lpe[t * V];
-        for (int step = 0; step < n1; ++step) {
+    float nll = INFINITY;
+    auto run = [&](auto alpha_c, auto second_c) {
+        constexpr bool ALPHA = decltype(alpha_c)::value, SECOND = decltype(second_c)::value;
+        constexpr int dt = ALPHA ? 1 : -1;
+        const int n = SECOND ? (ALPHA ? Tb - m : m) : (ALPHA ? m : Tb - m);
+        float* lat = ALPHA ? latA : latB - (long long)m * Lmax;           // row t of the wave's own lattice
+        const float* oth = ALPHA ? latB - (long long)m * Lmax : latA;     // row t of the OTHER lattice
+        int t = SECOND ? (ALPHA ? m : m - 1) : (ALPHA ? 0 : Tb - 1);
+        const int t_init = ALPHA ? 0 : Tb - 1;
+        float pb = n > 0 ? lpb[t * V] : 0.f, pe = n > 0 ? lpe[t * V] : 0.f;
+        for (int st = 0; st < n; ++st) {
             const int tn = t + dt, tc = min(max(tn, 0), Tb - 1);
             const float nb = lpb[tc * V], ne = lpe[tc * V];
-            frame(t, pb, pe);
-            if (live0) lat[t * Lmax + 2 * i] = v0;
-            if (live1) lat[t * Lmax + 2 * i + 1] = v1;
+            if constexpr (!SECOND) {
+                step(alpha_c, t == t_init, pb, pe);
+                if (live0) lat[t * Lmax + 2 * i] = v0;
+                if (live1) lat[t * Lmax + 2 * i + 1] = v1;
+            } else {
+                const float o1 = live1 ? oth[t * Lmax + 2 * i + 1] : -INFINITY;
+                step(alpha_c, t == t_init, pb, pe);
+                const float x1 = live1 ? v1 + o1 - pe : -INFINITY;   // log alpha beta / y of the label state
+                if (st == 0) {   // log-likelihood = logsumexp over ALL states of this frame (the only place the blank states' products are needed)
+                    const float x0 = live0 ? v0 + oth[t * Lmax + 2 * i] - pb : -INFINITY;
+                    const float mx = wave_max(fmaxf(x0, x1));
+                    if (mx > -INFINITY) {
+                        const float sm2 = wave_sum(expf(x0 - mx) + expf(x1 - mx));
+                        nll = -(mx + logf(sm2));
+                    }
+                    if (ALPHA && i == 0) s_nll = nll;
+                }
+                // posterior mass of the LABEL classes only: a frame's posteriors sum to one, so the blank column is filled in afterwards as
+                // 1 - (the labels' sum) instead of 61 same-address adds (or a wave reduction) per frame
+                if (nll < INFINITY && x1 > -INFINITY) atomicAdd(&occ[t * V + e], __builtin_amdgcn_exp2f((x1 + nll) * LOG2E));
+            }
             pb = nb; pe = ne; t = tn;
         }
+    };
+    if (Tb > 0) {
+        if (wv == 0) run(std::true_type{}, std::false_type{});
+        else if (wv == 1) run(std::false_type{}, std::false_type{});
     }
     __syncthreads();
-    float nll = INFINITY;
-    if (wv < 2 && Tb > 0) {
-        // ---- second half: the other wave's rows are known, the posterior is formed on the spot
-        const int n2 = alpha ? Tb - m : m, dt = alpha ? 1 : -1;
-        const float* oth = alpha ? latB - (long long)m * Lmax : latA;   // row t of the OTHER lattice
-        int t = alpha ? m : m - 1;
-        float pb = n2 > 0 ? lpb[t * V] : 0.f, pe = n2 > 0 ? lpe[t * V] : 0.f;
-        for (int step = 0; step < n2; ++step) {
-            const int tn = t + dt, tc = min(max(tn, 0), Tb - 1);
-            const float nb = lpb[tc * V], ne = lpe[tc * V];
-            const float o0 = live0 ? oth[t * Lmax + 2 * i] : -INFINITY, o1 = live1 ? oth[t * Lmax + 2 * i + 1] : -INFINITY;
-            frame(t, pb, pe);
-            const float x0 = live0 ? v0 + o0 - pb : -INFINITY, x1 = live1 ? v1 + o1 - pe : -INFINITY;   // log alpha beta / y
-            if (step == 0) {   // log-likelihood = logsumexp over the states of this frame
-                const float mx = wave_max(fmaxf(x0, x1));
-                if (mx > -INFINITY) {
-                    const float sm2 = wave_sum(expf(x0 - mx) + expf(x1 - mx));
-                    nll = -(mx + logf(sm2));
-                }
-                if (alpha && i == 0) s_nll = nll;
-            }
-            if (nll < INFINITY) {
-                if (x0 > -INFINITY) atomicAdd(&occ[t * V + blank], __builtin_amdgcn_exp2f((x0 + nll) * LOG2E));
-                if (x1 > -INFINITY) atomicAdd(&occ[t * V + e], __builtin_amdgcn_exp2f((x1 + nll) * LOG2E));
-            }
-            pb = nb; pe = ne; t = tn;
-        }
+    if (Tb > 0) {
+        if (wv == 0) run(std::true_type{}, std::true_type{});
+        else if (wv == 1) run(std::false_type{}, std::true_type{});
     }
     __syncthreads();
     nll = s_nll;
@@ -1250,6 +1255,12 @@ __global__ __launch_bounds__(256) void ctc_mid_kernel(const float* __restrict__ 
     const int tz = finite ? Tb : 0;
     for (long long k = tid + (long long)tz * ldd; k < (long long)Tp * ldd; k += 256) stf<TD>(dlogits, (long long)b * Tp * ldd + k, 0.f);
     if (!finite || Tb == 0) return;
+    for (int t = tid; t < Tb; t += 256) {   // the blank column: what the labels leave of the frame's unit mass
+        float sl = 0.f;
+        for (int c = 0; c < V; ++c) sl += (c == blank) ? 0.f : occ[t * V + c];
+        occ[t * V + blank] = 1.0f - sl;
+    }
+    __syncthreads();
     for (int k = tid; k < Tb * ldd; k += 256) {
         const int t = k / ldd, c = k % ldd;
         const float v = (c < V) ? (expf(lpl[t * V + c]) - occ[t * V + c]) * grad_scale : 0.f;
