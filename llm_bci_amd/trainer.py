@@ -34,7 +34,7 @@ def register_into(reference_trainer_module):
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
                  div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
-                 compute_per=True, blank_id=0, comm_dtype="fp32", side_stream="auto", side_stream_max_rows=1 << 30):
+                 compute_per=True, blank_id=0, comm_dtype="fp32", side_stream="auto", side_stream_max_rows=11500):
         self.model = model
         self.ga = gradient_accumulation_steps
         self.wd, self.eps, self.beta2 = wd, eps, betas[1]
@@ -65,7 +65,8 @@ class NativeTrainer:
         # One GPU: the weight-gradient GEMMs, the fold of the bias / LayerNorm gradient sums and the optimizer update (+ zero_grad) of
         # every finished segment run on a SECOND stream beside the data-gradient chain (nbci_ndt1_io.aux_stream). Same kernels, same
         # bits. Small batches leave most CUs idle inside every launch of the chain (B = 8: -7 % per step); at B = 64 it is still -2 %
-        # (in-box A/B, tools/ab_side_stream.py). "auto" = on when the model supports it and B x T' <= side_stream_max_rows.
+        # (in-box A/B, tools/ab_side_stream.py; B = 96 = 13 728 rows: +0.8 %, every launch fills the chip and the two streams only get
+        # in each other's way). "auto" = on when the model supports it and B x T' <= side_stream_max_rows (default: between the two).
         self.side_stream = side_stream
         self.side_stream_max_rows = side_stream_max_rows
         self._aux = None
