@@ -67,8 +67,13 @@ __global__ __launch_bounds__(256) void masker_zero_kernel(nbci_masker_desc d, un
         d.mask[i] = d.accumulate ? (d.mask[i] | (long long)mt) : (long long)mt;
         mx = fmaxf(mx, v);
     }
+    // ONE atomic per block: every atomic of the launch goes to the same word and they serialise in L2 at ~10 ns each - one per wave of
+    // 4096 blocks was 160 of this kernel's 192 us (iTransformer, 1500 channels)
+    __shared__ float wmax[4];
     mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, f2ord(mx));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(maxbits, f2ord(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // pass 2: of the masked elements that were not zeroed, `random_ratio` become U(0, max) (masker.py:100-102)
@@ -96,7 +101,7 @@ int masker_launch(const nbci_masker_desc& d, hipStream_t s) {
     NBCI_REQUIRE(d.mode != NBCI_MASK_TEMPORAL || (d.timespan >= 1 && d.timespan <= 64), NBCI_EINVAL, "masker: timespan must be in 1..64");
     NBCI_REQUIRE((long long)d.B * d.T * d.N < (1ll << 32), NBCI_ESHAPE, "masker: tensor too large for the 32-bit RNG counter");
     const long long n = (long long)d.B * d.T * d.N;
-    const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 4);   // (grid-stride loops; few blocks = few same-word atomics)
     NBCI_CHECK_HIP(hipMemsetAsync(d.scratch, 0, 4, s));   // ordered-uint encoding: 0 < every float
     hipLaunchKernelGGL(masker_zero_kernel, dim3(blocks), dim3(256), 0, s, d, (unsigned*)d.scratch);
     int rc = check_launch("masker_zero");
@@ -230,32 +235,41 @@ __global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const float* __re
                                                                float* __restrict__ dtab2, const long long* __restrict__ idx2,
                                                                float* __restrict__ dcls, RepCfg rc, int B, int N, int H, int use_cls,
                                                                unsigned thr, float dscale, uint32_t key) {
+    // a thread owns columns c0 + 64 e (e = 0..3) of its wave's 256-column span: every atomic wave-instruction then covers 64 CONSECUTIVE
+    // floats (f32 atomics run at full rate only in that shape; with four adjacent columns per thread each instruction touched 64 words
+    // spread over 1 KB: 232 us for the 18 M adds of the channel table at 1500 channels)
     const int S = N + use_cls;
     const long long row = (long long)blockIdx.y;
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= H) return;
+    const int c0 = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
     const int b = (int)(row / S), sidx = (int)(row % S);
-    const long long o = row * H + c;
-    const float4 g4 = *(const float4*)(dx0 + o);
-    float r[4] = {g4.x, g4.y, g4.z, g4.w};
-    if (thr) drop4(key, thr, (unsigned)o, dscale, r);
-    if (use_cls && sidx == 0) {
-        float* dc = rep_ptr(dcls, rc, (unsigned)b) + c;
+    float r[4];
+    bool ok[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dc + e, r[e]);
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + 64 * e;
+        ok[e] = c < H;
+        const long long o = row * H + c;
+        r[e] = ok[e] ? dx0[o] : 0.f;
+        if (thr && ok[e]) r[e] = drop_keep(key, thr, (unsigned)o) ? r[e] * dscale : 0.f;
+    }
+    if (use_cls && sidx == 0) {
+        float* dc = rep_ptr(dcls, rc, (unsigned)b) + c0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (ok[e]) atomicAdd(dc + 64 * e, r[e]);
         return;
     }
     const long long r0 = (long long)b * N + (sidx - use_cls);
-    *(float4*)(dtok + r0 * H + c) = make_float4(r[0], r[1], r[2], r[3]);
-    if (dtab1) {
-        float* p = dtab1 + idx1[r0] * H + c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(p + e, r[e]);
+    for (int e = 0; e < 4; ++e) if (ok[e]) dtok[r0 * H + c0 + 64 * e] = r[e];
+    if (dtab1) {
+        float* p = dtab1 + idx1[r0] * H + c0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (ok[e]) atomicAdd(p + 64 * e, r[e]);
     }
     if (dtab2) {
-        float* p = dtab2 + idx2[r0] * H + c;
+        float* p = dtab2 + idx2[r0] * H + c0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(p + e, r[e]);
+        for (int e = 0; e < 4; ++e) if (ok[e]) atomicAdd(p + 64 * e, r[e]);
     }
 }
 
