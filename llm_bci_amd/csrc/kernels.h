@@ -142,6 +142,8 @@ int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* 
                          int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8 = nullptr, void* q8_scales = nullptr);
 int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
                          float* partials, float* sums /* 3 D floats: the second pass's per-column coefficients */, long long M, int D, int train, hipStream_t s);
+// dW[D][pl] += de^T xm over all M rows (f32; the shared patch embedding's weight gradient as a streaming reduction)
+int ptst_embed_wgrad_launch(const float* de, const float* xm, float* dW, long long M, int pl, int D, hipStream_t s);
 int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s);
 int ptst_pool_bwd_launch(const float* dpooled, float* dh, int B, int C, int P, int D, hipStream_t s);
 int ptst_lens_launch(const int64_t* lens, int32_t* out, int B, int pl, int stride, hipStream_t s);
