@@ -604,14 +604,25 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmK& d, f32x4 (&acc)[
         if (ch == 0) STAMP(6);
         epi_tile_rows(d, tile, rows, m0 + ch * rows, n0, coff, t, nthreads, csum);
     }
-    if (d.colsum) {   // bias gradient: the two half-waves hold the same columns; one atomic per column per wave
+    if (d.colsum) {
+        // bias gradient: the waves' column sums (the two half-waves of a wave hold the same columns) meet in the - now free - LDS tile and
+        // ONE lane-contiguous atomic per column leaves the workgroup: 2 wave-instructions of 64 consecutive floats per tile. (Before, every
+        // wave added its own four adjacent columns per lane: 4 x waves instructions per tile, each touching 32 words spread over 512 B -
+        // the shape f32 atomics are slowest in; it showed in the short-K projections of PatchTST.)
         const int cbase = (int)(coff % d.ldc);
+        const int nwaves = nthreads >> 6;
+        __syncthreads();   // the row loops are done with the tile
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float s = csum[e];
             s += __shfl_xor(s, 32, 64);
-            if (lane < 32 && n + e < d.N)
-                atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(m0 >> 4) + (unsigned)(t >> 6) + (unsigned)(coff / d.ldc)) + cbase + n + e, s);
+            if (lane < 32) tile[(t >> 6) * 128 + c4 + e] = s;
+        }
+        __syncthreads();
+        if (t < 128 && n0 + t < d.N) {
+            float s = 0.f;
+            for (int w2 = 0; w2 < nwaves; ++w2) s += tile[w2 * 128 + t];
+            atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(m0 >> 4) + (unsigned)(coff / d.ldc)) + cbase + n0 + t, s);
         }
     }
 }

@@ -233,14 +233,23 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_pc_kernel(GemmK d) {
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
         const int nh = n0 + 128 * h;
         epi_tile_rows(d, (const float*)smem + h * (PC_BM * EPI_LD), PC_BM, m0, nh, coff, t, PC_THREADS, csum);
-        if (d.colsum) {   // bias gradient: the two half-waves hold the same columns; one atomic per column per wave
-            const int cbase = (int)(coff % d.ldc), n = nh + 4 * (t & 31);
+        if (d.colsum) {   // bias gradient: the eight waves' column sums meet in image h (read out by now) and ONE lane-contiguous atomic
+                          // per column leaves the workgroup (gemm_common.h, gemm_epilogue_tile)
+            const int cbase = (int)(coff % d.ldc);
+            float* red = (float*)smem + h * (PC_BM * EPI_LD);
+            __syncthreads();
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s = csum[e];
                 s += __shfl_xor(s, 32, 64);
-                if (lane < 32 && n + e < d.N)
-                    atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(m0 >> 4) + (unsigned)(t >> 6) + (unsigned)(coff / d.ldc)) + cbase + n + e, s);
+                if (lane < 32) red[(t >> 6) * 128 + 4 * (t & 31) + e] = s;
+            }
+            __syncthreads();
+            if (t < 128 && nh + t < d.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < PC_THREADS / 64; ++w2) s += red[w2 * 128 + t];
+                atomicAdd(rep_ptr(d.colsum, d.colsum_rc, (unsigned)(m0 >> 4) + (unsigned)(coff / d.ldc)) + cbase + nh + t, s);
             }
         }
     }

@@ -640,10 +640,12 @@ __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__
                                                        int cpt, int gpb) {
     // cpt = column-threads per row (N / 4, at most 256 per block), gpb = row groups per block (narrow matrices keep all
     // 256 threads busy); a block walks row groups with a grid stride so the column sums cost one atomic per thread.
+    __shared__ float csum[1024];   // [gpb][cpt * 4]: the row groups' column sums (colsum only)
     const int cg = threadIdx.x % cpt, rg = threadIdx.x / cpt;
     const int c = (blockIdx.x * cpt + cg) * 4;
-    if (c >= N || rg >= gpb) return;
+    const bool live = c < N && rg < gpb;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live)
     for (long long r0 = ((long long)blockIdx.y * gpb + rg) * DC_ROWS; r0 < M; r0 += (long long)gridDim.y * gpb * DC_ROWS) {
         float4 q[DC_ROWS];
 #pragma unroll
@@ -665,8 +667,18 @@ __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__
         }
     }
     if (colsum) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(rep_ptr(colsum, rc, blockIdx.y * gpb + rg) + c + e, s[e]);
+        // the block's row groups are summed through LDS and ONE lane-contiguous atomic per column leaves the block (a thread adding its
+        // four adjacent columns made every atomic wave-instruction touch 64 words spread over 1 KB, and every row group added its own)
+        const int ncol = cpt * 4;
+        if (live) *(float4*)(csum + rg * ncol + cg * 4) = make_float4(s[0], s[1], s[2], s[3]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncol; i += 256) {
+            const int col = blockIdx.x * ncol + i;
+            if (col >= N) break;
+            float t = 0.f;
+            for (int g2 = 0; g2 < gpb; ++g2) t += csum[g2 * ncol + i];
+            atomicAdd(rep_ptr(colsum, rc, blockIdx.y) + col, t);
+        }
     }
 }
 
