@@ -456,6 +456,9 @@ typedef struct nbci_itr_config { /* configs/itransformer.yaml, flattened */
     int32_t use_cls, mlp_decoder;
     int32_t loss;                    /* NBCI_LOSS_* (poisson_nll with log_input true/false, mse) */
     int32_t dtype;
+    int32_t residual_dtype;          /* storage of the LayerNorm inputs r1 / r2 and of the gradient streams between kernels: NBCI_F32 (default),
+                                      * or NBCI_BF16 (dtype bf16 only; f32 arithmetic, one rounding per store - as nbci_ndt1_config.residual_dtype).
+                                      * With bf16 the residual a layer adds is the bf16 LayerNorm output its GEMMs read (no f32 copy of it). */
 } nbci_itr_config;
 
 typedef struct nbci_itr_io {

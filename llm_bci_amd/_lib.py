@@ -83,7 +83,7 @@ LOSS_KIND = {("poisson_nll", True): 0, ("poisson_nll", False): 1, ("mse", True):
 class ItrConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("max_n_bins", "hidden", "n_heads", "n_layers", "max_n_channels", "n_regions", "act",
                                          "dec_act")] + [("embed_dropout", C.c_float), ("dropout", C.c_float)] + [
-        (n, C.c_int32) for n in ("use_cls", "mlp_decoder", "loss", "dtype")]
+        (n, C.c_int32) for n in ("use_cls", "mlp_decoder", "loss", "dtype", "residual_dtype")]
 
 
 class ItrIO(C.Structure):

@@ -539,6 +539,7 @@ __device__ __forceinline__ void epi_tile_rows(const GemmK& d, const float* tile,
                     NBCI_EPI_CASE(EPI_BIAS | EPI_RES_FIRST | EPI_RES_ROWS | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_BIAS | EPI_DROP | EPI_RES_LAST | EPI_RESBF16 | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_BIAS | EPI_RES_LAST | EPI_RESBF16 | EPI_CBF16)
+                    NBCI_EPI_CASE(EPI_RES_LAST | EPI_RESBF16 | EPI_CBF16)                                      // bf16 gradient stream + data gradient (iTransformer)
                     NBCI_EPI_CASE(EPI_DROP | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_COLSUM | EPI_CBF16)
                     NBCI_EPI_CASE(EPI_GATE_MUL | EPI_COLSUM | EPI_CBF16)

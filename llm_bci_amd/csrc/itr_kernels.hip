@@ -230,7 +230,8 @@ int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, con
 }
 
 // backward of the assembly: d = dx0 * keepmask; cls grad += sum_b d[b,0]; dtok[(b,n)] = d[b,1+n]; dtab[idx[b,n]] += d[b,1+n]
-__global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const float* __restrict__ dx0, float* __restrict__ dtok,
+template <typename TG>   // TG: storage of the incoming gradient stream (f32, or bf16)
+__global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const TG* __restrict__ dx0, float* __restrict__ dtok,
                                                                float* __restrict__ dtab1, const long long* __restrict__ idx1,
                                                                float* __restrict__ dtab2, const long long* __restrict__ idx2,
                                                                float* __restrict__ dcls, RepCfg rc, int B, int N, int H, int use_cls,
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const float* __re
         const int c = c0 + 64 * e;
         ok[e] = c < H;
         const long long o = row * H + c;
-        r[e] = ok[e] ? dx0[o] : 0.f;
+        r[e] = ok[e] ? (float)dx0[o] : 0.f;
         if (thr && ok[e]) r[e] = drop_keep(key, thr, (unsigned)o) ? r[e] * dscale : 0.f;
     }
     if (use_cls && sidx == 0) {
@@ -273,14 +274,18 @@ __global__ __launch_bounds__(256) void itr_assemble_bwd_kernel(const float* __re
     }
 }
 
-int itr_assemble_bwd_launch(const float* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
+int itr_assemble_bwd_launch(const void* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
                             float* dcls, RepCfg rc, int B, int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site,
-                            hipStream_t s) {
+                            hipStream_t s, int dx_dtype) {
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     dim3 g((H / 4 + 255) / 256, (unsigned)((long long)B * (N + use_cls)));
-    hipLaunchKernelGGL(itr_assemble_bwd_kernel, g, dim3(256), 0, s, dx0, dtok, dtab1, (const long long*)idx1, dtab2,
-                       (const long long*)idx2, dcls, rc, B, N, H, use_cls, thr, dscale, drop_key(seed, site));
+    if (dx_dtype == NBCI_BF16)
+        hipLaunchKernelGGL((itr_assemble_bwd_kernel<bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dx0, dtok, dtab1, (const long long*)idx1, dtab2,
+                           (const long long*)idx2, dcls, rc, B, N, H, use_cls, thr, dscale, drop_key(seed, site));
+    else
+        hipLaunchKernelGGL((itr_assemble_bwd_kernel<float>), g, dim3(256), 0, s, (const float*)dx0, dtok, dtab1, (const long long*)idx1, dtab2,
+                           (const long long*)idx2, dcls, rc, B, N, H, use_cls, thr, dscale, drop_key(seed, site));
     return check_launch("itr_assemble_bwd");
 }
 

@@ -149,6 +149,7 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
     const int S = N + (c.use_cls ? 1 : 0);
     NBCI_REQUIRE(S <= 2048, NBCI_ESHAPE, "itransformer: at most 2048 tokens per sample");
     const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
+    const size_t rs = c.residual_dtype == NBCI_BF16 ? 2 : 4;   // the LayerNorm inputs r1 / r2 and the gradient streams dY / dR
     const size_t H = c.hidden, F = 4 * H, T = c.max_n_bins;
     const size_t M = (size_t)B * S, M0 = (size_t)B * N;
     NBCI_REQUIRE(M * F < (1ull << 32), NBCI_ESHAPE, "itransformer: batch too large for the 32-bit dropout counter");
@@ -178,11 +179,11 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * H * es);
         l.lse = bump(cur, nstat * 4);
-        l.r1 = bump(cur, M * H * 4);
+        l.r1 = bump(cur, M * H * rs);
         l.mean1 = bump(cur, M * 4); l.rstd1 = bump(cur, M * 4);
         l.x1b = bump(cur, M * H * es);
         l.g = bump(cur, M * F * es);
-        l.r2 = bump(cur, M * H * 4);
+        l.r2 = bump(cur, M * H * rs);
         l.mean2 = bump(cur, M * 4); l.rstd2 = bump(cur, M * 4);
     }
     w.yA = bump(cur, M * H * 4);
@@ -195,8 +196,8 @@ static int itr_carve(const ItrPlan& p, int B, int N, ItrWS& w) {
     w.dpred = bump(cur, M * w.ldT * es);
     w.scores = bump(cur, w.small_attn ? 0 : (size_t)B * c.n_heads * S * w.ldS * 4);
     w.dsum = bump(cur, nstat * 4);
-    w.dY = bump(cur, M * H * 4);
-    w.dR = bump(cur, M * H * 4);
+    w.dY = bump(cur, M * H * rs);
+    w.dR = bump(cur, M * H * 4);   // (f32-sized whatever the stream type: the embedding's LayerNorm backward also uses it as its f32 dx sink)
     w.cA = bump(cur, M * H * es);
     w.cA2 = bump(cur, M * H * es);
     w.dU = bump(cur, M * F * es);
@@ -300,6 +301,10 @@ int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, co
     const float scale = 1.0f / sqrtf((float)hd);
     float* yA = (float*)(ws + w.yA);
     float* yB = (float*)(ws + w.yB);
+    // residual_dtype bf16: r1 / r2 are stored in bf16 and the residual a sub-layer adds is the bf16 LayerNorm output its GEMMs read
+    // (lw.xb / lw.x1b) - no f32 copies yA / yB of the LayerNorm outputs; sums in f32, one rounding per store
+    const int xdt = c.residual_dtype;
+    const bool rb = xdt == NBCI_BF16;
     for (int l = 0; l < c.n_layers; ++l) {
         const ItrLayerWS& lw = w.L[l];
         const ItrLayerOff& lo = p.L[l];
@@ -329,28 +334,32 @@ int itr_forward(const ItrPlan& p, const float* params, const void* params_lp, co
         }
         }
         {   // r1 = x + dropout1(out_proj(a))
-            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), ws + lw.r1, H, NBCI_F32);
-            d.bias = params + lo.ob; d.drop_p = pl; d.seed = io->seed; d.site = 17 + 4 * l; d.residual = yA; d.ldr = H;
+            nbci_gemm_desc d = gd(M, H, H, dt, op(ws + lw.ad, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 1), ws + lw.r1, H, xdt);
+            d.bias = params + lo.ob; d.drop_p = pl; d.seed = io->seed; d.site = 17 + 4 * l; d.ldr = H;
+            d.residual = rb ? (const void*)(ws + lw.xb) : (const void*)yA; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
-        TRY(layernorm_fwd_launch((const float*)(ws + lw.r1), params + lo.n1w, params + lo.n1b, ws + lw.x1b, dt, (float*)(ws + lw.mean1),
-                                 (float*)(ws + lw.rstd1), M, H, s, yB));
+        TRY(layernorm_fwd_launch(ws + lw.r1, xdt, params + lo.n1w, params + lo.n1b, ws + lw.x1b, dt, (float*)(ws + lw.mean1),
+                                 (float*)(ws + lw.rstd1), M, H, s, rb ? nullptr : yB));
         {   // g = dropout(act(linear1(x1)))
             nbci_gemm_desc d = gd(M, F, H, dt, op(ws + lw.x1b, es, 0, H, 1), op(x.W(lo.w1), es, 0, H, 1), ws + lw.g, F, dt);
             d.bias = params + lo.b1; d.act = c.act; d.drop_p = pl; d.seed = io->seed; d.site = 18 + 4 * l;
             TRY(gemm_launch_timed(d, s));
         }
         {   // r2 = x1 + dropout2(linear2(g))
-            nbci_gemm_desc d = gd(M, H, F, dt, op(ws + lw.g, es, 0, F, 1), op(x.W(lo.w2), es, 0, F, 1), ws + lw.r2, H, NBCI_F32);
-            d.bias = params + lo.b2; d.drop_p = pl; d.seed = io->seed; d.site = 19 + 4 * l; d.residual = yB; d.ldr = H;
+            nbci_gemm_desc d = gd(M, H, F, dt, op(ws + lw.g, es, 0, F, 1), op(x.W(lo.w2), es, 0, F, 1), ws + lw.r2, H, xdt);
+            d.bias = params + lo.b2; d.drop_p = pl; d.seed = io->seed; d.site = 19 + 4 * l; d.ldr = H;
+            d.residual = rb ? (const void*)(ws + lw.x1b) : (const void*)yB; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
         void* xb_next = ws + (l + 1 < c.n_layers ? w.L[l + 1].xb : w.xlast_b);
-        TRY(layernorm_fwd_launch((const float*)(ws + lw.r2), params + lo.n2w, params + lo.n2b, xb_next, dt, (float*)(ws + lw.mean2),
-                                 (float*)(ws + lw.rstd2), M, H, s, yA));
+        TRY(layernorm_fwd_launch(ws + lw.r2, xdt, params + lo.n2w, params + lo.n2b, xb_next, dt, (float*)(ws + lw.mean2),
+                                 (float*)(ws + lw.rstd2), M, H, s, rb ? nullptr : yA));
     }
-    // final norm (TransformerEncoder(norm=...), itransformer.py:168-173); yA holds its f32 input until the next forward
-    TRY(layernorm_fwd_launch(yA, params + p.fnw, params + p.fnb, ws + w.xo, dt, (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
+    // final norm (TransformerEncoder(norm=...), itransformer.py:168-173); its input (the last layer's output, or the assembled tokens) stays
+    // where it is until the next forward: yA in f32, or the bf16 operand copy
+    const void* fn_in = rb ? (const void*)(ws + w.xlast_b) : (const void*)yA;
+    TRY(layernorm_fwd_launch(fn_in, xdt, params + p.fnw, params + p.fnb, ws + w.xo, dt, (float*)(ws + w.mean_o), (float*)(ws + w.rstd_o), M, H, s));
     if (io->hidden_out)
         NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, ws + w.xo, (size_t)M * H * es, hipMemcpyDeviceToDevice, s));
     // decoder over every token row (the CLS rows are computed and ignored: 1/(N+1) extra work, no gather)
@@ -392,8 +401,10 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
     const bool train = io->train != 0;
     const float pe = train ? c.embed_dropout : 0.f, pl = train ? c.dropout : 0.f;
     char* ws = x.ws;
-    float* dY = (float*)(ws + w.dY);
+    float* dY = (float*)(ws + w.dY);   // (bf16 elements with residual_dtype bf16, as dR, r1, r2)
     float* dR = (float*)(ws + w.dR);
+    const int xdt = c.residual_dtype;
+    const bool rb = xdt == NBCI_BF16;
     const float scale = 1.0f / sqrtf((float)hd);
     float* rep = (float*)(ws + w.rep);
     const RepCfg rc{p.compact_total, NREP};
@@ -419,23 +430,23 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
                     TRY(gemm_launch_timed(d, s));
                 }
                 TRY(wgrad(s, dt, H, H, M, op(ws + w.cA, es, 0, H, 0), op(ws + w.xo, es, 0, H, 0), grads + p.d0w, H));
-                nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, NBCI_F32);
+                nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, xdt);
                 TRY(gemm_launch_timed(d, s));
             } else {
-                nbci_gemm_desc d = gd(M, H, T, dt, op(dp, es, 0, w.ldT, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, NBCI_F32);
+                nbci_gemm_desc d = gd(M, H, T, dt, op(dp, es, 0, w.ldT, 1), op(x.W(p.d0w), es, 0, H, 0), dR, H, xdt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(layernorm_bwd_launch(dR, (const float*)(ws + w.yA), params + p.fnw, (const float*)(ws + w.mean_o),
-                                     (const float*)(ws + w.rstd_o), dY, RG(p.fnw), RG(p.fnb), M, H, 0, s, rc, no_cast));
+            TRY(layernorm_bwd_launch(dR, rb, rb ? (const void*)(ws + w.xlast_b) : (const void*)(ws + w.yA), params + p.fnw,
+                                     (const float*)(ws + w.mean_o), (const float*)(ws + w.rstd_o), LnStreams{rb, nullptr, dY, rb}, RG(p.fnw),
+                                     RG(p.fnb), M, H, s, rc, no_cast));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const ItrLayerWS& lw = w.L[l];
             const ItrLayerOff& lo = p.L[l];
             WgradQueue wq; wq.dtype = dt; wq.s = s;
             // ---- x' = LN2(r2), r2 = x1 + dropout2(linear2(g)), g = dropout(act(linear1(x1)))
-            TRY(layernorm_bwd_launch(dY, (const float*)(ws + lw.r2), params + lo.n2w, (const float*)(ws + lw.mean2),
-                                     (const float*)(ws + lw.rstd2), dR, RG(lo.n2w), RG(lo.n2b), M, H, 0, s, rc,
-                                     cast_to(w.cA, pl, 19 + 4 * l, lo.b2)));
+            TRY(layernorm_bwd_launch(dY, rb, ws + lw.r2, params + lo.n2w, (const float*)(ws + lw.mean2), (const float*)(ws + lw.rstd2),
+                                     LnStreams{rb, nullptr, dR, rb}, RG(lo.n2w), RG(lo.n2b), M, H, s, rc, cast_to(w.cA, pl, 19 + 4 * l, lo.b2)));
             TRY(wq.push(H, F, M, op(ws + w.cA, es, 0, H, 0), op(ws + lw.g, es, 0, F, 0), grads + lo.w2, F));
             {   // du = (c W_2) * act'(u) * keep: for ReLU both factors are read off g itself (g > 0 <=> u > 0 and kept)
                 nbci_gemm_desc d = gd(M, F, H, dt, op(ws + w.cA, es, 0, H, 1), op(x.W(lo.w2), es, 0, F, 0), ws + w.dU, F, dt);
@@ -446,14 +457,13 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
             }
             TRY(wq.push(F, H, M, op(ws + w.dU, es, 0, F, 0), op(ws + lw.x1b, es, 0, H, 0), grads + lo.w1, H));
             {   // d x1 = du W_1 + d r2
-                nbci_gemm_desc d = gd(M, H, F, dt, op(ws + w.dU, es, 0, F, 1), op(x.W(lo.w1), es, 0, H, 0), dY, H, NBCI_F32);
-                d.residual = dR; d.ldr = H;
+                nbci_gemm_desc d = gd(M, H, F, dt, op(ws + w.dU, es, 0, F, 1), op(x.W(lo.w1), es, 0, H, 0), dY, H, xdt);
+                d.residual = dR; d.ldr = H; d.residual_dtype = xdt;
                 TRY(gemm_launch_timed(d, s));
             }
             // ---- x1 = LN1(r1), r1 = x + dropout1(out_proj(attn(x)))
-            TRY(layernorm_bwd_launch(dY, (const float*)(ws + lw.r1), params + lo.n1w, (const float*)(ws + lw.mean1),
-                                     (const float*)(ws + lw.rstd1), dR, RG(lo.n1w), RG(lo.n1b), M, H, 0, s, rc,
-                                     cast_to(w.cA2, pl, 17 + 4 * l, lo.ob)));
+            TRY(layernorm_bwd_launch(dY, rb, ws + lw.r1, params + lo.n1w, (const float*)(ws + lw.mean1), (const float*)(ws + lw.rstd1),
+                                     LnStreams{rb, nullptr, dR, rb}, RG(lo.n1w), RG(lo.n1b), M, H, s, rc, cast_to(w.cA2, pl, 17 + 4 * l, lo.ob)));
             TRY(wq.push(H, H, M, op(ws + w.cA2, es, 0, H, 0), op(ws + lw.ad, es, 0, H, 0), grads + lo.ow, H));
             {
                 nbci_gemm_desc d = gd(M, H, H, dt, op(ws + w.cA2, es, 0, H, 1), op(x.W(lo.ow), es, 0, H, 0), ws + w.dAtt, H, dt);
@@ -501,8 +511,8 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
             TRY(wq.push(3 * H, H, M, op(ws + w.dqkv, es, 0, 3 * H, 0), op(ws + lw.xb, es, 0, H, 0), grads + lo.inw, H));
             TRY(wq.flush());
             {   // d x = dqkv W_in + d r1
-                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.inw), es, 0, H, 0), dY, H, NBCI_F32);
-                d.residual = dR; d.ldr = H;
+                nbci_gemm_desc d = gd(M, H, 3 * H, dt, op(ws + w.dqkv, es, 0, 3 * H, 1), op(x.W(lo.inw), es, 0, H, 0), dY, H, xdt);
+                d.residual = dR; d.ldr = H; d.residual_dtype = xdt;
                 TRY(gemm_launch_timed(d, s));
             }
         } else {
@@ -511,7 +521,7 @@ int itr_backward(const ItrPlan& p, const float* params, const void* params_lp, c
             const int64_t* ss = io->spikes_spacestamp ? io->spikes_spacestamp : (const int64_t*)(ws + w.ssidx);
             TRY(itr_assemble_bwd_launch(dY, dtok, c.max_n_channels > 0 ? (float*)(ws + w.dchtab) : nullptr, ss,
                                         c.n_regions > 0 ? (float*)(ws + w.drgtab) : nullptr, io->region_idx,
-                                        c.use_cls ? RG(p.cls) : nullptr, rc, B, N, H, c.use_cls ? 1 : 0, pe, io->seed, 6, s));
+                                        c.use_cls ? RG(p.cls) : nullptr, rc, B, N, H, c.use_cls ? 1 : 0, pe, io->seed, 6, s, xdt));
             // embed.1 LayerNorm; its output gradient feeds embed.0.3 through the MLP's trailing Dropout (site 5)
             TRY(layernorm_bwd_launch(dtok, (const float*)(ws + w.t2), params + p.enw, (const float*)(ws + w.mean_e),
                                      (const float*)(ws + w.rstd_e), dR, RG(p.enw), RG(p.enb), M0, H, 0, s, rc, cast_to(w.cA, pe, 5, p.e3b)));
@@ -559,6 +569,8 @@ int nbci_itr_plan_create(const nbci_itr_config* cfg, nbci_itr_plan* out) {
     NBCI_REQUIRE(c.max_n_bins > 0 && c.max_n_bins % 4 == 0, NBCI_ESHAPE, "max_n_bins must be a positive multiple of 4");
     NBCI_REQUIRE(c.n_layers >= 0 && c.max_n_channels >= 0 && c.n_regions >= 0, NBCI_ESHAPE, "bad iTransformer shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.residual_dtype == NBCI_F32 || (c.residual_dtype == NBCI_BF16 && c.dtype == NBCI_BF16), NBCI_EINVAL,
+                 "residual_dtype must be f32, or bf16 together with dtype bf16");
     NBCI_REQUIRE(c.act == ACT_RELU && (!c.mlp_decoder || c.dec_act == ACT_RELU), NBCI_EINVAL,
                  "iTransformer HIP path supports activation: relu (the backward reads act' off the saved outputs)");
     NBCI_REQUIRE(c.loss >= NBCI_LOSS_POISSON_LOG && c.loss <= NBCI_LOSS_MSE, NBCI_EINVAL, "unknown loss");

@@ -124,9 +124,9 @@ int btn_to_bnt_launch(const float* in, float* out, int B, int T, int N, hipStrea
 int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, const float* tab1, const int64_t* idx1, const float* tab2,
                             const int64_t* idx2, const float* cls, float* x32, void* xb, int xb_dtype, float* mean, float* rstd, int B,
                             int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
-int itr_assemble_bwd_launch(const float* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
+int itr_assemble_bwd_launch(const void* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
                             float* dcls, RepCfg rc, int B, int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site,
-                            hipStream_t s);
+                            hipStream_t s, int dx_dtype = NBCI_F32);
 int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const int64_t* mask, const int64_t* smask, float* preds_out,
                         int64_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int N, int use_cls,
                         int kind, float grad_scale, hipStream_t s);

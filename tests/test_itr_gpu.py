@@ -181,23 +181,27 @@ def test_fp32_matches_reference_golden_c3_and_bf16_close(name):
         ref = fx["gval:" + k]
         got = g[k].reshape(-1)[fx["gidx:" + k]]
         np.testing.assert_allclose(got, ref, atol=2e-5 + 2e-3 * max(np.abs(ref).max(), fx["gsum:" + k][1] / g[k].size), err_msg=k)
-    # bf16 operands (f32 accumulate) stay close to the fp32 path
-    mb = _model(fx, dtype="bf16").to(DEV)
-    mb.eval()
-    mb.mask_override = torch.from_numpy(fx["eval_raw_mask"])
-    with torch.no_grad():
-        ob = mb(**batch)
-    assert np.abs(ob.preds.cpu().numpy() - p32).max() < 0.08
-    np.testing.assert_allclose(float(ob.loss), float(out.loss), rtol=2e-2)
-    mb.mask_override = torch.from_numpy(fx["raw_mask_step0"])
-    _, _, gb = _grads_of(mb, batch)
-    for k in g:
-        num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
-        assert num / den < 0.06, (k, num / den)
+    # bf16 operands (f32 accumulate) stay close to the fp32 path - with the LayerNorm inputs / gradient streams stored in f32 and in bf16
+    for streams in ("fp32", "bf16"):
+        mb = _model(fx, dtype="bf16", residual_dtype=streams).to(DEV)
+        mb.eval()
+        mb.mask_override = torch.from_numpy(fx["eval_raw_mask"])
+        with torch.no_grad():
+            ob = mb(**batch)
+        assert np.abs(ob.preds.cpu().numpy() - p32).max() < 0.08, streams
+        np.testing.assert_allclose(float(ob.loss), float(out.loss), rtol=2e-2)
+        mb.mask_override = torch.from_numpy(fx["raw_mask_step0"])
+        _, _, gb = _grads_of(mb, batch)
+        for k in g:
+            num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
+            # f32 streams: 6 % (measured margin of round 1); bf16 streams: the 8 % every other bf16 gradient test of this repo carries
+            # (worst here: the channel table's LayerNorm weight, 6.7 % - a small gradient summed over few rows)
+            assert num / den < (0.06 if streams == "fp32" else 0.08), (streams, k, num / den)
 
 
 # ----------------------------------------------------------------------------------------------- train mode vs oracle
-@pytest.mark.parametrize("dtype,N,lens", [("fp32", 10, [12, 9, 7]), ("fp32", 70, [12, 12, 5, 3]), ("bf16", 70, [12, 12, 5, 3])])
+@pytest.mark.parametrize("dtype,N,lens", [("fp32", 10, [12, 9, 7]), ("fp32", 70, [12, 12, 5, 3]), ("bf16", 70, [12, 12, 5, 3]),
+                                          ("bf16/f32 streams", 70, [12, 12, 5, 3])])
 def test_train_mode_dropout_and_maskers_match_oracle(dtype, N, lens):
     """recipe-style step: masker on (device RNG), dropout 0.2 / 0.4 on; the oracle mirrors every draw."""
     from llm_bci_amd.itransformer import SITE_MASKER
@@ -205,7 +209,9 @@ def test_train_mode_dropout_and_maskers_match_oracle(dtype, N, lens):
     mc = dict(active=True, force_active=True, mode="neuron", ratio=0.3, zero_ratio=0.8, random_ratio=0.5, expand_prob=0.0, max_timespan=1)
     over = {"encoder": {"embedder": {"max_n_bins": T, "dropout": 0.2}, "hidden_size": 32, "n_heads": 2, "n_layers": 2, "dropout": 0.4,
                         "max_n_channels": 96, "embed_region": False}, "masker": {"main": mc}}
-    m = _model(over, dtype=dtype).to(DEV)
+    kw = {"residual_dtype": "fp32"} if dtype.endswith("f32 streams") else {}   # ("bf16": the default, bf16 streams)
+    dtype = dtype.split("/")[0]
+    m = _model(over, dtype=dtype, **kw).to(DEV)
     p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     g = np.random.default_rng(5)
     spikes = g.poisson(0.7, (B, T, N)).astype(np.float32)
