@@ -524,6 +524,9 @@ typedef struct nbci_ptst_config { /* configs/patchtst.yaml, flattened */
     int32_t dtype;
     int32_t fp8_qkv;                   /* 1: the q / k / v projections of the FORWARD run on the block-scaled fp8 matrix instruction
                                           (MX e4m3, see nbci_gemm_fp8); needs dtype = NBCI_BF16 and d_model % 128 == 0 */
+    int32_t residual_dtype;            /* storage of the residual stream (the saved BatchNorm inputs) and of its gradient stream between kernels:
+                                          NBCI_F32 (default), or NBCI_BF16 (dtype bf16 only; f32 arithmetic, one rounding per store; the
+                                          data-gradient GEMMs then hand BatchNorm's backward a bf16 gradient as well). hidden_out stays f32. */
 } nbci_ptst_config;
 
 typedef struct nbci_ptst_io {

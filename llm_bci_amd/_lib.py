@@ -100,7 +100,7 @@ class PtstConfig(C.Structure):
         (n, C.c_float) for n in ("norm_eps", "attention_dropout", "positional_dropout", "path_dropout", "ff_dropout")] + [
         ("act", C.c_int32), ("do_mask_input", C.c_int32), ("random_mask_ratio", C.c_double), ("channel_consistent_masking", C.c_int32),
         ("mask_value", C.c_float), ("method", C.c_int32), ("vocab", C.c_int32), ("blank_id", C.c_int32), ("zero_infinity", C.c_int32),
-        ("mlp_decoder", C.c_int32), ("dec_act", C.c_int32), ("loss", C.c_int32), ("dtype", C.c_int32), ("fp8_qkv", C.c_int32)]
+        ("mlp_decoder", C.c_int32), ("dec_act", C.c_int32), ("loss", C.c_int32), ("dtype", C.c_int32), ("fp8_qkv", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
 class PtstIO(C.Structure):

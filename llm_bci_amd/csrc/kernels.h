@@ -65,8 +65,8 @@ int softmax_bwd_launch(const float* dPd, const void* P, void* dS, int p_dtype, i
 int dropcast_launch(const float* in, void* out, int out_dtype, int64_t n, float drop_p, uint32_t seed,
                     uint32_t site, hipStream_t s);
 // 2-D form with the bias-gradient column sum fused in: colsum[n] += sum_m out[m][n] (may be NULL)
-int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed,
-                      uint32_t site, float* colsum, hipStream_t s, RepCfg rc = RepCfg{0, 1});
+int dropcast2d_launch(const void* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed,
+                      uint32_t site, float* colsum, hipStream_t s, RepCfg rc = RepCfg{0, 1}, int in_dtype = NBCI_F32);   // in: f32, or a bf16 stream
 // out[n] += sum_m in[m][n]  (bias gradients)
 int colsum_launch(const void* in, int in_dtype, int64_t ld, int M, int N, float* out, hipStream_t s,
                   RepCfg rc = RepCfg{0, 1});
@@ -135,17 +135,20 @@ int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const 
 int ptst_mask_launch(uint8_t* mask, int B, int C, int P, double ratio, int channel_consistent, uint32_t seed, uint32_t site, hipStream_t s);
 int ptst_patchify_launch(const float* x, float* patch, float* xm, const uint8_t* mask, int B, int T, int C, int P, int pl, int stride,
                          int start, float mask_value, hipStream_t s);
-int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, float* h, long long M, int P, int pl, int D,
-                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, void* h, long long M, int P, int pl, int D,
+                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s, int h_dtype = NBCI_F32);
 size_t bn_partial_floats(long long M, int D);
-int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
-                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8 = nullptr, void* q8_scales = nullptr);
-int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
-                         float* partials, float* sums /* 3 D floats: the second pass's per-column coefficients */, long long M, int D, int train, hipStream_t s);
+// x (and in the backward the gradient stream dx): f32, or bf16 (nbci_ptst_config.residual_dtype); dy: f32, or bf16 as a bf16 GEMM writes it
+int batchnorm_fwd_launch(const void* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8 = nullptr, void* q8_scales = nullptr,
+                         int x_dtype = NBCI_F32);
+int batchnorm_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
+                         float* partials, float* sums /* 3 D floats: the second pass's per-column coefficients */, long long M, int D, int train, hipStream_t s,
+                         int dy_dtype = NBCI_F32, int stream_dtype = NBCI_F32);
 // dW[D][pl] += de^T xm over all M rows (f32; the shared patch embedding's weight gradient as a streaming reduction)
 int ptst_embed_wgrad_launch(const float* de, const float* xm, float* dW, long long M, int pl, int D, hipStream_t s);
-int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s);
-int ptst_pool_bwd_launch(const float* dpooled, float* dh, int B, int C, int P, int D, hipStream_t s);
+int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype = NBCI_F32);
+int ptst_pool_bwd_launch(const float* dpooled, void* dh, int B, int C, int P, int D, hipStream_t s, int dh_dtype = NBCI_F32);
 int ptst_lens_launch(const int64_t* lens, int32_t* out, int B, int pl, int stride, hipStream_t s);
 int ptst_mlm_loss_launch(const float* pred, int ldp, const float* target, const uint8_t* mask, const int64_t* smask, float* preds_out,
                          uint8_t* mask_out, void* dpred, int d_dtype, float* loss, int64_t* n_examples, int B, int T, int C, int P, int pl,

@@ -152,26 +152,6 @@ int token_prep_launch(const int64_t* mask, const int64_t* ts, const int64_t* len
     return check_launch("token_prep");
 }
 
-// four consecutive elements of a row as f32: an f32 row, or a bf16 one (a bf16 residual stream: half the bytes, widened here)
-template <typename T>
-__device__ __forceinline__ float4 ld4f(const T* p) {
-    if constexpr (sizeof(T) == 4) {
-        return *(const float4*)p;
-    } else {
-        const bf16x4 t = *(const bf16x4*)p;
-        return make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3]));
-    }
-}
-template <typename T>
-__device__ __forceinline__ void st4f(T* p, const float4& v) {
-    if constexpr (sizeof(T) == 4) {
-        *(float4*)p = v;
-    } else {
-        const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
-        *(bf16x4*)p = o;
-    }
-}
-
 // prefix tokens, forward: x (B, npre + Tp, H) = [table0[idx0[b]], (table1[idx1[b]]), xtok[b, :]] then the embedder dropout over ALL of
 // it (ndt1.py:192-203), dropout stream index = element offset in x
 template <typename T>   // T: storage type of x (f32, or a bf16 residual stream)
@@ -634,8 +614,8 @@ constexpr int DC_ROWS = 8;  // rows per block: all 8 row loads of a thread are i
 
 // out = in * keepmask (act dtype), optionally colsum[n] += sum_m out[m][n]. One thread owns 4
 // consecutive columns of DC_ROWS rows, so the bias-gradient column sums cost one atomic per column per block.
-template <typename TO>
-__global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__ in, TO* __restrict__ out, int M, int N,
+template <typename TO, typename TI>
+__global__ __launch_bounds__(256) void dropcast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int M, int N,
                                                        unsigned thr, float dscale, uint32_t key, float* __restrict__ colsum, RepCfg rc,
                                                        int cpt, int gpb) {
     // cpt = column-threads per row (N / 4, at most 256 per block), gpb = row groups per block (narrow matrices keep all
@@ -650,7 +630,7 @@ __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__
         float4 q[DC_ROWS];
 #pragma unroll
         for (int j = 0; j < DC_ROWS; ++j)
-            q[j] = (r0 + j < M) ? *(const float4*)(in + (r0 + j) * N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[j] = (r0 + j < M) ? ld4f(in + (r0 + j) * N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < DC_ROWS; ++j) {
             if (r0 + j >= M) break;
@@ -682,17 +662,23 @@ __global__ __launch_bounds__(256) void dropcast_kernel(const float* __restrict__
     }
 }
 
-int dropcast2d_launch(const float* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed, uint32_t site,
-                      float* colsum, hipStream_t s, RepCfg rc) {
+int dropcast2d_launch(const void* in, void* out, int out_dtype, int M, int N, float drop_p, uint32_t seed, uint32_t site,
+                      float* colsum, hipStream_t s, RepCfg rc, int in_dtype) {
     NBCI_REQUIRE(N % 4 == 0, NBCI_ESHAPE, "dropcast: N must be a multiple of 4");
     const unsigned thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int cpt = std::min(256, N / 4), gpb = std::max(1, 256 / cpt);
     const long long groups = ((long long)M + DC_ROWS - 1) / DC_ROWS;
     dim3 g((N / 4 + cpt - 1) / cpt, (unsigned)std::min<long long>((groups + gpb - 1) / gpb, 4096));
-    DISPATCH_DTYPE(out_dtype, TO,
-                   hipLaunchKernelGGL((dropcast_kernel<TO>), g, dim3(256), 0, s, in, (TO*)out, M, N, thr, dscale,
-                                      drop_key(seed, site), colsum, rc, cpt, gpb));
+    if (in_dtype == NBCI_BF16) {
+        DISPATCH_DTYPE(out_dtype, TO,
+                       hipLaunchKernelGGL((dropcast_kernel<TO, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)in, (TO*)out, M, N, thr, dscale,
+                                          drop_key(seed, site), colsum, rc, cpt, gpb));
+    } else {
+        DISPATCH_DTYPE(out_dtype, TO,
+                       hipLaunchKernelGGL((dropcast_kernel<TO, float>), g, dim3(256), 0, s, (const float*)in, (TO*)out, M, N, thr, dscale,
+                                          drop_key(seed, site), colsum, rc, cpt, gpb));
+    }
     return check_launch("dropcast");
 }
 

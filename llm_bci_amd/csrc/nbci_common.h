@@ -80,6 +80,26 @@ int available_cus();
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 
+// four consecutive elements of a row as f32: an f32 row, or a bf16 one (a bf16 residual stream: half the bytes, widened here)
+template <typename T>
+__device__ __forceinline__ float4 ld4f(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *(const float4*)p;
+    } else {
+        const bf16x4 t = *(const bf16x4*)p;
+        return make_float4(bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3]));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4f(T* p, const float4& v) {
+    if constexpr (sizeof(T) == 4) {
+        *(float4*)p = v;
+    } else {
+        const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+        *(bf16x4*)p = o;
+    }
+}
+
 // ---- stateless counter RNG -------------------------------------------------------
 // One 32-bit draw per (seed, site, element index). "site" separates the dropout /
 // noise call sites of one train step; the backward pass regenerates the same bits.

@@ -131,6 +131,7 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     const auto& c = p.c;
     NBCI_REQUIRE(B > 0, NBCI_ESHAPE, "patchtst: B must be positive");
     const size_t es = c.dtype == NBCI_BF16 ? 2 : 4;
+    const size_t rs = c.residual_dtype == NBCI_BF16 ? 2 : 4;   // the residual stream (saved BatchNorm inputs) and its gradient stream
     const size_t C = c.num_input_channels, P = p.P, D = c.d_model, F = c.ffn_dim, pl = c.patch_length, nh = c.num_attention_heads;
     const size_t M = (size_t)B * C * P;
     NBCI_REQUIRE(M * F < (1ull << 32) && (size_t)B * C * nh * P * P < (1ull << 32), NBCI_ESHAPE,
@@ -153,7 +154,7 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     const size_t nP = w.small_attn ? 0 : (size_t)B * C * nh * P * w.ldP;
     const size_t nstat = sattn_stat_floats(B * (int)C, (int)nh, (int)P);
     for (auto& l : w.L) {
-        l.x_in = bump(cur, M * D * 4);
+        l.x_in = bump(cur, M * D * rs);
         l.mean1 = bump(cur, D * 4); l.rstd1 = bump(cur, D * 4);
         l.y1 = bump(cur, M * D * es);
         l.qkv = bump(cur, M * 3 * D * es);
@@ -161,13 +162,13 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
         l.Pd = bump(cur, nP * es);
         l.ad = bump(cur, M * D * es);
         l.lse = bump(cur, nstat * 4);
-        l.x_mid = bump(cur, M * D * 4);
+        l.x_mid = bump(cur, M * D * rs);
         l.mean3 = bump(cur, D * 4); l.rstd3 = bump(cur, D * 4);
         l.y3 = bump(cur, M * D * es);
         l.u = bump(cur, M * F * es);
         l.g = bump(cur, M * F * es);
     }
-    w.x_last = bump(cur, M * D * 4);
+    w.x_last = bump(cur, M * D * rs);
     const size_t Mh = w.Mh;
     w.pooled = bump(cur, Mh * D * es);
     w.d1 = bump(cur, Mh * D * es);
@@ -182,8 +183,8 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.dsum = bump(cur, nstat * 4);
     w.bnpart = bump(cur, bn_partial_floats((long long)M, (int)D) * 4);
     w.bnsums = bump(cur, 3 * D * 4);   // per-column coefficients of the BatchNorm backward's second pass
-    w.dx = bump(cur, M * D * 4);
-    w.dtmp = bump(cur, M * D * 4);
+    w.dx = bump(cur, M * D * rs);
+    w.dtmp = bump(cur, M * D * 4);   // (f32-sized: also the f32 d(embedding output) of the patch embedding's backward)
     w.cA = bump(cur, M * D * es);
     w.cA2 = bump(cur, M * D * es);
     w.dU = bump(cur, M * F * es);
@@ -239,6 +240,8 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
     const long long M = w.M;
     const int Mi = (int)M;
     const int dt = c.dtype;
+    const int xdt = c.residual_dtype;   // storage of the residual stream between kernels (every kernel widens it and computes in f32)
+    const bool rb = xdt == NBCI_BF16;
     const size_t es = dt == NBCI_BF16 ? 2 : 4;
     const void* pw = dt == NBCI_BF16 ? params_lp : (const void*)params;
     auto W = [&](int64_t off) -> const void* { return (const char*)pw + off * (int64_t)es; };
@@ -260,18 +263,18 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
     }
     float* patch = io->patch_input ? io->patch_input : (float*)(ws + w.patch);
     TRY(ptst_patchify_launch(io->spikes, patch, (float*)(ws + w.xm), mask, B, T, C, P, pl, c.patch_stride, p.start, c.mask_value, s));
-    float* x_cur = (float*)(ws + (L ? w.L[0].x_in : w.x_last));
-    TRY(ptst_embed_launch((const float*)(ws + w.xm), params + p.embw, params + p.embb, aux.pos, x_cur, M, P, pl, D, ppos, io->seed, 4, s));
+    void* x_cur = ws + (L ? w.L[0].x_in : w.x_last);
+    TRY(ptst_embed_launch((const float*)(ws + w.xm), params + p.embw, params + p.embb, aux.pos, x_cur, M, P, pl, D, ppos, io->seed, 4, s, xdt));
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < L; ++l) {
         const PtLayerWS& lw = w.L[l];
         const PtLayerOff& lo = p.L[l];
-        float* x_in = (float*)(ws + lw.x_in);
-        float* x_mid = (float*)(ws + lw.x_mid);
-        float* x_out = (float*)(ws + (l + 1 < L ? w.L[l + 1].x_in : w.x_last));
+        void* x_in = ws + lw.x_in;
+        void* x_mid = ws + lw.x_mid;
+        void* x_out = ws + (l + 1 < L ? w.L[l + 1].x_in : w.x_last);
         TRY(batchnorm_fwd_launch(x_in, params + lo.n1w, params + lo.n1b, aux.rm1(l), aux.rv1(l), train, c.norm_eps, ws + lw.y1, dt,
                                  (float*)(ws + lw.mean1), (float*)(ws + lw.rstd1), (float*)(ws + w.bnpart), M, D, s,
-                                 c.fp8_qkv ? ws + w.y1q : nullptr, c.fp8_qkv ? ws + w.y1s : nullptr));
+                                 c.fp8_qkv ? ws + w.y1q : nullptr, c.fp8_qkv ? ws + w.y1s : nullptr, xdt));
         if (c.fp8_qkv) {   // q / k / v on the block-scaled fp8 matrix instruction (fp8.hip); y1 stays in bf16 for the weight gradient
             TRY(mx_quantize_launch(params + lo.qw, NBCI_F32, D, ws + w.wq8, ws + w.wq8s, 3 * D, D, s));   // from the f32 master weights
             TRY(gemm_fp8_launch(ws + w.y1q, ws + w.y1s, ws + w.wq8, ws + w.wq8s, params + lo.qb, ws + lw.qkv, dt, M, 3 * D, D, 3 * D, s));
@@ -301,29 +304,32 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
         }
         }
         {   // x_mid = x_in + path_dropout(out_proj(a))
-            nbci_gemm_desc d = gd(Mi, D, D, dt, op(ws + lw.ad, es, 0, D, 1), op(W(lo.ow), es, 0, D, 1), x_mid, D, NBCI_F32);
-            d.bias = params + lo.ob; d.drop_p = pp; d.seed = io->seed; d.site = 17 + 4 * l; d.residual = x_in; d.ldr = D;
+            nbci_gemm_desc d = gd(Mi, D, D, dt, op(ws + lw.ad, es, 0, D, 1), op(W(lo.ow), es, 0, D, 1), x_mid, D, xdt);
+            d.bias = params + lo.ob; d.drop_p = pp; d.seed = io->seed; d.site = 17 + 4 * l; d.residual = x_in; d.ldr = D; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
         TRY(batchnorm_fwd_launch(x_mid, params + lo.n3w, params + lo.n3b, aux.rm3(l), aux.rv3(l), train, c.norm_eps, ws + lw.y3, dt,
-                                 (float*)(ws + lw.mean3), (float*)(ws + lw.rstd3), (float*)(ws + w.bnpart), M, D, s));
+                                 (float*)(ws + lw.mean3), (float*)(ws + lw.rstd3), (float*)(ws + w.bnpart), M, D, s, nullptr, nullptr, xdt));
         {   // g = ff_dropout(act(ff.0(y3))); lw.u keeps act'(u) for the backward gate
             nbci_gemm_desc d = gd(Mi, F, D, dt, op(ws + lw.y3, es, 0, D, 1), op(W(lo.f0w), es, 0, D, 1), ws + lw.g, F, dt);
             d.bias = params + lo.f0b; d.act = c.act; d.C2 = ws + lw.u; d.c2_grad = 1; d.drop_p = pf; d.seed = io->seed; d.site = 18 + 4 * l;
             TRY(gemm_launch_timed(d, s));
         }
         {
-            nbci_gemm_desc d = gd(Mi, D, F, dt, op(ws + lw.g, es, 0, F, 1), op(W(lo.f3w), es, 0, F, 1), x_out, D, NBCI_F32);
-            d.bias = params + lo.f3b; d.drop_p = pp; d.seed = io->seed; d.site = 19 + 4 * l; d.residual = x_mid; d.ldr = D;
+            nbci_gemm_desc d = gd(Mi, D, F, dt, op(ws + lw.g, es, 0, F, 1), op(W(lo.f3w), es, 0, F, 1), x_out, D, xdt);
+            d.bias = params + lo.f3b; d.drop_p = pp; d.seed = io->seed; d.site = 19 + 4 * l; d.residual = x_mid; d.ldr = D; d.residual_dtype = xdt;
             TRY(gemm_launch_timed(d, s));
         }
     }
     if (train && L > 0) hipLaunchKernelGGL(pt_nbt_kernel, dim3(1), dim3(256), 0, s, (long long*)io->nbt, 2 * L);
-    const float* h = (const float*)(ws + w.x_last);
-    if (io->hidden_out) NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, h, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+    const void* h = ws + w.x_last;
+    if (io->hidden_out) {   // (B,C,P,D) f32 whatever the stream's storage
+        if (rb) TRY(dropcast2d_launch(h, io->hidden_out, NBCI_F32, Mi, D, 0.f, 0, 0, nullptr, s, RepCfg{0, 1}, NBCI_BF16));
+        else NBCI_CHECK_HIP(hipMemcpyAsync(io->hidden_out, h, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+    }
     if (c.method == NBCI_PTST_CTC) {
         const int Mh = w.Mh;
-        TRY(ptst_pool_fwd_launch(h, ws + w.pooled, dt, B, C, P, D, s));
+        TRY(ptst_pool_fwd_launch(h, ws + w.pooled, dt, B, C, P, D, s, xdt));
         const void* src = ws + w.pooled;
         int64_t ow = p.d0w, ob = p.d0b;
         if (c.mlp_decoder) {
@@ -348,9 +354,9 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
         }
     } else {
         NBCI_REQUIRE(mask, NBCI_EINVAL, "Can't pretrain with inactive masking");   // patchtst.py:193
-        // PretrainHead operands must be in the GEMM dtype: BatchNorm-free cast of the last hidden state
-        TRY(cast_launch(h, ws + w.pooled, dt, M * D, s));
-        const void* src = ws + w.pooled;
+        // PretrainHead operands must be in the GEMM dtype: BatchNorm-free cast of the last hidden state (a bf16 stream IS in that dtype)
+        if (!rb) TRY(cast_launch((const float*)h, ws + w.pooled, dt, M * D, s));
+        const void* src = rb ? h : (const void*)(ws + w.pooled);
         int64_t ow = p.d0w, ob = p.d0b;
         if (c.mlp_decoder) {
             nbci_gemm_desc d = gd(Mi, D, D, dt, op(src, es, 0, D, 1), op(W(p.d0w), es, 0, D, 1), ws + w.d1, D, dt);
@@ -394,7 +400,10 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
     const float pa = train ? c.attention_dropout : 0.f, pp = train ? c.path_dropout : 0.f, pf = train ? c.ff_dropout : 0.f,
                 ppos = train ? c.positional_dropout : 0.f;
     char* ws = (char*)io->workspace;
-    float* dx = (float*)(ws + w.dx);
+    const int xdt = c.residual_dtype;   // storage of the residual stream AND of its gradient stream dx
+    const bool rb = xdt == NBCI_BF16;
+    const int gdt = rb ? dt : NBCI_F32;   // what the data-gradient GEMMs hand BatchNorm's backward (dtmp): bf16 with bf16 streams
+    float* dx = (float*)(ws + w.dx);      // (bf16 elements when rb)
     float* dtmp = (float*)(ws + w.dtmp);
     const float scale = 1.0f / sqrtf((float)hd);
     float* rep = (float*)(ws + w.rep);
@@ -407,9 +416,11 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             const bool ctc = c.method == NBCI_PTST_CTC;
             const void* dl = ctc ? ws + w.dlogits : ws + w.dpred;
             const int ldl = ctc ? w.vpad : w.ldp, nout = p.nout;
-            const void* src = c.mlp_decoder ? ws + w.d1 : ws + w.pooled;
+            const void* head_in = (!ctc && rb) ? ws + w.x_last : ws + w.pooled;   // (mlm with a bf16 stream: the head read the stream itself)
+            const void* src = c.mlp_decoder ? ws + w.d1 : head_in;
             const int64_t ow = c.mlp_decoder ? p.d2w : p.d0w, ob = c.mlp_decoder ? p.d2b : p.d0b;
             float* dsrc = ctc ? (float*)(ws + w.dpool) : dx;   // mlm: the head's input gradient IS the stream gradient
+            const int dsdt = ctc ? NBCI_F32 : xdt;             // (the pooled gradient stays f32: B*P rows)
             TRY(colsum_launch(dl, dt, ldl, Mh, nout, RG(ob), s, rc));
             TRY(wgrad(s, dt, nout, D, Mh, op(dl, es, 0, ldl, 0), op(src, es, 0, D, 0), grads + ow, D));
             if (c.mlp_decoder) {
@@ -419,21 +430,21 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
                     d.colsum = RG(p.d0b); d.colsum_rep_stride = rc.stride; d.colsum_nrep = rc.n;
                     TRY(gemm_launch_timed(d, s));
                 }
-                TRY(wgrad(s, dt, D, D, Mh, op(ws + w.cA2, es, 0, D, 0), op(ws + w.pooled, es, 0, D, 0), grads + p.d0w, D));
-                nbci_gemm_desc d = gd(Mh, D, D, dt, op(ws + w.cA2, es, 0, D, 1), op(W(p.d0w), es, 0, D, 0), dsrc, D, NBCI_F32);
+                TRY(wgrad(s, dt, D, D, Mh, op(ws + w.cA2, es, 0, D, 0), op(head_in, es, 0, D, 0), grads + p.d0w, D));
+                nbci_gemm_desc d = gd(Mh, D, D, dt, op(ws + w.cA2, es, 0, D, 1), op(W(p.d0w), es, 0, D, 0), dsrc, D, dsdt);
                 TRY(gemm_launch_timed(d, s));
             } else {
-                nbci_gemm_desc d = gd(Mh, D, nout, dt, op(dl, es, 0, ldl, 1), op(W(p.d0w), es, 0, D, 0), dsrc, D, NBCI_F32);
+                nbci_gemm_desc d = gd(Mh, D, nout, dt, op(dl, es, 0, ldl, 1), op(W(p.d0w), es, 0, D, 0), dsrc, D, dsdt);
                 TRY(gemm_launch_timed(d, s));
             }
-            if (ctc) TRY(ptst_pool_bwd_launch(dsrc, dx, B, C, P, D, s));
+            if (ctc) TRY(ptst_pool_bwd_launch(dsrc, dx, B, C, P, D, s, xdt));
         } else if (seg >= 1) {
             const int l = seg - 1;
             const PtLayerWS& lw = w.L[l];
             const PtLayerOff& lo = p.L[l];
             WgradQueue wq; wq.dtype = dt; wq.s = s;
             // ---- x_out = x_mid + path_drop(ff.3(ff_drop(act(ff.0(BN3(x_mid))))))
-            TRY(dropcast2d_launch(dx, ws + w.cA, dt, Mi, D, pp, io->seed, 19 + 4 * l, RG(lo.f3b), s, rc));
+            TRY(dropcast2d_launch(dx, ws + w.cA, dt, Mi, D, pp, io->seed, 19 + 4 * l, RG(lo.f3b), s, rc, xdt));
             TRY(wq.push(D, F, Mi, op(ws + w.cA, es, 0, D, 0), op(ws + lw.g, es, 0, F, 0), grads + lo.f3w, F));
             {
                 nbci_gemm_desc d = gd(Mi, F, D, dt, op(ws + w.cA, es, 0, D, 1), op(W(lo.f3w), es, 0, F, 0), ws + w.dU, F, dt);
@@ -443,14 +454,14 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             }
             TRY(wq.push(F, D, Mi, op(ws + w.dU, es, 0, F, 0), op(ws + lw.y3, es, 0, D, 0), grads + lo.f0w, D));
             {
-                nbci_gemm_desc d = gd(Mi, D, F, dt, op(ws + w.dU, es, 0, F, 1), op(W(lo.f0w), es, 0, D, 0), dtmp, D, NBCI_F32);
+                nbci_gemm_desc d = gd(Mi, D, F, dt, op(ws + w.dU, es, 0, F, 1), op(W(lo.f0w), es, 0, D, 0), dtmp, D, gdt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(batchnorm_bwd_launch(dtmp, (const float*)(ws + lw.x_mid), (const float*)(ws + lw.mean3), (const float*)(ws + lw.rstd3),
+            TRY(batchnorm_bwd_launch(dtmp, ws + lw.x_mid, (const float*)(ws + lw.mean3), (const float*)(ws + lw.rstd3),
                                      params + lo.n3w, dx, grads + lo.n3w, grads + lo.n3b, (float*)(ws + w.bnpart), (float*)(ws + w.bnsums), M, D,
-                                     train, s));
+                                     train, s, gdt, xdt));
             // ---- x_mid = x_in + path_drop(out_proj(MHA(BN1(x_in))))
-            TRY(dropcast2d_launch(dx, ws + w.cA2, dt, Mi, D, pp, io->seed, 17 + 4 * l, RG(lo.ob), s, rc));
+            TRY(dropcast2d_launch(dx, ws + w.cA2, dt, Mi, D, pp, io->seed, 17 + 4 * l, RG(lo.ob), s, rc, xdt));
             TRY(wq.push(D, D, Mi, op(ws + w.cA2, es, 0, D, 0), op(ws + lw.ad, es, 0, D, 0), grads + lo.ow, D));
             {
                 nbci_gemm_desc d = gd(Mi, D, D, dt, op(ws + w.cA2, es, 0, D, 1), op(W(lo.ow), es, 0, D, 0), ws + w.dAtt, D, dt);
@@ -498,17 +509,17 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             TRY(wq.push(3 * D, D, Mi, op(ws + w.dqkv, es, 0, 3 * D, 0), op(ws + lw.y1, es, 0, D, 0), grads + lo.qw, D));
             TRY(wq.flush());
             {
-                nbci_gemm_desc d = gd(Mi, D, 3 * D, dt, op(ws + w.dqkv, es, 0, 3 * D, 1), op(W(lo.qw), es, 0, D, 0), dtmp, D, NBCI_F32);
+                nbci_gemm_desc d = gd(Mi, D, 3 * D, dt, op(ws + w.dqkv, es, 0, 3 * D, 1), op(W(lo.qw), es, 0, D, 0), dtmp, D, gdt);
                 TRY(gemm_launch_timed(d, s));
             }
-            TRY(batchnorm_bwd_launch(dtmp, (const float*)(ws + lw.x_in), (const float*)(ws + lw.mean1), (const float*)(ws + lw.rstd1),
+            TRY(batchnorm_bwd_launch(dtmp, ws + lw.x_in, (const float*)(ws + lw.mean1), (const float*)(ws + lw.rstd1),
                                      params + lo.n1w, dx, grads + lo.n1w, grads + lo.n1b, (float*)(ws + w.bnpart), (float*)(ws + w.bnsums), M, D,
-                                     train, s));
+                                     train, s, gdt, xdt));
         } else {
             // ---- shared patch embedding (positions are fixed): K = patch_length, runs on the exact-f32 path
             const float* de = dx;
-            if (ppos > 0.f) {
-                TRY(dropcast2d_launch(dx, dtmp, NBCI_F32, Mi, D, ppos, io->seed, 4, RG(p.embb), s, rc));
+            if (ppos > 0.f || rb) {   // (a bf16 stream is widened on the way: the K = all-rows weight gradient below reads f32)
+                TRY(dropcast2d_launch(dx, dtmp, NBCI_F32, Mi, D, ppos, io->seed, 4, RG(p.embb), s, rc, xdt));
                 de = dtmp;
             } else {
                 TRY(colsum_launch(dx, NBCI_F32, D, Mi, D, RG(p.embb), s, rc));
@@ -540,6 +551,8 @@ int nbci_ptst_plan_create(const nbci_ptst_config* cfg, nbci_ptst_plan* out) {
     NBCI_REQUIRE(c.patch_length <= 32, NBCI_ESHAPE, "patch_length must be <= 32");
     NBCI_REQUIRE(c.num_input_channels > 0 && c.num_hidden_layers >= 0, NBCI_ESHAPE, "bad PatchTST shape parameters");
     NBCI_REQUIRE(c.dtype == NBCI_F32 || c.dtype == NBCI_BF16, NBCI_EINVAL, "dtype must be f32 or bf16");
+    NBCI_REQUIRE(c.residual_dtype == NBCI_F32 || (c.residual_dtype == NBCI_BF16 && c.dtype == NBCI_BF16), NBCI_EINVAL,
+                 "residual_dtype must be f32, or bf16 together with dtype bf16");
     NBCI_REQUIRE(c.method == NBCI_PTST_CTC || c.method == NBCI_PTST_MLM, NBCI_EINVAL, "Method not implemented yet for PatchTST");
     NBCI_REQUIRE(c.method != NBCI_PTST_CTC || (c.vocab > 0 && c.blank_id >= 0 && c.blank_id < c.vocab), NBCI_EINVAL, "bad vocab / blank_id");
     NBCI_REQUIRE(c.method != NBCI_PTST_MLM || c.do_mask_input, NBCI_EINVAL, "Can't pretrain with inactive masking");

@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void ptst_embed_kernel(const float* __restrict
 // of the row: one cache line) and one float4 of the position table. The per-output version above issues ~64 load instructions per four
 // outputs (2.0 ms at 420 k rows x 256: the 430 MB result is written at 0.2 TB/s); this one ~12.
 constexpr int EMB_ROWS = 64;   // rows per block
-template <int PLMAX>
+template <int PLMAX, typename TH>   // TH: storage of the residual stream (f32, or bf16)
 __global__ __launch_bounds__(256) void ptst_embed_rows_kernel(const float* __restrict__ xm, const float* __restrict__ W, const float* __restrict__ bias,
-                                                              const float* __restrict__ pos, float* __restrict__ h, long long M, int P, int pl, int D,
+                                                              const float* __restrict__ pos, TH* __restrict__ h, long long M, int P, int pl, int D,
                                                               unsigned thr, float dscale, uint32_t key) {
     const int dq = D / 4, rpp = 256 / dq;            // threads per row, rows per pass (the launcher checks 256 % dq == 0)
     const int d = (threadIdx.x % dq) * 4, rsub = threadIdx.x / dq;
@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256) void ptst_embed_rows_kernel(const float* __res
         r[0] += pe.x; r[1] += pe.y; r[2] += pe.z; r[3] += pe.w;
         const long long o = row * D + d;
         if (thr) drop4(key, thr, (unsigned)o, dscale, r);
-        *(float4*)(h + o) = make_float4(r[0], r[1], r[2], r[3]);
+        st4f(h + o, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
-int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, float* h, long long M, int P, int pl, int D,
-                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+int ptst_embed_launch(const float* xm, const float* W, const float* bias, const float* pos, void* h, long long M, int P, int pl, int D,
+                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s, int h_dtype) {
     NBCI_REQUIRE(pl <= 32 && D % 4 == 0, NBCI_ESHAPE, "ptst embed: patch_length <= 32 and d_model % 4 == 0");
     NBCI_REQUIRE(M * D < (1ll << 32), NBCI_ESHAPE, "ptst embed: tensor too large for the dropout counter");
     const unsigned thr = drop_threshold(drop_p);
@@ -162,12 +162,16 @@ int ptst_embed_launch(const float* xm, const float* W, const float* bias, const 
     const long long n = M * (D / 4);
     dim3 g((unsigned)((n + 255) / 256));
     if (pl <= 16 && D / 4 <= 256 && 256 % (D / 4) == 0) {
-        hipLaunchKernelGGL((ptst_embed_rows_kernel<16>), dim3((unsigned)((M + EMB_ROWS - 1) / EMB_ROWS)), dim3(256), 0, s, xm, W, bias, pos, h, M, P, pl, D, thr,
-                           dscale, drop_key(seed, site));
+        const dim3 gr((unsigned)((M + EMB_ROWS - 1) / EMB_ROWS));
+        if (h_dtype == NBCI_BF16)
+            hipLaunchKernelGGL((ptst_embed_rows_kernel<16, bf16_t>), gr, dim3(256), 0, s, xm, W, bias, pos, (bf16_t*)h, M, P, pl, D, thr, dscale, drop_key(seed, site));
+        else
+            hipLaunchKernelGGL((ptst_embed_rows_kernel<16, float>), gr, dim3(256), 0, s, xm, W, bias, pos, (float*)h, M, P, pl, D, thr, dscale, drop_key(seed, site));
         return check_launch("ptst_embed");
     }
-    if (pl <= 16) hipLaunchKernelGGL((ptst_embed_kernel<16>), g, dim3(256), 0, s, xm, W, bias, pos, h, M, P, pl, D, thr, dscale, drop_key(seed, site));
-    else hipLaunchKernelGGL((ptst_embed_kernel<32>), g, dim3(256), 0, s, xm, W, bias, pos, h, M, P, pl, D, thr, dscale, drop_key(seed, site));
+    NBCI_REQUIRE(h_dtype == NBCI_F32, NBCI_ESHAPE, "ptst embed: a bf16 residual stream needs patch_length <= 16 and d_model / 4 dividing 256");
+    if (pl <= 16) hipLaunchKernelGGL((ptst_embed_kernel<16>), g, dim3(256), 0, s, xm, W, bias, pos, (float*)h, M, P, pl, D, thr, dscale, drop_key(seed, site));
+    else hipLaunchKernelGGL((ptst_embed_kernel<32>), g, dim3(256), 0, s, xm, W, bias, pos, (float*)h, M, P, pl, D, thr, dscale, drop_key(seed, site));
     return check_launch("ptst_embed");
 }
 
@@ -232,15 +236,16 @@ int ptst_embed_wgrad_launch(const float* de, const float* xm, float* dW, long lo
 constexpr int BN_ROWS = 512;   // rows per chunk
 
 // per (chunk, column): count, mean, M2 — shifted accumulation inside the chunk
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long long M, int D) {
+template <typename TX>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const TX* __restrict__ x, float* __restrict__ part, long long M, int D) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= D) return;
     const long long r0 = (long long)blockIdx.x * BN_ROWS;
     const long long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
-    const float K = x[r0 * D + c];
+    const float K = (float)x[r0 * D + c];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
-    for (long long r = r0; r < r1; ++r) { const float v = x[r * D + c] - K; s1 += v; s2 += v * v; }
+    for (long long r = r0; r < r1; ++r) { const float v = (float)x[r * D + c] - K; s1 += v; s2 += v * v; }
     const float n = (float)(r1 - r0);
     const float mean = K + s1 / n;
     const float m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
@@ -294,14 +299,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(n > 1.0 ? m2 / (n - 1.0) : var);
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+template <typename TO, typename TX>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ w, const float* __restrict__ b, TO* __restrict__ y, long long n4,
                                                        int D) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)((i * 4) % D);
-    const float4 v = *(const float4*)(x + i * 4);
+    const float4 v = ld4f(x + i * 4);
     const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c), ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
     stq<TO>(y, i * 4 + 0, (v.x - mu.x) * rs.x * ww.x + bb.x);
     stq<TO>(y, i * 4 + 1, (v.y - mu.y) * rs.y * ww.y + bb.y);
@@ -310,15 +315,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // bn_apply + MX fp8 copy of the result (fp8.hip): 8 consecutive threads hold one 32-element block of a row (D % 32 == 0)
-template <typename TO>
-__global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+template <typename TO, typename TX>
+__global__ __launch_bounds__(256) void bn_apply_q_kernel(const TX* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ w, const float* __restrict__ b, TO* __restrict__ y,
                                                          uint8_t* __restrict__ q, uint8_t* __restrict__ sc, long long n4, int D) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         const int c = (int)((i * 4) % D);
-        const float4 v = *(const float4*)(x + i * 4);
+        const float4 v = ld4f(x + i * 4);
         const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c), ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
         o[0] = (v.x - mu.x) * rs.x * ww.x + bb.x; o[1] = (v.y - mu.y) * rs.y * ww.y + bb.y;
         o[2] = (v.z - mu.z) * rs.z * ww.z + bb.z; o[3] = (v.w - mu.w) * rs.w * ww.w + bb.w;
@@ -344,12 +349,13 @@ __global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict
 
 size_t bn_partial_floats(long long M, int D) { return (size_t)((M + BN_ROWS - 1) / BN_ROWS) * 2 * D; }
 
-int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
-                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8, void* q8_scales) {
+template <typename TX>
+static int batchnorm_fwd_t(const TX* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
+                           int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8, void* q8_scales) {
     NBCI_REQUIRE(D % 4 == 0, NBCI_ESHAPE, "batchnorm: features must be a multiple of 4");
     const int nchunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
     if (train) {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, x, partials, M, D);
+        hipLaunchKernelGGL((bn_stats_kernel<TX>), dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, x, partials, M, D);
         int rc = check_launch("bn_stats");
         if (rc != NBCI_OK) return rc;
     }
@@ -360,17 +366,25 @@ int batchnorm_fwd_launch(const float* x, const float* w, const float* b, float* 
     dim3 g((unsigned)((n4 + 255) / 256));
     if (q8) {   // also the MX fp8 copy the block-scaled QKV GEMM reads (blocks of 32 along the feature axis)
         NBCI_REQUIRE(D % 32 == 0 && q8_scales, NBCI_ESHAPE, "batchnorm: the fp8 copy needs features in multiples of 32");
-        if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_q_kernel<bf16_t>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
-        else hipLaunchKernelGGL((bn_apply_q_kernel<float>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
+        if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_q_kernel<bf16_t, TX>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
+        else hipLaunchKernelGGL((bn_apply_q_kernel<float, TX>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, (uint8_t*)q8, (uint8_t*)q8_scales, n4, D);
         return check_launch("bn_apply_q");
     }
-    if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, n4, D);
-    else hipLaunchKernelGGL((bn_apply_kernel<float>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, n4, D);
+    if (y_dtype == NBCI_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, TX>), g, dim3(256), 0, s, x, mean, rstd, w, b, (bf16_t*)y, n4, D);
+    else hipLaunchKernelGGL((bn_apply_kernel<float, TX>), g, dim3(256), 0, s, x, mean, rstd, w, b, (float*)y, n4, D);
     return check_launch("bn_apply");
+}
+int batchnorm_fwd_launch(const void* x, const float* w, const float* b, float* run_mean, float* run_var, int train, float eps, void* y,
+                         int y_dtype, float* mean, float* rstd, float* partials, long long M, int D, hipStream_t s, void* q8, void* q8_scales,
+                         int x_dtype) {
+    if (x_dtype == NBCI_BF16)
+        return batchnorm_fwd_t<bf16_t>((const bf16_t*)x, w, b, run_mean, run_var, train, eps, y, y_dtype, mean, rstd, partials, M, D, s, q8, q8_scales);
+    return batchnorm_fwd_t<float>((const float*)x, w, b, run_mean, run_var, train, eps, y, y_dtype, mean, rstd, partials, M, D, s, q8, q8_scales);
 }
 
 // backward pass 1: per (chunk, column) sums of dy and dy * xhat
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+template <typename TY, typename TX>   // TY: the incoming gradient (f32, or bf16 as a bf16 data-gradient GEMM writes it); TX: the saved input
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const TY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ part, long long M, int D) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= D) return;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     const float mu = mean[c], rs = rstd[c];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
-    for (long long r = r0; r < r1; ++r) { const float g = dy[r * D + c]; s1 += g; s2 += g * (x[r * D + c] - mu) * rs; }
+    for (long long r = r0; r < r1; ++r) { const float g = (float)dy[r * D + c]; s1 += g; s2 += g * ((float)x[r * D + c] - mu) * rs; }
     float* o = part + ((long long)blockIdx.x * 2) * D;
     o[c] = s1; o[D + c] = s2;
 }
@@ -410,14 +424,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // pass 2: dx += w * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M)   (eval mode: dx += dy * w * rstd), as dx += A dy - B - C (x - mean)
 // with the per-column A, B, C of the finalize kernel: four vector loads of column data per thread instead of twenty scalar ones, two
 // float4 elements per thread in flight
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ coef, float* __restrict__ dx, long long n4, int D) {
+template <typename TY, typename TX, typename TD>   // TD: the gradient stream dx (read, added to, written: f32 arithmetic, one rounding)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ coef, TD* __restrict__ dx, long long n4, int D) {
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
     float4 g[2], v[2], o[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const long long i = i0 + u;
-        if (i < n4) { g[u] = *(const float4*)(dy + i * 4); v[u] = *(const float4*)(x + i * 4); o[u] = *(const float4*)(dx + i * 4); }
+        if (i < n4) { g[u] = ld4f(dy + i * 4); v[u] = ld4f(x + i * 4); o[u] = ld4f(dx + i * 4); }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -429,14 +444,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         o[u].y += A.y * g[u].y - B.y - Cc.y * (v[u].y - mu.y);
         o[u].z += A.z * g[u].z - B.z - Cc.z * (v[u].z - mu.z);
         o[u].w += A.w * g[u].w - B.w - Cc.w * (v[u].w - mu.w);
-        *(float4*)(dx + i * 4) = o[u];
+        st4f(dx + i * 4, o[u]);
     }
 }
 
-int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
-                         float* partials, float* sums, long long M, int D, int train, hipStream_t s) {
+template <typename TY, typename TX, typename TD>
+static int batchnorm_bwd_t(const TY* dy, const TX* x, const float* mean, const float* rstd, const float* w, TD* dx, float* dw, float* db,
+                           float* partials, float* sums, long long M, int D, int train, hipStream_t s) {
     const int nchunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, dy, x, mean, rstd, partials, M, D);
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<TY, TX>), dim3(nchunks, (D + 255) / 256), dim3(256), 0, s, dy, x, mean, rstd, partials, M, D);
     int rc = check_launch("bn_bwd_stats");
     if (rc != NBCI_OK) return rc;
     NBCI_REQUIRE(D % 4 == 0, NBCI_ESHAPE, "batchnorm backward: features must be a multiple of 4");
@@ -445,15 +461,26 @@ int batchnorm_bwd_launch(const float* dy, const float* x, const float* mean, con
     rc = check_launch("bn_bwd_finalize");
     if (rc != NBCI_OK) return rc;
     const long long n4 = M * D / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 511) / 512)), dim3(256), 0, s, dy, x, mean, sums, dx, n4, D);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TY, TX, TD>), dim3((unsigned)((n4 + 511) / 512)), dim3(256), 0, s, dy, x, mean, sums, dx, n4, D);
     return check_launch("bn_bwd_apply");
+}
+// dy_dtype: the incoming gradient; stream_dtype: the saved input x AND the gradient stream dx (both f32, or both bf16)
+int batchnorm_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
+                         float* partials, float* sums, long long M, int D, int train, hipStream_t s, int dy_dtype, int stream_dtype) {
+    if (stream_dtype == NBCI_BF16) {
+        NBCI_REQUIRE(dy_dtype == NBCI_BF16, NBCI_EINVAL, "batchnorm backward: bf16 streams take a bf16 incoming gradient");
+        return batchnorm_bwd_t<bf16_t, bf16_t, bf16_t>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, w, (bf16_t*)dx, dw, db, partials, sums, M, D, train, s);
+    }
+    if (dy_dtype == NBCI_BF16)
+        return batchnorm_bwd_t<bf16_t, float, float>((const bf16_t*)dy, (const float*)x, mean, rstd, w, (float*)dx, dw, db, partials, sums, M, D, train, s);
+    return batchnorm_bwd_t<float, float, float>((const float*)dy, (const float*)x, mean, rstd, w, (float*)dx, dw, db, partials, sums, M, D, train, s);
 }
 
 // ------------------------------------------------------------------------------------------
 // PredictHead pooling (patchtst.py:89): pooled[(b,p), :] = mean_c h[b,c,p,:]; backward broadcasts d/C to every channel
 // ------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const float* __restrict__ h, TO* __restrict__ pooled, int B, int C, int P, int D) {
+template <typename TO, typename TH>
+__global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const TH* __restrict__ h, TO* __restrict__ pooled, int B, int C, int P, int D) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, p, d/4)
     const int dq = D / 4;
     if (i >= (long long)B * P * dq) return;
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const float* __restr
     const int p = (int)(bp % P), b = (int)(bp / P);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < C; ++c) {
-        const float4 v = *(const float4*)(h + (((long long)b * C + c) * P + p) * D + d);
+        const float4 v = ld4f(h + (((long long)b * C + c) * P + p) * D + d);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     const float inv = 1.0f / (float)C;
@@ -470,7 +497,8 @@ __global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const float* __restr
     stq<TO>(pooled, o + 0, a.x * inv); stq<TO>(pooled, o + 1, a.y * inv); stq<TO>(pooled, o + 2, a.z * inv); stq<TO>(pooled, o + 3, a.w * inv);
 }
 
-__global__ __launch_bounds__(256) void ptst_pool_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dh, int B, int C, int P, int D) {
+template <typename TD>
+__global__ __launch_bounds__(256) void ptst_pool_bwd_kernel(const float* __restrict__ dpooled, TD* __restrict__ dh, int B, int C, int P, int D) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, c, p, d/4)
     const int dq = D / 4;
     if (i >= (long long)B * C * P * dq) return;
@@ -480,20 +508,24 @@ __global__ __launch_bounds__(256) void ptst_pool_bwd_kernel(const float* __restr
     const int b = (int)(row / ((long long)C * P));
     const float4 v = *(const float4*)(dpooled + ((long long)b * P + p) * D + d);
     const float inv = 1.0f / (float)C;
-    *(float4*)(dh + row * D + d) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    st4f(dh + row * D + d, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
 }
 
-int ptst_pool_fwd_launch(const float* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s) {
+int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype) {
     const long long n = (long long)B * P * (D / 4);
     dim3 g((unsigned)((n + 255) / 256));
-    if (dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t>), g, dim3(256), 0, s, h, (bf16_t*)pooled, B, C, P, D);
-    else hipLaunchKernelGGL((ptst_pool_fwd_kernel<float>), g, dim3(256), 0, s, h, (float*)pooled, B, C, P, D);
+    if (h_dtype == NBCI_BF16) {
+        NBCI_REQUIRE(dtype == NBCI_BF16, NBCI_EINVAL, "pool: a bf16 stream goes with bf16 operands");
+        hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)pooled, B, C, P, D);
+    } else if (dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t, float>), g, dim3(256), 0, s, (const float*)h, (bf16_t*)pooled, B, C, P, D);
+    else hipLaunchKernelGGL((ptst_pool_fwd_kernel<float, float>), g, dim3(256), 0, s, (const float*)h, (float*)pooled, B, C, P, D);
     return check_launch("ptst_pool_fwd");
 }
 
-int ptst_pool_bwd_launch(const float* dpooled, float* dh, int B, int C, int P, int D, hipStream_t s) {
+int ptst_pool_bwd_launch(const float* dpooled, void* dh, int B, int C, int P, int D, hipStream_t s, int dh_dtype) {
     const long long n = (long long)B * C * P * (D / 4);
-    hipLaunchKernelGGL(ptst_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpooled, dh, B, C, P, D);
+    if (dh_dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_bwd_kernel<bf16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpooled, (bf16_t*)dh, B, C, P, D);
+    else hipLaunchKernelGGL((ptst_pool_bwd_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpooled, (float*)dh, B, C, P, D);
     return check_launch("ptst_pool_bwd");
 }
 

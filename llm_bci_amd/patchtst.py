@@ -153,6 +153,13 @@ class PatchTSTForSpikingActivity(FlatParamModule):
         c.loss = LOSS_KIND[(self.loss_name, self.log_input)] if self.method == "mlm" else 0
         c.dtype = self.compute_dtype
         c.fp8_qkv = 1 if self.fp8_qkv else 0
+        # storage of the residual stream / its gradient stream between kernels (as NDT1's residual_dtype): bf16 by default on the bf16 / fp8
+        # paths, "fp32" on request and always for compute_dtype fp32
+        res_name = kwargs.get("residual_dtype", None) or ("bf16" if self.compute_dtype == NBCI_BF16 else "fp32")
+        self.residual_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[res_name]
+        if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
+            raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16' or 'fp8'")
+        c.residual_dtype = self.residual_dtype
         self._ccfg = c
         self.config = config
         T, pl, st = c.context_length, c.patch_length, c.patch_stride

@@ -19,12 +19,13 @@ def _dev(batch):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in batch.items()}
 
 
-def _model(fx_or_over, dtype="fp32", kwargs=None):
+def _model(fx_or_over, dtype="fp32", kwargs=None, extra=None):
     from llm_bci_amd.patchtst import PatchTSTForSpikingActivity
     if isinstance(fx_or_over, dict):
         over, kw = fx_or_over, dict(kwargs)
     else:
         over, kw = json.loads(str(fx_or_over["config_json"])), json.loads(str(fx_or_over["kwargs_json"]))
+    kw.update(extra or {})
     torch.manual_seed(1)
     return PatchTSTForSpikingActivity(over, compute_dtype=dtype, **kw)
 
@@ -117,24 +118,27 @@ def test_fp32_matches_reference_golden_c5_shapes_and_bf16_close():
         ref = fx["gval:" + k]
         got = g[k].reshape(-1)[fx["gidx:" + k]]
         np.testing.assert_allclose(got, ref, atol=2e-6 + 3e-3 * max(np.abs(ref).max(), fx["gsum:" + k][1] / g[k].size), err_msg=k)
-    mb = _model(fx, dtype="bf16").to(DEV)
-    lb, pb, gb = _grads_of(mb, batch)
-    assert np.abs(pb.cpu().numpy() - preds.cpu().numpy()).max() < 0.08
-    np.testing.assert_allclose(float(lb.sum()), float(loss.sum()), rtol=2e-2)
-    for k in g:
-        if k.endswith("k_proj.bias"):
-            continue
-        num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
-        assert num / den < 0.08, (k, num / den)
+    for streams in ("fp32", "bf16"):   # the residual / gradient streams stored in f32, or in bf16 (the default of the bf16 path)
+        mb = _model(fx, dtype="bf16", extra={"residual_dtype": streams}).to(DEV)
+        lb, pb, gb = _grads_of(mb, batch)
+        assert np.abs(pb.cpu().numpy() - preds.cpu().numpy()).max() < 0.08, streams
+        np.testing.assert_allclose(float(lb.sum()), float(loss.sum()), rtol=2e-2)
+        for k in g:
+            if k.endswith("k_proj.bias"):
+                continue
+            num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
+            assert num / den < 0.08, (streams, k, num / den)
 
 
-@pytest.mark.parametrize("method,dtype", [("ctc", "fp32"), ("mlm", "fp32"), ("mlm", "bf16")])
+@pytest.mark.parametrize("method,dtype", [("ctc", "fp32"), ("mlm", "fp32"), ("mlm", "bf16"), ("ctc", "bf16"), ("mlm", "bf16/f32 streams")])
 def test_train_mode_dropout_and_random_mask_match_oracle(method, dtype):
     enc = {"num_input_channels": 7, "context_length": 64, "patch_length": 8, "patch_stride": 4, "num_hidden_layers": 2, "d_model": 32,
            "num_attention_heads": 2, "ffn_dim": 64, "attention_dropout": 0.3, "ff_dropout": 0.4, "path_dropout": 0.1, "positional_dropout": 0.1,
            "do_mask_input": True, "random_mask_ratio": 0.4}
     kw = dict(method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True) if method == "ctc" else dict(method_name="mlm", loss="poisson_nll", log_input=True)
-    m = _model({"encoder": enc}, dtype=dtype, kwargs=kw).to(DEV)
+    extra = {"residual_dtype": "fp32"} if dtype.endswith("f32 streams") else None   # ("bf16": bf16 streams, the default)
+    dtype = dtype.split("/")[0]
+    m = _model({"encoder": enc}, dtype=dtype, kwargs=kw, extra=extra).to(DEV)
     st = {k: v.detach().float().cpu().numpy().copy() for k, v in m.state_dict().items()}
     p = {k: v for k, v in st.items() if not k.endswith(STAT) and not k.endswith("position_enc")}
     p["encoder.encoder.positional_encoder.position_enc"] = st["encoder.encoder.positional_encoder.position_enc"]
