@@ -258,6 +258,7 @@ static void ln_fwd_dispatch(int nv, hipStream_t s, const TX* x, const float* w, 
                             float* mean, float* rstd, int M, int H, float* y32) {
     const dim3 g((unsigned)((M + 3) / 4));
     if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
+    else if (nv == 3) hipLaunchKernelGGL((ln_fwd_kernel<3, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);   // (hidden 768: no idle quarter)
     else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
     else if (nv <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
     else hipLaunchKernelGGL((ln_fwd_kernel<16, TO, TX>), g, dim3(256), 0, s, x, w, b, y, mean, rstd, M, H, y32);
@@ -443,6 +444,7 @@ static void ln_bwd_dispatch(int nv, dim3 g, hipStream_t s, const void* dy, const
                                (const TX*)x, w, mean, rstd, (const TD*)dx_in, (TD*)dx_out, dw, db, M, H, rc, cz, iters, notail);        \
     } while (0)
     if (nv <= 1) LNB(1);
+    else if (nv == 3) LNB(3);   // (hidden 768, the iTransformer's: three exact column groups instead of four with one masked off)
     else if (nv <= 4) LNB(4);
     else LNB(8);
 #undef LNB
