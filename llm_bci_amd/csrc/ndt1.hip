@@ -721,7 +721,7 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
                 const int st = c.stack_stride, nwin = c.stack_size / st;
                 if (part != 2) TRY(fork());
                 if (part != 2)   // K = all B*Q rows (the zero rows add nothing): row r of dx0 against the window starting at bin st*r of y, both
-                                 // operands plain (the window rows overlap: rpb = -1) - no view stepping in the K loop (187 -> 14x us)
+                                 // operands plain (the window rows overlap: rpb = -1) - no view stepping in the K loop (187 -> 161 us)
                     TRY(wgrad(wgs, dt, H, KS, B * w.Q, op(ws + w.dAp, es, (int64_t)w.npad * H, H, 0),
                               op(ws + w.y, es, 0, (int64_t)st * D, 0, -1), grads + p.stkw, KS));
                 if (part != 1) {
