@@ -147,7 +147,8 @@ int batchnorm_bwd_launch(const void* dy, const void* x, const float* mean, const
                          int dy_dtype = NBCI_F32, int stream_dtype = NBCI_F32);
 // dW[D][pl] += de^T xm over all M rows (f32; the shared patch embedding's weight gradient as a streaming reduction)
 int ptst_embed_wgrad_launch(const float* de, const float* xm, float* dW, long long M, int pl, int D, hipStream_t s);
-int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype = NBCI_F32);
+size_t ptst_pool_partial_floats(int B, int P, int D);   // f32 scratch of the pooling's channel-chunk partial sums
+int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype, float* partial);
 int ptst_pool_bwd_launch(const float* dpooled, void* dh, int B, int C, int P, int D, hipStream_t s, int dh_dtype = NBCI_F32);
 int ptst_lens_launch(const int64_t* lens, int32_t* out, int B, int pl, int stride, hipStream_t s);
 int ptst_mlm_loss_launch(const float* pred, int ldp, const float* target, const uint8_t* mask, const int64_t* smask, float* preds_out,

@@ -119,7 +119,7 @@ struct PtWS {
     size_t mask, mask2, xm, patch;
     std::vector<PtLayerWS> L;
     size_t x_last, pooled, d1, logits, alpha, dlogits, argmax, tlens, pred, dpred, scores, bnpart, bnsums;
-    size_t dx, dtmp, cA, cA2, dU, dAtt, dqkv, dS, dpool, dsum, rep;
+    size_t dx, dtmp, cA, cA2, dU, dAtt, dqkv, dS, dpool, poolpart, dsum, rep;
     size_t y1q, y1s, wq8, wq8s;   // fp8_qkv: MX e4m3 copy of the BatchNorm output (M x D bytes + M x D/32 scale bytes), quantised q/k/v weights
     size_t bytes;
     long long M;
@@ -192,6 +192,7 @@ static int pt_carve(const PtPlan& p, int B, int S, PtWS& w) {
     w.dqkv = bump(cur, M * 3 * D * es);
     w.dS = bump(cur, nP * es);
     w.dpool = bump(cur, Mh * D * 4);
+    w.poolpart = bump(cur, c.method == NBCI_PTST_CTC ? ptst_pool_partial_floats(B, (int)P, (int)D) * 4 : 0);
     w.rep = bump(cur, (size_t)NREP * p.compact_total * 4);
     if (c.fp8_qkv) {
         NBCI_REQUIRE(c.dtype == NBCI_BF16 && D % 128 == 0, NBCI_ESHAPE, "patchtst: fp8_qkv needs the bf16 path and d_model in multiples of 128");
@@ -329,7 +330,7 @@ int ptst_forward(const PtPlan& p, const float* params, const void* params_lp, co
     }
     if (c.method == NBCI_PTST_CTC) {
         const int Mh = w.Mh;
-        TRY(ptst_pool_fwd_launch(h, ws + w.pooled, dt, B, C, P, D, s, xdt));
+        TRY(ptst_pool_fwd_launch(h, ws + w.pooled, dt, B, C, P, D, s, xdt, (float*)(ws + w.poolpart)));
         const void* src = ws + w.pooled;
         int64_t ow = p.d0w, ob = p.d0b;
         if (c.mlp_decoder) {

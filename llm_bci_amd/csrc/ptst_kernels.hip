@@ -479,22 +479,38 @@ int batchnorm_bwd_launch(const void* dy, const void* x, const float* mean, const
 // ------------------------------------------------------------------------------------------
 // PredictHead pooling (patchtst.py:89): pooled[(b,p), :] = mean_c h[b,c,p,:]; backward broadcasts d/C to every channel
 // ------------------------------------------------------------------------------------------
-template <typename TO, typename TH>
-__global__ __launch_bounds__(256) void ptst_pool_fwd_kernel(const TH* __restrict__ h, TO* __restrict__ pooled, int B, int C, int P, int D) {
+// Two passes, both deterministic: (1) thread (chunk, b, p, d/4) sums ITS chunk of the channels into partial[chunk][...]; (2) thread
+// (b, p, d/4) adds the chunks in order, scales by 1 / C and stores. One thread walking all C = 1024 channels of its (b, p, d/4) - 26 k
+// threads chip-wide, a dependent load per channel - took 411 us for 215 MB.
+constexpr int POOL_CHUNKS = 32;
+template <typename TH>
+__global__ __launch_bounds__(256) void ptst_pool_part_kernel(const TH* __restrict__ h, float* __restrict__ partial, int B, int C, int P, int D, int cpc) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, p, d/4)
     const int dq = D / 4;
-    if (i >= (long long)B * P * dq) return;
+    const long long n = (long long)B * P * dq;
+    if (i >= n) return;
     const int d = (int)(i % dq) * 4;
     const long long bp = i / dq;
     const int p = (int)(bp % P), b = (int)(bp / P);
+    const int c0 = blockIdx.y * cpc, c1 = min(C, c0 + cpc);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
         const float4 v = ld4f(h + (((long long)b * C + c) * P + p) * D + d);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    const float inv = 1.0f / (float)C;
-    const long long o = bp * D + d;
-    stq<TO>(pooled, o + 0, a.x * inv); stq<TO>(pooled, o + 1, a.y * inv); stq<TO>(pooled, o + 2, a.z * inv); stq<TO>(pooled, o + 3, a.w * inv);
+    *(float4*)(partial + ((long long)blockIdx.y * n + i) * 4) = a;
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void ptst_pool_sum_kernel(const float* __restrict__ partial, TO* __restrict__ pooled, long long n, int nchunks, float inv) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nchunks; ++k) {
+        const float4 v = *(const float4*)(partial + ((long long)k * n + i) * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    stq<TO>(pooled, i * 4 + 0, a.x * inv); stq<TO>(pooled, i * 4 + 1, a.y * inv); stq<TO>(pooled, i * 4 + 2, a.z * inv); stq<TO>(pooled, i * 4 + 3, a.w * inv);
 }
 
 template <typename TD>
@@ -511,15 +527,20 @@ __global__ __launch_bounds__(256) void ptst_pool_bwd_kernel(const float* __restr
     st4f(dh + row * D + d, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
 }
 
-int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype) {
+size_t ptst_pool_partial_floats(int B, int P, int D) { return (size_t)POOL_CHUNKS * B * P * D; }
+int ptst_pool_fwd_launch(const void* h, void* pooled, int dtype, int B, int C, int P, int D, hipStream_t s, int h_dtype, float* partial) {
+    NBCI_REQUIRE(partial && D % 4 == 0, NBCI_EINVAL, "pool: scratch for the channel-chunk partial sums is required");
     const long long n = (long long)B * P * (D / 4);
-    dim3 g((unsigned)((n + 255) / 256));
-    if (h_dtype == NBCI_BF16) {
-        NBCI_REQUIRE(dtype == NBCI_BF16, NBCI_EINVAL, "pool: a bf16 stream goes with bf16 operands");
-        hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)pooled, B, C, P, D);
-    } else if (dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_fwd_kernel<bf16_t, float>), g, dim3(256), 0, s, (const float*)h, (bf16_t*)pooled, B, C, P, D);
-    else hipLaunchKernelGGL((ptst_pool_fwd_kernel<float, float>), g, dim3(256), 0, s, (const float*)h, (float*)pooled, B, C, P, D);
-    return check_launch("ptst_pool_fwd");
+    const int cpc = (C + POOL_CHUNKS - 1) / POOL_CHUNKS, nchunks = (C + cpc - 1) / cpc;
+    dim3 g((unsigned)((n + 255) / 256), (unsigned)nchunks);
+    if (h_dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_part_kernel<bf16_t>), g, dim3(256), 0, s, (const bf16_t*)h, partial, B, C, P, D, cpc);
+    else hipLaunchKernelGGL((ptst_pool_part_kernel<float>), g, dim3(256), 0, s, (const float*)h, partial, B, C, P, D, cpc);
+    int rc = check_launch("ptst_pool_part");
+    if (rc != NBCI_OK) return rc;
+    const float inv = 1.0f / (float)C;
+    if (dtype == NBCI_BF16) hipLaunchKernelGGL((ptst_pool_sum_kernel<bf16_t>), dim3(g.x), dim3(256), 0, s, partial, (bf16_t*)pooled, n, nchunks, inv);
+    else hipLaunchKernelGGL((ptst_pool_sum_kernel<float>), dim3(g.x), dim3(256), 0, s, partial, (float*)pooled, n, nchunks, inv);
+    return check_launch("ptst_pool_sum");
 }
 
 int ptst_pool_bwd_launch(const float* dpooled, void* dh, int B, int C, int P, int D, hipStream_t s, int dh_dtype) {
