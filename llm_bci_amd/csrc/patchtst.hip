@@ -525,7 +525,7 @@ int ptst_backward(const PtPlan& p, const float* params, const void* params_lp, c
             } else {
                 TRY(colsum_launch(dx, NBCI_F32, D, Mi, D, RG(p.embb), s, rc));
             }
-            if (pl <= 16) TRY(ptst_embed_wgrad_launch(de, (const float*)(ws + w.xm), grads + p.embw, Mi, pl, D, s));
+            if (pl <= 16 && D % 4 == 0 && D / 4 <= 256 && 256 % (D / 4) == 0 && (256 / (D / 4)) * D * pl * 4 <= 65536) TRY(ptst_embed_wgrad_launch(de, (const float*)(ws + w.xm), grads + p.embw, Mi, pl, D, s));
             else TRY(wgrad(s, NBCI_F32, D, pl, Mi, op(de, 4, 0, D, 0), op(ws + w.xm, 4, 0, pl, 0), grads + p.embw, pl));
         }
     }

@@ -181,15 +181,19 @@ int ptst_embed_launch(const float* xm, const float* W, const float* bias, const 
 // for every thread: staged through LDS in chunks, read back as broadcasts); at the end the block's D x pl partials go through LDS so that
 // each atomic wave-instruction covers 64 CONSECUTIVE floats of dW. Reads de once: ~80 us at 420 k x 256.
 constexpr int EWG_CHUNK = 128;   // rows of xm staged per pass
+// A thread owns FOUR adjacent columns (one 16-byte load per row) of every rpp-th row of the chunk (rpp = 256 / (D / 4) row groups per
+// block); the row groups' partial sums meet in LDS at the end. (One column per thread kept 1 KB per wave-load in flight: 1.4 TB/s.)
 template <int PLMAX>
 __global__ __launch_bounds__(256) void ptst_embed_wgrad_kernel(const float* __restrict__ de, const float* __restrict__ xm, float* __restrict__ dW,
                                                               long long M, int pl, int D, long long rows_per_block) {
-    extern __shared__ float sm[];                   // [EWG_CHUNK][PLMAX] patch rows; afterwards [D][pl] partials
-    const int d = blockIdx.y * 256 + threadIdx.x;   // this thread's column
-    const bool live = d < D;
-    float acc[PLMAX];
+    extern __shared__ float sm[];                   // [EWG_CHUNK][PLMAX] patch rows; afterwards [rpp][D][pl] partials
+    const int dq = D / 4, rpp = 256 / dq;           // (the launcher checks 256 % dq == 0)
+    const int d = (threadIdx.x % dq) * 4, rsub = threadIdx.x / dq;
+    float acc[4][PLMAX];
 #pragma unroll
-    for (int j = 0; j < PLMAX; ++j) acc[j] = 0.f;
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < PLMAX; ++j) acc[e][j] = 0.f;
     for (int i = threadIdx.x; i < EWG_CHUNK * PLMAX; i += 256) sm[i] = 0.f;   // (the stage's columns >= pl stay zero)
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     for (long long rc = r0; rc < r1; rc += EWG_CHUNK) {
@@ -197,36 +201,41 @@ __global__ __launch_bounds__(256) void ptst_embed_wgrad_kernel(const float* __re
         __syncthreads();
         for (int i = threadIdx.x; i < nr * pl; i += 256) sm[(i / pl) * PLMAX + i % pl] = xm[rc * pl + i];
         __syncthreads();
-        if (live) {
 #pragma unroll 4
-            for (int r = 0; r < nr; ++r) {
-                const float g = de[(rc + r) * D + d];
+        for (int r = rsub; r < nr; r += rpp) {
+            const float4 g = *(const float4*)(de + (rc + r) * D + d);
 #pragma unroll
-                for (int j = 0; j < PLMAX; ++j) acc[j] += g * sm[r * PLMAX + j];
+            for (int j = 0; j < PLMAX; ++j) {
+                const float xv = sm[r * PLMAX + j];
+                acc[0][j] += g.x * xv; acc[1][j] += g.y * xv; acc[2][j] += g.z * xv; acc[3][j] += g.w * xv;
             }
         }
     }
     __syncthreads();
-    const int c0 = blockIdx.y * 256;
-    const int nd = min(256, D - c0);
-    if (live) {
 #pragma unroll
-        for (int j = 0; j < PLMAX; ++j) if (j < pl) sm[threadIdx.x * pl + j] = acc[j];
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < PLMAX; ++j) if (j < pl) sm[((long long)rsub * D + d + e) * pl + j] = acc[e][j];
     __syncthreads();
-    for (int i = threadIdx.x; i < nd * pl; i += 256) atomicAdd(dW + (long long)c0 * pl + i, sm[i]);
+    for (int i = threadIdx.x; i < D * pl; i += 256) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < rpp; ++g2) t += sm[(long long)g2 * D * pl + i];
+        atomicAdd(dW + i, t);
+    }
 }
 
 int ptst_embed_wgrad_launch(const float* de, const float* xm, float* dW, long long M, int pl, int D, hipStream_t s) {
-    NBCI_REQUIRE(pl >= 1 && pl <= 16 && D >= 1, NBCI_ESHAPE, "ptst embed wgrad: patch_length <= 16");
-    const int by = (D + 255) / 256;
-    long long bx = std::min<long long>((M + EWG_CHUNK - 1) / EWG_CHUNK, 1024 / by > 0 ? 1024 / by : 1);
+    NBCI_REQUIRE(pl >= 1 && pl <= 16 && D % 4 == 0 && D / 4 <= 256 && 256 % (D / 4) == 0, NBCI_ESHAPE,
+                 "ptst embed wgrad: patch_length <= 16 and d_model / 4 dividing 256");
+    long long bx = std::min<long long>((M + EWG_CHUNK - 1) / EWG_CHUNK, 1024);
     if (bx < 1) bx = 1;
     long long rpb = (M + bx - 1) / bx;
     rpb = (rpb + EWG_CHUNK - 1) / EWG_CHUNK * EWG_CHUNK;
     bx = (M + rpb - 1) / rpb;
-    const size_t lds = sizeof(float) * (size_t)std::max(EWG_CHUNK * 16, 256 * pl);
-    hipLaunchKernelGGL((ptst_embed_wgrad_kernel<16>), dim3((unsigned)bx, (unsigned)by), dim3(256), lds, s, de, xm, dW, M, pl, D, rpb);
+    const int rpp = 256 / (D / 4);
+    const size_t lds = sizeof(float) * (size_t)std::max(EWG_CHUNK * 16, rpp * D * pl);
+    NBCI_REQUIRE(lds <= 65536, NBCI_ESHAPE, "ptst embed wgrad: d_model x patch_length too large for the LDS reduction");
+    hipLaunchKernelGGL((ptst_embed_wgrad_kernel<16>), dim3((unsigned)bx), dim3(256), lds, s, de, xm, dW, M, pl, D, rpb);
     return check_launch("ptst_embed_wgrad");
 }
 
