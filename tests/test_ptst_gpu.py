@@ -202,3 +202,28 @@ def test_autograd_bridge_checkpoint_roundtrip_and_errors(tmp_path):
         PatchTSTForSpikingActivity({}, method_name="autoregressive")
     with pytest.raises(Exception):
         m(torch.zeros(1, 45, 6), torch.ones(1, 45, dtype=torch.int64), torch.tensor([45]))      # CPU tensors: no fallback
+
+
+def test_hidden_out_is_f32_last_hidden_state_whatever_the_stream_storage():
+    """nbci_ptst_io.hidden_out is (B, C, P, D) f32 (the reference's last_hidden_state): with bf16 streams it is a widening copy of the bf16
+    stream; it must match the f32-stream run of the same bf16 model within bf16 rounding of values of order one, and the fp32 model closely."""
+    enc = {"num_input_channels": 5, "context_length": 64, "patch_length": 8, "patch_stride": 4, "num_hidden_layers": 2, "d_model": 32,
+           "num_attention_heads": 2, "ffn_dim": 64, "do_mask_input": False}
+    kw = dict(method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
+    g = np.random.default_rng(3)
+    B, T, C = 3, 64, 5
+    batch = _dev(dict(spikes=g.standard_normal((B, T, C)).astype(np.float32), spikes_mask=np.ones((B, T), np.int64),
+                      spikes_lengths=np.array([64, 64, 64]), targets=g.integers(1, 11, (B, 4)).astype(np.int64), targets_lengths=np.array([4, 3, 4])))
+    outs = {}
+    for name, dtype, extra in (("fp32", "fp32", None), ("bf16/f32", "bf16", {"residual_dtype": "fp32"}), ("bf16/bf16", "bf16", {"residual_dtype": "bf16"})):
+        m = _model({"encoder": enc}, dtype=dtype, kwargs=kw, extra=extra).to(DEV)
+        m.eval()
+        P = m._ccfg_P if hasattr(m, "_ccfg_P") else 1 + (T - 8) // 4
+        h = torch.full((B, C, P, 32), float("nan"), device=DEV)
+        with torch.no_grad():
+            m._run_forward(batch, want_grad=False, hidden_out=h)
+        torch.cuda.synchronize()
+        assert h.dtype == torch.float32 and torch.isfinite(h).all(), name
+        outs[name] = h.cpu().numpy()
+    assert np.abs(outs["bf16/bf16"] - outs["bf16/f32"]).max() <= 2.0 ** -7 * max(1.0, np.abs(outs["bf16/f32"]).max())
+    assert np.abs(outs["bf16/f32"] - outs["fp32"]).max() < 0.08
