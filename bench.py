@@ -141,7 +141,7 @@ def roofline_from_profile(l, nsteps):
     return roof
 
 
-def other_model_points(l, dev, steps):
+def other_model_points(l, dev, steps, residual_dtype="bf16"):
     """The other rows of BASELINE.json's configs on the same binary (not bench lines): iTransformer SSL at 668 / 1500 channels
     (configs[2], recipe trainer_ssl_itransformer.yaml: B = 16, T = 100), PatchTST at 1024 channels x 2050 bins with fp8 q/k/v
     (configs[4], B = 2 per GPU) and the BCI coupler at its real widths (configs[3]: projector 1024 -> 2048 -> 4096 + splice, forward
@@ -186,7 +186,7 @@ def other_model_points(l, dev, steps):
         from llm_bci_amd.itransformer import iTransformer
         torch.manual_seed(1)
         m = iTransformer({"encoder": {"embed_region": False}, "masker": {"main": {"active": True}}}, method_name="mlm", loss="poisson_nll",
-                         log_input=True, compute_dtype="bf16").to(dev)
+                         log_input=True, compute_dtype="bf16", residual_dtype=residual_dtype).to(dev)
         tr = NativeTrainer(m, lr=1e-4, wd=0.01, eps=1e-8, scheduler="cosine", total_steps=100000, warmup_pct=0.15, div_factor=25, compute_per=False)
         B, T = 16, 100
         b = {"spikes": torch.from_numpy(g.poisson(0.5, (B, T, N)).astype(np.float32)).to(dev), "spikes_mask": torch.ones(B, T, dtype=torch.int64, device=dev),
@@ -202,7 +202,7 @@ def other_model_points(l, dev, steps):
         torch.manual_seed(1)
         B, Cn, T = 2, 1024, 2050
         m = PatchTSTForSpikingActivity({"encoder": {"num_input_channels": Cn, "context_length": T, "do_mask_input": False}}, compute_dtype="fp8",
-                                       method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True).to(dev)
+                                       residual_dtype=residual_dtype, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True).to(dev)
         tr = NativeTrainer(m, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=100000, warmup_pct=0.0, div_factor=25)
         b = {"spikes": torch.from_numpy(g.standard_normal((B, T, Cn)).astype(np.float32)).to(dev), "spikes_mask": torch.ones(B, T, dtype=torch.int64, device=dev),
              "spikes_lengths": torch.full((B,), T, dtype=torch.int64, device=dev), "targets": torch.from_numpy(g.integers(1, 41, (B, 60))).to(dev),
@@ -531,7 +531,7 @@ def main():
             tr.read_stats()
             tr = tr_main
             del m2
-        extra["other_models"] = other_model_points(lib(), dev, max(5, args.steps // 2))
+        extra["other_models"] = other_model_points(lib(), dev, max(5, args.steps // 2), args.residual_dtype)
     if world > 1:
         dist.barrier()
 

@@ -22,7 +22,8 @@
 // (owner j * 8 + xcd waits for helper j * 8 + nb + xcd / per), so there the argument is residency alone.
 // Placement (b % 8 = which blocks share an XCD) is a speed assumption only: partials and flags go past every cache level.
 // Every spin is BOUNDED (SK_SPIN_LIMIT sleeps, about a second): on expiry the owner gives up, counts the event in the scratch
-// buffer's timeout word and finishes with what it has - a wrong tile instead of a hung GPU; nbci_streamk_timeouts() reads the count.
+// buffer's timeout word and stores its tile as NaN - a LOUD wrong tile (the next loss / AdamW step is NaN) instead of a hung GPU or a
+// silently short sum; nbci_streamk_timeouts() reads the count, NativeTrainer.read_stats / save_checkpoint and bench.py raise on it.
 // Flags carry the launch's epoch (a per-process counter), so they are never reset.
 #include <hip/hip_runtime.h>
 
@@ -40,6 +41,7 @@ namespace nbci {
 constexpr int SK_MAX = 6;
 constexpr int SK_SPIN_LIMIT = 1 << 22;   // x s_sleep(8) ~ 0.25 us each
 constexpr int SK_MAXP = 8;   // aligned scheme: most pieces (scratch slots) one helper workgroup may produce
+constexpr int SK_LDS = 128 * EPI_LD * 4;   // staging / epilogue image; one more 16-byte slot behind it holds the owner's "gave up" word
 struct StreamK {
     int n;
     int tile_start[SK_MAX + 1];    // prefix sums of output tiles per problem
@@ -161,6 +163,9 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
         }
         return;
     }
+    volatile int* gave_up = (volatile int*)(smem + SK_LDS);   // written by thread 0 only, monotone within a piece
+    int timed_out = 0;
+    const bool exchange = nadd > 0 && !(s.dbg & 1);
     for (int i = 0; i < nadd && !(s.dbg & 1); ++i) {
         const int sl = slot_of(i);
         const float4* slot = sk_uniform((float4*)s.partial + (size_t)sl * (MI * NI * GEMM_THREADS));
@@ -168,8 +173,9 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
             int spins = 0;
             while (__hip_atomic_load(s.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s.epoch) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > SK_SPIN_LIMIT) { atomicAdd(s.timeouts, 1); break; }
+                if (++spins > SK_SPIN_LIMIT) { atomicAdd(s.timeouts, 1); timed_out = 1; break; }
             }
+            *gave_up = timed_out;
         }
         __syncthreads();
         // the partial was never cached here (first touch) but may be on another XCD: read it past the caches as well
@@ -185,6 +191,13 @@ __device__ __forceinline__ void sk_piece(const StreamK& s, char* smem, int p, in
 #pragma unroll
             for (int b = 0; b < NI; ++b) acc[a][b] += v[b];
         }
+    }
+    if (exchange && *gave_up) {   // (the last iteration's barrier ordered thread 0's write before this read) a contributor never showed up:
+        const float qnan = __builtin_nanf("");   // poison the tile so that the failure cannot pass for a gradient
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = (f32x4){qnan, qnan, qnan, qnan};
     }
     gemm_epilogue_tile<MI, NI>(d, acc, wm * MI * 16, wn * NI * 16, m0, n0, BM, 0, t, GEMM_THREADS, smem);
     __syncthreads();   // the epilogue's LDS tile is read out before the next piece stages into it
@@ -493,7 +506,7 @@ int gemm_streamk_launch(const nbci_gemm_desc* descs, const GemmK* ks, int n, hip
     s.timeouts = sc.flags + sc.slots;
     s.epoch = g_sk_epoch.fetch_add(1);
     s.dbg = measure_env("NBCI_STREAMK_DBG", 0);
-    constexpr int lds = 128 * EPI_LD * 4;
+    constexpr int lds = SK_LDS + 16;
     TRY_(ensure_dyn_lds(ak ? (bk ? (const void*)gemm_streamk_kernel<true, true> : (const void*)gemm_streamk_kernel<true, false>)
                            : (bk ? (const void*)gemm_streamk_kernel<false, true> : (const void*)gemm_streamk_kernel<false, false>), lds, "gemm stream-K"));
     dim3 grid(slots);

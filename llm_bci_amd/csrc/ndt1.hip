@@ -772,8 +772,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     int clo = p.cseg[seg_lo].first, chi = p.cseg[seg_hi].second;
     if (seg_lo == 0 && io->embed_part == 1) clo = p.compact_of(p.stkb);
     if (seg_lo == 0 && io->embed_part == 2) chi = p.compact_of(p.stkb);
+    // The join of this call's main-stream work onto the aux stream is unconditional: position / prefix / adapt gradients and the main
+    // chain's reads of the segment's bf16 weights must happen-before whatever the caller queues on aux next (per-segment AdamW + zero_grad,
+    // an all-reduce) even for a segment without 1-D parameters, i.e. with nothing to fold.
+    TRY(fork());
     if (chi > clo) {
-        TRY(fork());
         TRYP("fold_replicas_kernel", 0, (double)(chi - clo) * (rc.n + 1) * 4, aux, fold_replicas_launch(rep, rc.stride, rc.n, p.d_flat_of, clo, chi, grads, aux));
     }
     return NBCI_OK;

@@ -207,9 +207,9 @@ class iTransformer(FlatParamModule):
         c.use_cls, c.mlp_decoder = (1 if dec.use_cls else 0), (1 if dec.mlp_decoder else 0)
         c.loss = LOSS_KIND[(self.loss_name, self.log_input)]
         c.dtype = self.compute_dtype
-        # storage of the LayerNorm inputs and the gradient streams between kernels (as NDT1's residual_dtype): bf16 by default on the
-        # bf16 path, "fp32" on request / always for compute_dtype fp32
-        res_name = kwargs.get("residual_dtype", None) or ("bf16" if self.compute_dtype == NBCI_BF16 else "fp32")
+        # storage of the LayerNorm inputs and the gradient streams between kernels (as NDT1's residual_dtype): "fp32" by default
+        # (parity: the reference keeps these in f32 under autocast), "bf16" opt-in on the bf16 path
+        res_name = kwargs.get("residual_dtype", None) or "fp32"
         self.residual_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[res_name]
         if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
             raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16'")

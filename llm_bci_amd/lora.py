@@ -85,7 +85,9 @@ def save_adapter(model, save_dir):
     m0 = mods[0][1]
     r = m0.lora_A["default"].weight.shape[0]
     drop = m0.lora_dropout["default"]
-    cfg = {"peft_type": "LORA", "task_type": None, "inference_mode": True, "r": int(r), "lora_alpha": float(m0.scaling * r),
+    alpha = float(m0.scaling * r)
+    cfg = {"peft_type": "LORA", "task_type": None, "inference_mode": True, "r": int(r),
+           "lora_alpha": int(round(alpha)) if abs(alpha - round(alpha)) < 1e-9 else alpha,   # (peft writes an int when it is one)
            "lora_dropout": float(drop.p) if isinstance(drop, nn.Dropout) else 0.0, "bias": "none", "fan_in_fan_out": False,
            "target_modules": sorted({n.rsplit(".", 1)[-1] for n, _ in mods}), "modules_to_save": None,
            "base_model_name_or_path": getattr(getattr(model, "config", None), "_name_or_path", None) or None, "init_lora_weights": True}
@@ -110,6 +112,17 @@ def load_adapter(model, load_dir):
     cfg = json.load(open(os.path.join(load_dir, ADAPTER_CONFIG)))
     if cfg.get("peft_type", "LORA") != "LORA":
         raise ValueError(f"load_adapter: peft_type {cfg.get('peft_type')} is not LoRA")
+    # Anything that changes the adapter's scaling or structure beyond plain LoRA (W + (alpha / r) B A on `target_modules`) would load
+    # with the wrong arithmetic: refuse it by name instead.
+    unsupported = [k for k, bad in (("use_rslora", bool(cfg.get("use_rslora"))), ("use_dora", bool(cfg.get("use_dora"))),
+                                    ("rank_pattern", bool(cfg.get("rank_pattern"))), ("alpha_pattern", bool(cfg.get("alpha_pattern"))),
+                                    ("bias", cfg.get("bias", "none") not in ("none", None)),
+                                    ("modules_to_save", bool(cfg.get("modules_to_save"))),
+                                    ("fan_in_fan_out", bool(cfg.get("fan_in_fan_out"))),
+                                    ("layers_to_transform", cfg.get("layers_to_transform") is not None)) if bad]
+    if unsupported:
+        raise ValueError(f"load_adapter: {os.path.join(load_dir, ADAPTER_CONFIG)} uses {', '.join(unsupported)}, which this loader does not "
+                         "implement (plain LoRA only: r, lora_alpha, lora_dropout, target_modules); load it through peft instead")
     if not has_injected_lora(model):
         inject_lora(model, int(cfg["r"]), float(cfg["lora_alpha"]), float(cfg.get("lora_dropout", 0.0)), cfg["target_modules"])
     wpath = os.path.join(load_dir, ADAPTER_WEIGHTS)

@@ -65,7 +65,8 @@ class _NDT1Function(torch.autograd.Function):
 class NDT1(nn.Module):
     """See module docstring. kwargs: method_name ("ctc"), vocab_size, blank_id, zero_infinity
     (reference ndt1.py:465,489,517); extra: compute_dtype ("bf16" | "fp32", default bf16), residual_dtype ("bf16" | "fp32": storage
-    of the residual stream and its gradient stream between kernels; default = compute_dtype, bf16 with compute_dtype bf16 only)."""
+    of the residual stream and its gradient stream between kernels; default "fp32" = what the reference's bf16 autocast keeps in f32,
+    ndt1.py:325,328; "bf16" is opt-in and needs compute_dtype bf16)."""
 
     _supports_aux_stream = True   # _run_backward(aux=...): weight gradients / fold on a second stream (NativeTrainer, small batches)
 
@@ -116,10 +117,10 @@ class NDT1(nn.Module):
         c.pos = 1 if emb.pos else 0
         c.blank_id, c.zero_infinity = kwargs["blank_id"], 1 if kwargs["zero_infinity"] else 0
         c.dtype = self.compute_dtype
-        # storage of the residual stream / its gradient stream between kernels: "bf16" (the default of the bf16 path: every kernel still
-        # adds / normalises in f32 and rounds once at its store) or "fp32" (what bf16 autocast keeps in f32 in the reference; always
-        # for compute_dtype fp32)
-        res_name = kwargs.get("residual_dtype", None) or ("bf16" if self.compute_dtype == NBCI_BF16 else "fp32")
+        # storage of the residual stream / its gradient stream between kernels: "fp32" (the default: what bf16 autocast keeps in f32 in the
+        # reference, ndt1.py:325,328 - the parity setting, like comm_dtype "fp32") or "bf16" (opt-in, bf16 path only: every kernel still
+        # adds / normalises in f32 and rounds once at its store; about twice the logit error, profiles/r03_ab_residual.txt)
+        res_name = kwargs.get("residual_dtype", None) or "fp32"
         self.residual_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[res_name]
         if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
             raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16'")

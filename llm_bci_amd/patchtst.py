@@ -153,9 +153,9 @@ class PatchTSTForSpikingActivity(FlatParamModule):
         c.loss = LOSS_KIND[(self.loss_name, self.log_input)] if self.method == "mlm" else 0
         c.dtype = self.compute_dtype
         c.fp8_qkv = 1 if self.fp8_qkv else 0
-        # storage of the residual stream / its gradient stream between kernels (as NDT1's residual_dtype): bf16 by default on the bf16 / fp8
-        # paths, "fp32" on request and always for compute_dtype fp32
-        res_name = kwargs.get("residual_dtype", None) or ("bf16" if self.compute_dtype == NBCI_BF16 else "fp32")
+        # storage of the residual stream / its gradient stream between kernels (as NDT1's residual_dtype): "fp32" by default (parity: the
+        # reference keeps these in f32 under autocast), "bf16" opt-in on the bf16 / fp8 paths
+        res_name = kwargs.get("residual_dtype", None) or "fp32"
         self.residual_dtype = {"bf16": NBCI_BF16, "bfloat16": NBCI_BF16, "fp32": NBCI_F32, "float32": NBCI_F32}[res_name]
         if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
             raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16' or 'fp8'")

@@ -256,11 +256,22 @@ class NativeTrainer:
         self.global_step += 1
         return loss_vec, preds
 
+    @staticmethod
+    def check_kernels():
+        """Raises when a balanced grouped weight-gradient launch (gemm_streamk.hip) gave up waiting for a contributor: the tile it then
+        stored is NaN-poisoned, so the gradients since the last check cannot be trusted. Synchronises the streams those launches ran on."""
+        n = C.c_int64(0)
+        check(lib().nbci_streamk_timeouts(C.byref(n)), "nbci_streamk_timeouts")
+        if n.value:
+            raise RuntimeError(f"{n.value} stream-K owner workgroup(s) timed out waiting for a partial tile: weight gradients were "
+                               "poisoned with NaN (a stalled or starved contributor workgroup; see csrc/gemm_streamk.hip)")
+
     def read_stats(self, reset=True):
         """{'loss': sum_loss/sum_examples, 'PER': mean of per-batch ratios} over the steps since the
         last read (trainer.py:306-307,370-371); ONE host sync, one small all-reduce."""
         if self._mstream is not None:
             torch.cuda.current_stream().wait_stream(self._mstream)
+        self.check_kernels()
         s = reduce_stats(self.stats.clone(), self.group).cpu()
         out = {"loss": (s[0] / s[1]).item() if s[1] > 0 else 0.0, "n_examples": int(s[1].item()),
                "PER": (s[2] / s[3]).item() if s[3] > 0 else None}
@@ -304,11 +315,13 @@ class NativeTrainer:
             return
         if self._mstream is not None:
             torch.cuda.current_stream().wait_stream(self._mstream)
+        self.check_kernels()   # never persist weights that a timed-out (NaN-poisoned) weight gradient may have reached
         self.model.save_checkpoint(save_dir)
         m = self.model
         state = {"layout": [(n, o, k) for (n, o, k, _s, _g) in m._layout], "m": self.m.cpu(), "v": self.v.cpu(),
                  "global_step": self.global_step, "opt_step": self.opt_step, "step_seed": m._step_seed,
-                 "sched_epoch": getattr(self.sched, "epoch", 0), "grads": self.grads.cpu()}
+                 "sched_epoch": getattr(self.sched, "epoch", 0), "grads": self.grads.cpu(),
+                 "numerics": self._numerics()}
         if hasattr(m, "_resume_state"):   # BCI: f32 masters of the LLM's trainable (half-precision) tensors
             state["model_extra"] = m._resume_state()
         torch.save(state, os.path.join(save_dir, "trainer_state.pth"))
@@ -326,3 +339,16 @@ class NativeTrainer:
             self.model._load_resume_state(st.get("model_extra"))
         if hasattr(self.sched, "epoch"):
             self.sched.epoch = st["sched_epoch"]
+        was = st.get("numerics")
+        if was is not None and was != self._numerics():
+            import warnings
+            warnings.warn(f"resuming with different numerics than the run that wrote {load_dir}: saved {was}, now {self._numerics()} "
+                          "(compute_dtype / residual_dtype / comm_dtype change the rounding of every step from here on)")
+
+    def _numerics(self):
+        """the storage / arithmetic choices that change a run's rounding: recorded in trainer_state.pth, compared on resume"""
+        names = {0: "fp32", 1: "bf16"}
+        m = self.model
+        return {"compute_dtype": names.get(getattr(m, "compute_dtype", 0), str(getattr(m, "compute_dtype", None))),
+                "residual_dtype": names.get(getattr(m, "residual_dtype", 0), str(getattr(m, "residual_dtype", None))),
+                "comm_dtype": "bf16" if self.reducer.comm_bf16 else "fp32"}

@@ -271,6 +271,16 @@ def test_lora_checkpoint_is_adapter_only_and_round_trips_without_peft(tmp_path):
     save_file(few, os.path.join(d, "adapter_model.safetensors"))
     with pytest.raises(KeyError):
         _tiny_bci(cfg).load_checkpoint(d)
+    # adapter variants whose arithmetic this loader does not implement are refused by name, not loaded with the wrong scaling
+    save_file(sd, os.path.join(d, "adapter_model.safetensors"))
+    assert isinstance(ac["lora_alpha"], int)                                                # as peft writes an integral alpha
+    for key, val in (("use_rslora", True), ("use_dora", True), ("rank_pattern", {"q_proj": 8}), ("alpha_pattern", {"q_proj": 4}),
+                     ("bias", "all"), ("modules_to_save", ["lm_head"])):
+        json.dump(dict(ac, **{key: val}), open(os.path.join(d, "adapter_config.json"), "w"))
+        with pytest.raises(ValueError, match=key):
+            L.load_adapter(_tiny_bci(cfg).llm, d)
+    json.dump(ac, open(os.path.join(d, "adapter_config.json"), "w"))
+    L.load_adapter(_tiny_bci(cfg).llm, d)
 
 
 def test_bci_joint_flat_layout_on_cpu():
@@ -340,6 +350,7 @@ def test_ndt1_residual_dtype_needs_the_bf16_path():
     kw = dict(method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True)
     with pytest.raises(Exception, match="residual_dtype 'bf16' needs compute_dtype 'bf16'"):
         NDT1({}, compute_dtype="fp32", residual_dtype="bf16", **kw)
-    assert NDT1({}, compute_dtype="bf16", **kw)._ccfg.residual_dtype == 1            # default of the bf16 path
+    assert NDT1({}, compute_dtype="bf16", **kw)._ccfg.residual_dtype == 0            # default = the parity setting (reference ndt1.py:325,328)
+    assert NDT1({}, compute_dtype="bf16", residual_dtype="bf16", **kw)._ccfg.residual_dtype == 1   # opt-in
     assert NDT1({}, compute_dtype="bf16", residual_dtype="fp32", **kw)._ccfg.residual_dtype == 0
     assert NDT1({}, compute_dtype="fp32", **kw)._ccfg.residual_dtype == 0

@@ -209,7 +209,7 @@ def test_train_mode_dropout_and_maskers_match_oracle(dtype, N, lens):
     mc = dict(active=True, force_active=True, mode="neuron", ratio=0.3, zero_ratio=0.8, random_ratio=0.5, expand_prob=0.0, max_timespan=1)
     over = {"encoder": {"embedder": {"max_n_bins": T, "dropout": 0.2}, "hidden_size": 32, "n_heads": 2, "n_layers": 2, "dropout": 0.4,
                         "max_n_channels": 96, "embed_region": False}, "masker": {"main": mc}}
-    kw = {"residual_dtype": "fp32"} if dtype.endswith("f32 streams") else {}   # ("bf16": the default, bf16 streams)
+    kw = {"residual_dtype": "fp32" if (dtype.endswith("f32 streams") or dtype == "fp32") else "bf16"}   # ("bf16": the opt-in bf16 streams)
     dtype = dtype.split("/")[0]
     m = _model(over, dtype=dtype, **kw).to(DEV)
     p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}

@@ -136,7 +136,7 @@ def test_train_mode_dropout_and_random_mask_match_oracle(method, dtype):
            "num_attention_heads": 2, "ffn_dim": 64, "attention_dropout": 0.3, "ff_dropout": 0.4, "path_dropout": 0.1, "positional_dropout": 0.1,
            "do_mask_input": True, "random_mask_ratio": 0.4}
     kw = dict(method_name="ctc", vocab_size=11, blank_id=0, zero_infinity=True) if method == "ctc" else dict(method_name="mlm", loss="poisson_nll", log_input=True)
-    extra = {"residual_dtype": "fp32"} if dtype.endswith("f32 streams") else None   # ("bf16": bf16 streams, the default)
+    extra = {"residual_dtype": "fp32" if (dtype.endswith("f32 streams") or dtype == "fp32") else "bf16"}   # ("bf16": the opt-in bf16 streams)
     dtype = dtype.split("/")[0]
     m = _model({"encoder": enc}, dtype=dtype, kwargs=kw, extra=extra).to(DEV)
     st = {k: v.detach().float().cpu().numpy().copy() for k, v in m.state_dict().items()}

@@ -26,13 +26,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--residual-dtype", default=None, help="fp32 | bf16 (default: bf16 with --dtype bf16)")
+    ap.add_argument("--residual-dtype", default="bf16", help="fp32 | bf16 (the models default to fp32 = parity; the benches measure the bf16 streams unless told otherwise)")
     a = ap.parse_args()
     from llm_bci_amd.itransformer import iTransformer
     from llm_bci_amd.trainer import NativeTrainer
     torch.manual_seed(1)
     over = {"encoder": {"embed_region": False}, "masker": {"main": {"active": True}}}
-    m = iTransformer(over, method_name="mlm", loss="poisson_nll", log_input=True, compute_dtype=a.dtype, residual_dtype=a.residual_dtype).to("cuda")
+    m = iTransformer(over, method_name="mlm", loss="poisson_nll", log_input=True, compute_dtype=a.dtype, residual_dtype=("fp32" if a.dtype == "fp32" else a.residual_dtype)).to("cuda")
     tr = NativeTrainer(m, lr=1e-4, wd=0.01, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.15, div_factor=25, compute_per=False)
     g = np.random.default_rng(0)
     B, T, N = a.batch, 100, a.channels

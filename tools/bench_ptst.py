@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--residual-dtype", default=None, help="fp32 | bf16 (default: bf16 with --dtype bf16 / fp8)")
+    ap.add_argument("--residual-dtype", default="bf16", help="fp32 | bf16 (the models default to fp32 = parity; the benches measure the bf16 streams unless told otherwise)")
     ap.add_argument("--method", default="ctc")
     a = ap.parse_args()
     from llm_bci_amd.patchtst import PatchTSTForSpikingActivity
@@ -33,7 +33,7 @@ def main():
     T = 2050
     over = {"encoder": {"num_input_channels": a.channels, "context_length": T, "do_mask_input": a.method == "mlm"}}
     kw = dict(method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True) if a.method == "ctc" else dict(method_name="mlm", loss="poisson_nll", log_input=True)
-    m = PatchTSTForSpikingActivity(over, compute_dtype=a.dtype, residual_dtype=a.residual_dtype, **kw).to("cuda")
+    m = PatchTSTForSpikingActivity(over, compute_dtype=a.dtype, residual_dtype=("fp32" if a.dtype == "fp32" else a.residual_dtype), **kw).to("cuda")
     tr = NativeTrainer(m, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0, div_factor=25, compute_per=a.method == "ctc")
     g = np.random.default_rng(0)
     B, C = a.batch, a.channels
