@@ -459,6 +459,13 @@ typedef struct nbci_itr_config { /* configs/itransformer.yaml, flattened */
     int32_t residual_dtype;          /* storage of the LayerNorm inputs r1 / r2 and of the gradient streams between kernels: NBCI_F32 (default),
                                       * or NBCI_BF16 (dtype bf16 only; f32 arithmetic, one rounding per store - as nbci_ndt1_config.residual_dtype).
                                       * With bf16 the residual a layer adds is the bf16 LayerNorm output its GEMMs read (no f32 copy of it). */
+    int32_t embed_depth;             /* 1: depth_embeddings = LayerNorm(Linear(act(Linear(neuron_depths)))) added to the channel tokens
+                                      * (itransformer.py:143-150,200-202); io.neuron_depths required */
+    int32_t emb_mode;                /* 0: `mlp` embedder (itransformer.py:108-118); 1: `transformer` = UnivariateTransformer (:40-93) + embed_proj
+                                      * (:119-124): every (sample, channel) is a sequence [cls | its max_n_bins bins], token = Linear(act(Linear(count)))
+                                      * + embed_pos[timestamp], a post-norm encoder of emb_layers layers, the CLS output projected to `hidden` */
+    int32_t emb_hidden, emb_heads, emb_layers;   /* configs/itransformer.yaml encoder.embedder.{hidden_size, n_heads, n_layers} (emb_mode 1);
+                                                  * its layers' dropout is embed_dropout, its activation `act` (relu) */
 } nbci_itr_config;
 
 typedef struct nbci_itr_io {
@@ -469,6 +476,8 @@ typedef struct nbci_itr_io {
     const int64_t* spikes_mask;         /* (B,T) padding mask */
     const int64_t* spikes_spacestamp;   /* (B,N) channel ids or NULL = arange(N) */
     const int64_t* region_idx;          /* (B,N) region ids when n_regions > 0 */
+    const int64_t* spikes_timestamp;    /* (B,T) bin timestamps, values < max_n_bins (emb_mode 1: rows of embed_pos), or NULL = arange(T) */
+    const float* neuron_depths;         /* (B,N) f32 when embed_depth */
     int32_t train, want_grad;
     uint32_t seed;
     float grad_scale;

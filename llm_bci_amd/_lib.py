@@ -83,12 +83,14 @@ LOSS_KIND = {("poisson_nll", True): 0, ("poisson_nll", False): 1, ("mse", True):
 class ItrConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("max_n_bins", "hidden", "n_heads", "n_layers", "max_n_channels", "n_regions", "act",
                                          "dec_act")] + [("embed_dropout", C.c_float), ("dropout", C.c_float)] + [
-        (n, C.c_int32) for n in ("use_cls", "mlp_decoder", "loss", "dtype", "residual_dtype")]
+        (n, C.c_int32) for n in ("use_cls", "mlp_decoder", "loss", "dtype", "residual_dtype", "embed_depth", "emb_mode", "emb_hidden",
+                                 "emb_heads", "emb_layers")]
 
 
 class ItrIO(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("spikes", C.c_void_p), ("masked", C.c_void_p), ("mask", C.c_void_p),
                 ("spikes_mask", C.c_void_p), ("spikes_spacestamp", C.c_void_p), ("region_idx", C.c_void_p),
+                ("spikes_timestamp", C.c_void_p), ("neuron_depths", C.c_void_p),
                 ("train", C.c_int32), ("want_grad", C.c_int32), ("seed", C.c_uint32), ("grad_scale", C.c_float),
                 ("preds", C.c_void_p), ("mask_out", C.c_void_p), ("loss", C.c_void_p), ("n_examples", C.c_void_p),
                 ("hidden_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]

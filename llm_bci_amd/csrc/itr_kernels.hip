@@ -1,6 +1,8 @@
 // itr_kernels.hip — the non-GEMM kernels that only the iTransformer SSL path needs (models/masker.py,
 // models/itransformer.py). All HBM-bound: one pass over the (B,T,N) spike tensor each, transposes go
 // through a padded LDS tile so both sides stay coalesced. See kernels.h for the launch API.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace nbci {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void itr_assemble_fwd_kernel(const float* __re
                                                                const long long* __restrict__ idx2, const float* __restrict__ cls,
                                                                float* __restrict__ x32, TO* __restrict__ xb, float* __restrict__ mean,
                                                                float* __restrict__ rstd, int B, int N, int H, int use_cls,
-                                                               unsigned thr, float dscale, uint32_t key) {
+                                                               unsigned thr, float dscale, uint32_t key, const float* __restrict__ extra) {
     const int lane = threadIdx.x & 63;
     const int S = N + use_cls;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void itr_assemble_fwd_kernel(const float* __re
                                        (v[k].z - mu) * rs * ww.z + bv.z, (v[k].w - mu) * rs * ww.w + bv.w);
                 if (e1) { const float4 e = *(const float4*)(e1 + c); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
                 if (e2) { const float4 e = *(const float4*)(e2 + c); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
+                if (extra) { const float4 e = *(const float4*)(extra + r0 * H + c); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
                 v[k] = r;
             }
         }
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void itr_assemble_fwd_kernel(const float* __re
 
 int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, const float* tab1, const int64_t* idx1, const float* tab2,
                             const int64_t* idx2, const float* cls, float* x32, void* xb, int xb_dtype, float* mean, float* rstd, int B,
-                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const float* extra) {
     NBCI_REQUIRE(H % 4 == 0 && H <= 4096, NBCI_ESHAPE, "itr assemble: hidden must be a multiple of 4 and <= 4096");
     NBCI_REQUIRE((long long)B * (N + use_cls) * H < (1ll << 32), NBCI_ESHAPE, "itr assemble: tensor too large for the dropout counter");
     const unsigned thr = drop_threshold(drop_p);
@@ -222,7 +225,7 @@ int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, con
     const int nv = (H + 255) / 256;
 #define ASM(NVV, TO)                                                                                                        \
     hipLaunchKernelGGL((itr_assemble_fwd_kernel<NVV, TO>), g, dim3(256), 0, s, t2, w, b, tab1, (const long long*)idx1, tab2,    \
-                       (const long long*)idx2, cls, x32, (TO*)xb, mean, rstd, B, N, H, use_cls, thr, dscale, drop_key(seed, site))
+                       (const long long*)idx2, cls, x32, (TO*)xb, mean, rstd, B, N, H, use_cls, thr, dscale, drop_key(seed, site), extra)
     if (xb_dtype == NBCI_BF16) { if (nv <= 4) ASM(4, bf16_t); else ASM(16, bf16_t); }
     else { if (nv <= 4) ASM(4, float); else ASM(16, float); }
 #undef ASM
@@ -367,6 +370,183 @@ int itr_mlm_loss_launch(const float* pred, int ldp, const float* targets, const 
                            (const long long*)smask, preds_out, (long long*)mask_out, (float*)dpred, loss,
                            (unsigned long long*)n_examples, T, N, use_cls, kind, grad_scale);
     return check_launch("itr_mlm_loss");
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear(1 -> W) + ReLU on a scalar per row: the first layer of the UnivariateTransformer's embed_spikes (models/itransformer.py:48-52,81:
+// the scalar is one bin's spike count) and of depth_embeddings (:145-150,201: the scalar is the neuron's depth).
+//   out[r][j] = relu(x(r) * w[j] + b[j])
+// period > 0: rows come in sequences of `period` = 1 + T rows whose first row is the CLS slot (written as zeros, so it adds nothing to
+// the weight gradients downstream) and x(r) = x[(r / period) * (period - 1) + r % period - 1]; period == 0: x(r) = x[r].
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void scalar_lin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             TO* __restrict__ out, long long rows, int W, int period) {
+    const long long n = rows * (long long)(W / 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / (W / 4);
+        const int c = (int)(i % (W / 4)) * 4;
+        float xv = 0.f;
+        bool cls = false;
+        if (period > 0) {
+            const long long z = r / period;
+            const int j = (int)(r % period);
+            cls = j == 0;
+            if (!cls) xv = x[z * (period - 1) + j - 1];
+        } else {
+            xv = x[r];
+        }
+        const float4 ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
+        float v[4] = {fmaxf(xv * ww.x + bb.x, 0.f), fmaxf(xv * ww.y + bb.y, 0.f), fmaxf(xv * ww.z + bb.z, 0.f), fmaxf(xv * ww.w + bb.w, 0.f)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stv<TO>(out, r * W + c + e, cls ? 0.f : v[e]);
+    }
+}
+
+int scalar_lin_fwd_launch(const float* x, const float* w, const float* b, void* out, int out_dtype, long long rows, int W, int period, hipStream_t s) {
+    NBCI_REQUIRE(W % 4 == 0 && rows > 0, NBCI_ESHAPE, "scalar linear: width must be a multiple of 4");
+    const long long n = rows * (W / 4);
+    dim3 g((unsigned)std::min<long long>((n + 255) / 256, 1 << 16));
+    if (out_dtype == NBCI_BF16) hipLaunchKernelGGL((scalar_lin_fwd_kernel<bf16_t>), g, dim3(256), 0, s, x, w, b, (bf16_t*)out, rows, W, period);
+    else hipLaunchKernelGGL((scalar_lin_fwd_kernel<float>), g, dim3(256), 0, s, x, w, b, (float*)out, rows, W, period);
+    return check_launch("scalar_lin_fwd");
+}
+
+// its backward: dw[j] += sum_r du[r][j] x(r), db[j] += sum_r du[r][j] (du already carries relu' - the gated data-gradient GEMM wrote it).
+// A block walks SL_ROWS rows; a thread owns one column of a 256-column pass; replicated atomics at the end (one per thread and pass).
+constexpr int SL_ROWS = 1024;
+template <typename TI>
+__global__ __launch_bounds__(256) void scalar_lin_bwd_kernel(const TI* __restrict__ du, const float* __restrict__ x, float* __restrict__ dw,
+                                                             float* __restrict__ db, RepCfg rc, long long rows, int W, int period) {
+    const int cpp = W < 256 ? W : 256;            // columns per pass
+    const int rpar = 256 / cpp;                   // rows walked side by side
+    const int tc = threadIdx.x % cpp, tr = threadIdx.x / cpp;
+    const long long r0 = (long long)blockIdx.x * SL_ROWS, r1 = r0 + SL_ROWS < rows ? r0 + SL_ROWS : rows;
+    if (tr >= rpar) return;
+    for (int c0 = 0; c0 < W; c0 += cpp) {
+        const int c = c0 + tc;
+        if (c >= W) continue;
+        float sw = 0.f, sb = 0.f;
+        for (long long r = r0 + tr; r < r1; r += rpar) {
+            float xv;
+            if (period > 0) {
+                const int j = (int)(r % period);
+                if (j == 0) continue;              // CLS slot: no scalar input
+                xv = x[(r / period) * (period - 1) + j - 1];
+            } else {
+                xv = x[r];
+            }
+            const float g = (float)du[r * W + c];
+            sw += g * xv; sb += g;
+        }
+        atomicAdd(rep_ptr(dw, rc, blockIdx.x) + c, sw);
+        atomicAdd(rep_ptr(db, rc, blockIdx.x) + c, sb);
+    }
+}
+
+int scalar_lin_bwd_launch(const void* du, int du_dtype, const float* x, float* dw, float* db, RepCfg rc, long long rows, int W, int period, hipStream_t s) {
+    dim3 g((unsigned)((rows + SL_ROWS - 1) / SL_ROWS));
+    if (du_dtype == NBCI_BF16) hipLaunchKernelGGL((scalar_lin_bwd_kernel<bf16_t>), g, dim3(256), 0, s, (const bf16_t*)du, x, dw, db, rc, rows, W, period);
+    else hipLaunchKernelGGL((scalar_lin_bwd_kernel<float>), g, dim3(256), 0, s, (const float*)du, x, dw, db, rc, rows, W, period);
+    return check_launch("scalar_lin_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// UnivariateTransformer input assembly (itransformer.py:83-87): per (sample, channel) sequence of 1 + T rows,
+//   row 0 = cls_embed, row 1 + t = t_in[row] + embed_pos[ts[b][t]]   (t_in = the second embed_spikes Linear's output, bias included)
+// written as the operand copy xb and (y32 != NULL) the f32 residual copy.
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void uni_finish_fwd_kernel(const float* __restrict__ t_in, const float* __restrict__ pos, const long long* __restrict__ ts,
+                                                             const float* __restrict__ cls, float* __restrict__ y32, TO* __restrict__ xb, long long rows,
+                                                             int N, int T, int h) {
+    const long long n = rows * (long long)(h / 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / (h / 4);
+        const int c = (int)(i % (h / 4)) * 4;
+        const long long z = r / (T + 1);
+        const int j = (int)(r % (T + 1));
+        float4 v;
+        if (j == 0) {
+            v = *(const float4*)(cls + c);
+        } else {
+            const long long b = z / N;
+            const long long tpos = ts ? ts[b * T + j - 1] : (long long)(j - 1);
+            const float4 a = *(const float4*)(t_in + r * h + c), p = *(const float4*)(pos + tpos * h + c);
+            v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        }
+        if (y32) *(float4*)(y32 + r * h + c) = v;
+        stv<TO>(xb, r * h + c, v.x); stv<TO>(xb, r * h + c + 1, v.y); stv<TO>(xb, r * h + c + 2, v.z); stv<TO>(xb, r * h + c + 3, v.w);
+    }
+}
+
+int uni_finish_fwd_launch(const float* t_in, const float* pos, const int64_t* ts, const float* cls, float* y32, void* xb, int xb_dtype, int B, int N,
+                          int T, int h, hipStream_t s) {
+    NBCI_REQUIRE(h % 4 == 0, NBCI_ESHAPE, "uni finish: embedder hidden size must be a multiple of 4");
+    const long long rows = (long long)B * N * (T + 1), n = rows * (h / 4);
+    dim3 g((unsigned)std::min<long long>((n + 255) / 256, 1 << 16));
+    if (xb_dtype == NBCI_BF16)
+        hipLaunchKernelGGL((uni_finish_fwd_kernel<bf16_t>), g, dim3(256), 0, s, t_in, pos, (const long long*)ts, cls, y32, (bf16_t*)xb, rows, N, T, h);
+    else
+        hipLaunchKernelGGL((uni_finish_fwd_kernel<float>), g, dim3(256), 0, s, t_in, pos, (const long long*)ts, cls, y32, (float*)xb, rows, N, T, h);
+    return check_launch("uni_finish_fwd");
+}
+
+// its backward, part 1: dseq (the gradient stream at the embedder stack's input) -> dte = the operand copy of the token rows' gradient with the
+// CLS rows zeroed (they have no embed_spikes input), and cls_embed's gradient = the sum of the CLS rows.
+template <typename TG, typename TO>
+__global__ __launch_bounds__(256) void uni_split_bwd_kernel(const TG* __restrict__ dseq, TO* __restrict__ dte, float* __restrict__ dcls, RepCfg rc,
+                                                            long long rows, int T, int h) {
+    const long long n = rows * (long long)h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / h;
+        const int c = (int)(i % h);
+        const float v = (float)dseq[i];
+        if (r % (T + 1) == 0) {
+            atomicAdd(rep_ptr(dcls, rc, (unsigned)(r / (T + 1))) + c, v);
+            stv<TO>(dte, i, 0.f);
+        } else {
+            stv<TO>(dte, i, v);
+        }
+    }
+}
+
+int uni_split_bwd_launch(const void* dseq, int stream_dtype, void* dte, int dte_dtype, float* dcls, RepCfg rc, long long rows, int T, int h, hipStream_t s) {
+    const long long n = rows * h;
+    dim3 g((unsigned)std::min<long long>((n + 255) / 256, 1 << 16));
+#define USB(TG, TO) hipLaunchKernelGGL((uni_split_bwd_kernel<TG, TO>), g, dim3(256), 0, s, (const TG*)dseq, (TO*)dte, dcls, rc, rows, T, h)
+    if (stream_dtype == NBCI_BF16) { if (dte_dtype == NBCI_BF16) USB(bf16_t, bf16_t); else USB(bf16_t, float); }
+    else { if (dte_dtype == NBCI_BF16) USB(float, bf16_t); else USB(float, float); }
+#undef USB
+    return check_launch("uni_split_bwd");
+}
+
+// part 2: embed_pos gradient: dpos[ts[b][t]][:] += sum over the sample's N channels of dseq[(b, n), 1 + t][:] (itransformer.py:85: the position
+// embedding is broadcast over channels). One wave per (b, t): the channel sum stays in registers, then one atomic per column.
+template <typename TG>
+__global__ __launch_bounds__(256) void uni_posgrad_kernel(const TG* __restrict__ dseq, const long long* __restrict__ ts, float* __restrict__ dpos, int B,
+                                                          int N, int T, int h) {
+    const int lane = threadIdx.x & 63;
+    const long long bt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= (long long)B * T) return;
+    const int b = (int)(bt / T), t = (int)(bt % T);
+    const long long tpos = ts ? ts[bt] : (long long)t;
+    for (int c0 = 0; c0 < h; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= h) continue;
+        float acc = 0.f;
+        const TG* p = dseq + (((long long)b * N) * (T + 1) + 1 + t) * h + c;
+#pragma unroll 8
+        for (int n = 0; n < N; ++n) acc += (float)p[(long long)n * (T + 1) * h];
+        atomicAdd(dpos + tpos * h + c, acc);
+    }
+}
+
+int uni_posgrad_launch(const void* dseq, int stream_dtype, const int64_t* ts, float* dpos, int B, int N, int T, int h, hipStream_t s) {
+    dim3 g((unsigned)(((long long)B * T + 3) / 4));
+    if (stream_dtype == NBCI_BF16) hipLaunchKernelGGL((uni_posgrad_kernel<bf16_t>), g, dim3(256), 0, s, (const bf16_t*)dseq, (const long long*)ts, dpos, B, N, T, h);
+    else hipLaunchKernelGGL((uni_posgrad_kernel<float>), g, dim3(256), 0, s, (const float*)dseq, (const long long*)ts, dpos, B, N, T, h);
+    return check_launch("uni_posgrad");
 }
 
 }  // namespace nbci

@@ -123,7 +123,17 @@ int masker_launch(const nbci_masker_desc& d, hipStream_t s);
 int btn_to_bnt_launch(const float* in, float* out, int B, int T, int N, hipStream_t s);
 int itr_assemble_fwd_launch(const float* t2, const float* w, const float* b, const float* tab1, const int64_t* idx1, const float* tab2,
                             const int64_t* idx2, const float* cls, float* x32, void* xb, int xb_dtype, float* mean, float* rstd, int B,
-                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+                            int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site, hipStream_t s,
+                            const float* extra = nullptr);   // extra: optional f32 (B*N, H) added to the channel tokens (the depth embedding)
+// Linear(1 -> W) + ReLU of a scalar per row and its weight / bias gradients (UnivariateTransformer embed_spikes.0, depth_embeddings.0)
+int scalar_lin_fwd_launch(const float* x, const float* w, const float* b, void* out, int out_dtype, long long rows, int W, int period, hipStream_t s);
+int scalar_lin_bwd_launch(const void* du, int du_dtype, const float* x, float* dw, float* db, RepCfg rc, long long rows, int W, int period, hipStream_t s);
+// UnivariateTransformer (itransformer.py:75-93): input assembly [cls | tokens + embed_pos] and its backward (token-gradient operand copy + cls
+// gradient; position-table gradient)
+int uni_finish_fwd_launch(const float* t_in, const float* pos, const int64_t* ts, const float* cls, float* y32, void* xb, int xb_dtype, int B, int N,
+                          int T, int h, hipStream_t s);
+int uni_split_bwd_launch(const void* dseq, int stream_dtype, void* dte, int dte_dtype, float* dcls, RepCfg rc, long long rows, int T, int h, hipStream_t s);
+int uni_posgrad_launch(const void* dseq, int stream_dtype, const int64_t* ts, float* dpos, int B, int N, int T, int h, hipStream_t s);
 int itr_assemble_bwd_launch(const void* dx0, float* dtok, float* dtab1, const int64_t* idx1, float* dtab2, const int64_t* idx2,
                             float* dcls, RepCfg rc, int B, int N, int H, int use_cls, float drop_p, uint32_t seed, uint32_t site,
                             hipStream_t s, int dx_dtype = NBCI_F32);

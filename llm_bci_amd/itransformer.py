@@ -1,7 +1,8 @@
 """iTransformer (SSL / mlm) behind the reference's plugin surface, running on libnbci.so.
 
-Drop-in for `models.itransformer.iTransformer` (reference models/itransformer.py:212-375) for method "mlm" with the
-`mlp` embedder: same constructor `(config, **kwargs)` (kwargs: method_name, loss, log_input), same forward keyword
+Drop-in for `models.itransformer.iTransformer` (reference models/itransformer.py:212-375) for method "mlm" with either embedder
+(`mlp`, :108-118, or `transformer` = UnivariateTransformer, :40-93,119-124) and the channel / region / depth embeddings
+(:126-150,189-202): same constructor `(config, **kwargs)` (kwargs: method_name, loss, log_input), same forward keyword
 names, returns `iTransformerOutput(loss = masked sum, n_examples = #masked bins, mask, preds (B,T,N), targets)`, same
 state-dict keys (`encoder.embed.0.0.weight`, `encoder.transformer.layers.N.self_attn.in_proj_weight`, ...,
 `decoder.2.bias`) and checkpoint files. The maskers (models/masker.py) run on the device through `nbci_masker`.
@@ -70,28 +71,49 @@ def region_sample(seed, site, regions, n):
     return pool[:n]
 
 
-def layout_of(T, H, L, C_, R, use_cls, mlp_decoder):
+def _layer_entries(b, pre, H, seg):
+    """one torch.nn.TransformerEncoderLayer in state-dict order"""
+    b.add(pre + "self_attn.in_proj_weight", (3 * H, H), seg); b.add(pre + "self_attn.in_proj_bias", (3 * H,), seg)
+    b.add(pre + "self_attn.out_proj.weight", (H, H), seg); b.add(pre + "self_attn.out_proj.bias", (H,), seg)
+    b.add(pre + "linear1.weight", (4 * H, H), seg); b.add(pre + "linear1.bias", (4 * H,), seg)
+    b.add(pre + "linear2.weight", (H, 4 * H), seg); b.add(pre + "linear2.bias", (H,), seg)
+    b.add(pre + "norm1.weight", (H,), seg); b.add(pre + "norm1.bias", (H,), seg)
+    b.add(pre + "norm2.weight", (H,), seg); b.add(pre + "norm2.bias", (H,), seg)
+
+
+def layout_of(T, H, L, C_, R, use_cls, mlp_decoder, embed_depth=False, embedder=None):
+    """embedder: None = `mlp`; dict(h, nh, L) = the UnivariateTransformer embedder (itransformer.py:40-93) + embed_proj (:119-124)"""
     b = LayoutBuilder()
-    b.add("encoder.embed.0.0.weight", (H, T), 0); b.add("encoder.embed.0.0.bias", (H,), 0)
-    b.add("encoder.embed.0.3.weight", (H, H), 0); b.add("encoder.embed.0.3.bias", (H,), 0)
-    b.add("encoder.embed.1.weight", (H,), 0); b.add("encoder.embed.1.bias", (H,), 0)
+    if embedder is None:
+        b.add("encoder.embed.0.0.weight", (H, T), 0); b.add("encoder.embed.0.0.bias", (H,), 0)
+        b.add("encoder.embed.0.3.weight", (H, H), 0); b.add("encoder.embed.0.3.bias", (H,), 0)
+        b.add("encoder.embed.1.weight", (H,), 0); b.add("encoder.embed.1.bias", (H,), 0)
+    else:
+        h = embedder["h"]
+        b.add("encoder.embed.embed_spikes.0.weight", (h, 1), 0); b.add("encoder.embed.embed_spikes.0.bias", (h,), 0)
+        b.add("encoder.embed.embed_spikes.2.weight", (h, h), 0); b.add("encoder.embed.embed_spikes.2.bias", (h,), 0)
+        b.add("encoder.embed.embed_pos.weight", (T, h), 0)
+        b.add("encoder.embed.cls_embed.weight", (1, h), 0)
+        for l in range(embedder["L"]):
+            _layer_entries(b, f"encoder.embed.transformer.layers.{l}.", h, 0)
+        b.add("encoder.embed.transformer.norm.weight", (h,), 0); b.add("encoder.embed.transformer.norm.bias", (h,), 0)
+        b.add("encoder.embed_proj.0.weight", (H, h), 0); b.add("encoder.embed_proj.0.bias", (H,), 0)
+        b.add("encoder.embed_proj.1.weight", (H,), 0); b.add("encoder.embed_proj.1.bias", (H,), 0)
     if C_:
         b.add("encoder.channel_embeddings.0.weight", (C_, H), 0)
         b.add("encoder.channel_embeddings.1.weight", (H,), 0); b.add("encoder.channel_embeddings.1.bias", (H,), 0)
     if R:
         b.add("encoder.region_embeddings.0.weight", (R, H), 0)
         b.add("encoder.region_embeddings.1.weight", (H,), 0); b.add("encoder.region_embeddings.1.bias", (H,), 0)
+    if embed_depth:
+        b.add("encoder.depth_embeddings.0.weight", (H, 1), 0); b.add("encoder.depth_embeddings.0.bias", (H,), 0)
+        b.add("encoder.depth_embeddings.2.weight", (H, H), 0); b.add("encoder.depth_embeddings.2.bias", (H,), 0)
+        b.add("encoder.depth_embeddings.3.weight", (H,), 0); b.add("encoder.depth_embeddings.3.bias", (H,), 0)
     if use_cls:
         b.add("encoder.cls_embed.weight", (1, H), 0)
     b.end_segment()
     for l in range(L):
-        pre = f"encoder.transformer.layers.{l}."
-        b.add(pre + "self_attn.in_proj_weight", (3 * H, H), l + 1); b.add(pre + "self_attn.in_proj_bias", (3 * H,), l + 1)
-        b.add(pre + "self_attn.out_proj.weight", (H, H), l + 1); b.add(pre + "self_attn.out_proj.bias", (H,), l + 1)
-        b.add(pre + "linear1.weight", (4 * H, H), l + 1); b.add(pre + "linear1.bias", (4 * H,), l + 1)
-        b.add(pre + "linear2.weight", (H, 4 * H), l + 1); b.add(pre + "linear2.bias", (H,), l + 1)
-        b.add(pre + "norm1.weight", (H,), l + 1); b.add(pre + "norm1.bias", (H,), l + 1)
-        b.add(pre + "norm2.weight", (H,), l + 1); b.add(pre + "norm2.bias", (H,), l + 1)
+        _layer_entries(b, f"encoder.transformer.layers.{l}.", H, l + 1)
         b.end_segment()
     hs = L + 1
     b.add("encoder.transformer.norm.weight", (H,), hs); b.add("encoder.transformer.norm.bias", (H,), hs)
@@ -104,11 +126,12 @@ def layout_of(T, H, L, C_, R, use_cls, mlp_decoder):
     return b
 
 
-def reference_order_init(cfg_shapes, seed=None, n_regions=0, dropout=0.0):
+def reference_order_init(cfg_shapes, seed=None, n_regions=0, dropout=0.0, embed_depth=False, embedder=None, embedder_dropout=0.0):
     """Initial weights drawn exactly as the reference's constructors draw them, in their order (itransformer.py:107-173,
     264-279), using torch's own layer constructors (pure CPU; torch is the init plumbing, nothing from the reference):
-    the embedding MLP's two Linears, channel (region) Embedding tables, the CLS Embedding, ONE
-    nn.TransformerEncoderLayer that nn.TransformerEncoder deep-copies into every layer (so all layers start equal),
+    the embedder (the MLP's two Linears - or the UnivariateTransformer's embed_spikes Linears, embed_pos / cls Embeddings, ONE
+    TransformerEncoderLayer deep-copied into its layers, then embed_proj), channel / region Embedding tables, the depth MLP, the CLS
+    Embedding, ONE nn.TransformerEncoderLayer that nn.TransformerEncoder deep-copies into every layer (so all layers start equal),
     then the decoder Linears. With torch.manual_seed(s) beforehand the model equals the reference's bit for bit."""
     T, H, L, nh, C_ = (cfg_shapes[k] for k in ("T", "H", "L", "nh", "C"))
     if seed is not None:
@@ -119,15 +142,33 @@ def reference_order_init(cfg_shapes, seed=None, n_regions=0, dropout=0.0):
         m = nn.Linear(i, o)
         p[name + ".weight"], p[name + ".bias"] = m.weight.detach(), m.bias.detach()
 
-    lin("encoder.embed.0.0", T, H)
-    lin("encoder.embed.0.3", H, H)
-    p["encoder.embed.1.weight"], p["encoder.embed.1.bias"] = torch.ones(H), torch.zeros(H)
+    if embedder is None:
+        lin("encoder.embed.0.0", T, H)
+        lin("encoder.embed.0.3", H, H)
+        p["encoder.embed.1.weight"], p["encoder.embed.1.bias"] = torch.ones(H), torch.zeros(H)
+    else:   # UnivariateTransformer.__init__ (itransformer.py:48-73), then embed_proj (:121-124)
+        h = embedder["h"]
+        lin("encoder.embed.embed_spikes.0", 1, h)
+        lin("encoder.embed.embed_spikes.2", h, h)
+        p["encoder.embed.embed_pos.weight"] = nn.Embedding(T, h).weight.detach()
+        p["encoder.embed.cls_embed.weight"] = nn.Embedding(1, h).weight.detach()
+        elayer = nn.TransformerEncoderLayer(d_model=h, nhead=embedder["nh"], dim_feedforward=4 * h, dropout=embedder_dropout, batch_first=True)
+        for l in range(embedder["L"]):
+            for k, v in elayer.state_dict().items():
+                p[f"encoder.embed.transformer.layers.{l}.{k}"] = v.detach().clone()
+        p["encoder.embed.transformer.norm.weight"], p["encoder.embed.transformer.norm.bias"] = torch.ones(h), torch.zeros(h)
+        lin("encoder.embed_proj.0", h, H)
+        p["encoder.embed_proj.1.weight"], p["encoder.embed_proj.1.bias"] = torch.ones(H), torch.zeros(H)
     if C_:
         p["encoder.channel_embeddings.0.weight"] = nn.Embedding(C_, H).weight.detach()
         p["encoder.channel_embeddings.1.weight"], p["encoder.channel_embeddings.1.bias"] = torch.ones(H), torch.zeros(H)
     if n_regions:
         p["encoder.region_embeddings.0.weight"] = nn.Embedding(n_regions, H).weight.detach()
         p["encoder.region_embeddings.1.weight"], p["encoder.region_embeddings.1.bias"] = torch.ones(H), torch.zeros(H)
+    if embed_depth:   # nn.Sequential(Linear(1,H), act, Linear(H,H), LayerNorm(H)) (itransformer.py:145-150)
+        lin("encoder.depth_embeddings.0", 1, H)
+        lin("encoder.depth_embeddings.2", H, H)
+        p["encoder.depth_embeddings.3.weight"], p["encoder.depth_embeddings.3.bias"] = torch.ones(H), torch.zeros(H)
     if cfg_shapes["use_cls"]:
         p["encoder.cls_embed.weight"] = nn.Embedding(1, H).weight.detach()
     layer = nn.TransformerEncoderLayer(d_model=H, nhead=nh, dim_feedforward=4 * H, dropout=dropout, batch_first=True)
@@ -184,10 +225,13 @@ class iTransformer(FlatParamModule):
             raise Exception(f"Method {self.method} not implemented on the iTransformer HIP path (only 'mlm'; ctc / dyn_behaviour / "
                             "stat_behaviour stay on the reference implementation)")
         enc, dec = DictConfig(config["encoder"]), DictConfig(config["decoder"])
-        if enc.embedder.mode != "mlp":
-            raise Exception("iTransformer HIP path supports embedder.mode: mlp (the UnivariateTransformer embedder is not built)")
-        if enc.embed_depth:
-            raise Exception("iTransformer HIP path supports embed_depth: false")
+        if enc.embedder.mode not in ("mlp", "transformer"):
+            raise Exception(f"embedder.mode {enc.embedder.mode} not implemented (itransformer.py:108-124 knows mlp | transformer)")
+        self.embedder = None
+        if enc.embedder.mode == "transformer":   # UnivariateTransformer(config.embedder) (itransformer.py:120)
+            if enc.embedder.activation != "relu":
+                raise Exception("iTransformer HIP path supports embedder.activation: relu")
+            self.embedder = dict(h=int(enc.embedder.hidden_size), nh=int(enc.embedder.n_heads), L=int(enc.embedder.n_layers))
         if not enc.bias:
             raise Exception("iTransformer HIP path expects bias: true")
         self.loss_name, self.log_input = kwargs["loss"], bool(kwargs.get("log_input", True))
@@ -214,15 +258,20 @@ class iTransformer(FlatParamModule):
         if self.residual_dtype == NBCI_BF16 and self.compute_dtype != NBCI_BF16:
             raise Exception("residual_dtype 'bf16' needs compute_dtype 'bf16'")
         c.residual_dtype = self.residual_dtype
+        c.embed_depth = 1 if enc.embed_depth else 0
+        if self.embedder is not None:
+            c.emb_mode, c.emb_hidden, c.emb_heads, c.emb_layers = 1, self.embedder["h"], self.embedder["nh"], self.embedder["L"]
         self._ccfg = c
         self.config = config
         self.use_cls = bool(dec.use_cls)
         self.masker_cfg = [(k, DictConfig(m)) for k, m in config["masker"].items()]
-        b = layout_of(c.max_n_bins, c.hidden, c.n_layers, c.max_n_channels, c.n_regions, c.use_cls, c.mlp_decoder)
+        b = layout_of(c.max_n_bins, c.hidden, c.n_layers, c.max_n_channels, c.n_regions, c.use_cls, c.mlp_decoder,
+                      embed_depth=bool(c.embed_depth), embedder=self.embedder)
         self._layout, self._segments, self._total = b.entries, b.segments, b.cur
         flat = torch.zeros(self._total, dtype=torch.float32)
         init = reference_order_init(dict(T=c.max_n_bins, H=c.hidden, L=c.n_layers, nh=c.n_heads, C=c.max_n_channels,
-                                         use_cls=c.use_cls, mlp_decoder=c.mlp_decoder), n_regions=c.n_regions, dropout=c.dropout)
+                                         use_cls=c.use_cls, mlp_decoder=c.mlp_decoder), n_regions=c.n_regions, dropout=c.dropout,
+                                    embed_depth=bool(c.embed_depth), embedder=self.embedder, embedder_dropout=c.embed_dropout)
         for (name, off, numel, _shape, _seg) in self._layout:
             flat[off:off + numel] = init[name].reshape(-1)
         self._plan = None
@@ -362,8 +411,21 @@ class iTransformer(FlatParamModule):
             ss = ss.long().expand(B, N).contiguous() if ss.dim() == 1 else ss.contiguous().long()
         regions = batch.get("neuron_regions")
         ridx = None
-        if self._ccfg.n_regions:
-            ridx = torch.tensor([[self.region_to_indx[r] for r in row] for row in regions], dtype=torch.int64, device=dev)
+        if self._ccfg.n_regions:   # itransformer.py:196: region_to_indx of every neuron's region name
+            if regions is None:
+                raise ValueError("embed_region: true needs neuron_regions in the batch (itransformer.py:195-198)")
+            ridx = torch.from_numpy(np.array([[self.region_to_indx[str(r)] for r in row] for row in np.asarray(regions)], dtype=np.int64)
+                                    .reshape(B, N)).to(dev)
+        depths = batch.get("neuron_depths")
+        if self._ccfg.embed_depth:
+            if depths is None:
+                raise ValueError("embed_depth: true needs neuron_depths in the batch (itransformer.py:200-202)")
+            depths = torch.as_tensor(depths, dtype=torch.float32).to(dev).reshape(B, N).contiguous()
+        else:
+            depths = None
+        ts = batch.get("spikes_timestamp") if self._ccfg.emb_mode == 1 else None
+        if ts is not None:
+            ts = ts.to(dev).long().reshape(B, T).contiguous()
         if seed is None:
             self._step_seed = (self._step_seed * 1664525 + 1013904223) & 0xFFFFFFFF
             seed = self._step_seed
@@ -377,6 +439,7 @@ class iTransformer(FlatParamModule):
         io.B, io.N = B, N
         io.spikes, io.masked, io.mask, io.spikes_mask = _ptr(spikes), _ptr(masked), _ptr(mask), _ptr(smask)
         io.spikes_spacestamp, io.region_idx = _ptr(ss), _ptr(ridx)
+        io.spikes_timestamp, io.neuron_depths = _ptr(ts), _ptr(depths)
         io.train = 1 if self.training else 0
         io.want_grad = 1 if want_grad else 0
         io.seed, io.grad_scale = seed, grad_scale
@@ -384,7 +447,7 @@ class iTransformer(FlatParamModule):
         io.hidden_out = _ptr(hidden_out)
         io.workspace, io.workspace_bytes = _ptr(ws), need
         check(lib().nbci_itr_forward(self._plan, _ptr(self._flat), _ptr(self._flat_lp), C.byref(io), _stream()), "nbci_itr_forward")
-        self._io_keepalive = (io, spikes, masked, mask, smask, ss, ridx, ws, preds, mask_out, loss, nex, hidden_out, keep)
+        self._io_keepalive = (io, spikes, masked, mask, smask, ss, ridx, ws, preds, mask_out, loss, nex, hidden_out, keep, ts, depths)
         self.last_n_examples = nex
         self.last_mask = mask_out
         self.last_targets = spikes
@@ -401,7 +464,8 @@ class iTransformer(FlatParamModule):
 
     def forward(self, spikes, spikes_mask, spikes_timestamp, spikes_spacestamp=None, spikes_lengths=None, targets=None,
                 targets_lengths=None, neuron_regions=None, neuron_depths=None):
-        batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_spacestamp=spikes_spacestamp, neuron_regions=neuron_regions)
+        batch = dict(spikes=spikes, spikes_mask=spikes_mask, spikes_spacestamp=spikes_spacestamp, neuron_regions=neuron_regions,
+                     neuron_depths=neuron_depths, spikes_timestamp=spikes_timestamp)
         bridge_begin(self)   # an external optimizer may have stepped the f32 views since the bf16 shadow was taken
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list):
             loss, preds = _ItrFunction.apply(self, batch, *self._param_list)

@@ -266,6 +266,14 @@ if __name__ == "__main__" and "--factors" in sys.argv:
                                                  "init_range": 0.1}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     sys.exit(0)
 
+if __name__ == "__main__" and "--rope" in sys.argv:
+    # RoPE (ndt1.py:46-71,285-286) at real widths: C1 (2 layers x 1024, head 128, ragged, T' = 18 / 10 - the one-workgroup attention)
+    # and a long case (T' = 293 / 218 - the streaming attention), positions = the stacked timestamps
+    rope = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2, "use_rope": True}}}
+    run_case("g_c1_rope", rope, [100, 70], [10, 6], 64)
+    run_case("g_long_rope", rope, [1200, 900], [80, 60], 64)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--long" in sys.argv:
     # sequences beyond the one-workgroup attention kernel (T' > 160): 1200 bins -> 293 tokens, ragged, 2 layers x 1024 (head 128)
     c1 = {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}
@@ -273,7 +281,8 @@ if __name__ == "__main__" and "--long" in sys.argv:
     c1c = json.loads(json.dumps(c1)); c1c["encoder"]["context"] = {"forward": 5, "backward": 40}
     run_case("g_long_ctx", c1c, [1200, 900], [80, 60], 64)
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst", "--masker-copy", "--long")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--bci", "--itr", "--ptst", "--masker-copy", "--long", "--itr-region", "--itr-uni",
+                                                             "--itr-wide", "--ckpt", "--ckpt-itr", "--rope")):
     run_case("g_tiny", tiny(), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_ctx", tiny(context={"forward": 3, "backward": 2}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
     run_case("g_tiny_rope", tiny(transformer={"use_rope": True}), [30, 22, 17], [5, 4, 2], 16, vocab=11, full=True)
@@ -434,7 +443,9 @@ def _install_torchvision_mlp():
     sys.modules["torchvision"] = tv; sys.modules["torchvision.ops"] = ops
 
 
-def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisson_nll", spacestamp=False):
+def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisson_nll", spacestamp=False, regions=False, depths=False):
+    """regions: per-neuron brain-region names drawn from over["encoder"]["regions"] (embed_region, itransformer.py:133-141,195-198);
+    depths: per-neuron depths (embed_depth, :143-150,200-202). Both are forward() inputs, recorded in the fixture."""
     from models.itransformer import iTransformer
     cfg = update_config("configs/itransformer.yaml", over)
     torch.manual_seed(1)
@@ -450,6 +461,15 @@ def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisso
         ss = np.stack([g.permutation(model.config.encoder.max_n_channels)[:N] for _ in range(B)]).astype(np.int64)
         batch["spikes_spacestamp"] = torch.from_numpy(ss)
     fx = {"in_" + k: v.numpy() for k, v in batch.items()}
+    if regions:
+        names = list(over["encoder"]["regions"])
+        nr = np.array(names)[g.integers(0, len(names), (B, N))]
+        batch["neuron_regions"] = nr                                   # np.ndarray of str, as datasets.py hands it over
+        fx["in_neuron_regions"] = nr.astype("U16")
+    if depths:
+        nd = (g.uniform(0.0, 3.84, (B, N))).astype(np.float32)          # probe depth in mm
+        batch["neuron_depths"] = torch.from_numpy(nd)
+        fx["in_neuron_depths"] = nd
     inter, masks = {}, []
 
     def hook(nm):
@@ -458,15 +478,23 @@ def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisso
         return f
 
     enc = model.encoder
-    hs = [enc.embed.register_forward_hook(hook("embed")), enc.embed_dropout.register_forward_hook(hook("tokens")),
+    uni = enc.mode == "transformer"
+    # (mlp mode: the hooked output of `embed` is the tensor the in-place `tokens += ...` adds then land in; transformer mode: `embed` =
+    #  the UnivariateTransformer's CLS outputs (B,N,h), `embed_proj` = the tensor the adds land in)
+    hs = [enc.embed.register_forward_hook(hook("emb_cls" if uni else "embed")), enc.embed_dropout.register_forward_hook(hook("tokens")),
           enc.transformer.register_forward_hook(hook("encoder"))]
+    if uni:
+        hs.append(enc.embed_proj.register_forward_hook(hook("embed")))
+        hs.append(enc.embed.transformer.register_forward_hook(hook("emb_out")))
+        for i, lyr in enumerate(enc.embed.transformer.layers):
+            hs.append(lyr.register_forward_hook(hook(f"emb_layer{i}")))
     for i, lyr in enumerate(enc.transformer.layers):
         hs.append(lyr.register_forward_hook(hook(f"layer{i}")))
     for mk in model.masker.values():
         hs.append(mk.register_forward_hook(lambda mod, inp, out: masks.append(out[1].numpy().copy())))
     model.eval()
     with torch.no_grad():
-        out = model(**{k: v.clone() for k, v in batch.items()})
+        out = model(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
     cut = (lambda a: a) if full else (lambda a: a[..., ::37])
     fx["eval_raw_mask"] = masks[-1]
     fx["eval_loss"] = out.loss.numpy(); fx["eval_n_examples"] = out.n_examples.numpy()
@@ -477,6 +505,11 @@ def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisso
     for i in range(len(enc.transformer.layers)):
         fx[f"layer{i}_out"] = cut(inter[f"layer{i}"].numpy())
     fx["encoder_out"] = cut(inter["encoder"].numpy())
+    if uni:
+        ecut = (lambda a: a) if full else (lambda a: a[::5, ::7, ::9])      # (B*N, T+1, h)
+        fx["emb_cls"] = inter["emb_cls"].numpy(); fx["emb_out"] = ecut(inter["emb_out"].numpy())
+        for i in range(len(enc.embed.transformer.layers)):
+            fx[f"emb_layer{i}_out"] = ecut(inter[f"emb_layer{i}"].numpy())
     for h in hs[:-len(model.masker)]:
         h.remove()
     model.train()
@@ -485,7 +518,7 @@ def itr_case(name, over, B, N, lens, full, steps=2, log_input=True, loss="poisso
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for s in range(steps):
         fx[f"lr_step{s}"] = np.float64(opt.param_groups[0]["lr"]); fx[f"beta1_step{s}"] = np.float64(opt.param_groups[0]["betas"][0])
-        out = model(**{k: v.clone() for k, v in batch.items()})
+        out = model(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
         fx[f"raw_mask_step{s}"] = masks[-1]
         out.loss.backward()
         fx[f"loss_step{s}"] = out.loss.detach().numpy(); fx[f"n_examples_step{s}"] = out.n_examples.numpy()
@@ -592,6 +625,30 @@ if __name__ == "__main__" and "--itr" in sys.argv:
                           "masker": {"main": {"active": True, "regions": None}}}, 4, 64, [100, 100, 80, 61], full=False)
     masker_cases()
 
+
+if __name__ == "__main__" and "--itr-region" in sys.argv:
+    # embed_region: true - the shipped default of configs/itransformer.yaml:38 (main.py:39-42 fills `regions` from the data) - and embed_depth
+    _install_torchvision_mlp()
+    REGS = ["CA1", "DG", "LP", "PO", "VISa"]
+    itr_case("g_itr_tiny_region", itr_tiny(embed_region=True, regions=REGS), 3, 10, [12, 9, 7], full=True, regions=True)
+    itr_case("g_itr_tiny_region_depth", itr_tiny(embed_region=True, regions=REGS[:3], embed_depth=True), 3, 10, [12, 12, 5], full=True,
+             regions=True, depths=True, spacestamp=True)
+    itr_case("g_itr_tiny_depth", itr_tiny(embed_depth=True), 3, 10, [12, 9, 7], full=True, depths=True)
+    itr_case("g_itr_c3w_region", {"encoder": {"embedder": {"dropout": 0.0}, "dropout": 0.0, "embed_region": True, "regions": REGS + ["VISp", "TH", "ZI"]},
+                                  "masker": {"main": {"active": True, "regions": None}}}, 2, 668, [100, 73], full=False, regions=True)
+
+if __name__ == "__main__" and "--itr-uni" in sys.argv:
+    # embedder.mode: transformer - the UnivariateTransformer embedder (itransformer.py:40-93) + embed_proj (:119-124)
+    _install_torchvision_mlp()
+    emb = {"mode": "transformer", "max_n_bins": 12, "dropout": 0.0, "hidden_size": 16, "n_heads": 2, "n_layers": 2, "activation": "relu"}
+    if "--only-c3" not in sys.argv:
+        itr_case("g_itr_tiny_uni", itr_tiny(embedder=emb), 3, 10, [12, 9, 7], full=True)
+    if "--only-c3" not in sys.argv:
+        itr_case("g_itr_tiny_uni_all", itr_tiny(embedder=emb, embed_region=True, regions=["CA1", "DG", "LP"], embed_depth=True), 3, 10, [12, 12, 5],
+                 full=True, regions=True, depths=True, spacestamp=True, loss="mse")
+    # the shipped embedder widths (configs/itransformer.yaml:21-27: 128 x 4 heads x 4 layers, 100 bins) under the shipped encoder, few channels
+    itr_case("g_itr_uni_c3", {"encoder": {"embedder": {"mode": "transformer", "dropout": 0.0}, "dropout": 0.0, "embed_region": False},
+                              "masker": {"main": {"active": True, "regions": None}}}, 2, 24, [100, 61], full=False)
 
 if __name__ == "__main__" and "--itr-wide" in sys.argv:   # the recipe's channel count (configs/itransformer.yaml: 668 channels): sampled fixture
     _install_torchvision_mlp()

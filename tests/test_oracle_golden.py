@@ -167,6 +167,8 @@ def _regen(over, vocab=41):
     ("g_c2", {}),
     ("g_long", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}}}),
     ("g_long_ctx", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2}, "context": {"forward": 5, "backward": 40}}}),
+    ("g_c1_rope", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2, "use_rope": True}}}),     # RoPE at head 128
+    ("g_long_rope", {"encoder": {"embedder": {"n_channels": 64}, "transformer": {"n_layers": 2, "use_rope": True}}}),
 ])
 def test_c1_c2_init_and_oracle(name, over):
     fx = load(name)

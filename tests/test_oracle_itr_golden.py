@@ -24,13 +24,30 @@ def itr_cfg(fx):
     for src, dst in (("hidden_size", "hidden"), ("n_heads", "n_heads"), ("n_layers", "n_layers"), ("max_n_channels", "max_n_channels")):
         if src in enc:
             c[dst] = enc[src]
-    if "max_n_bins" in enc.get("embedder", {}):
-        c["max_n_bins"] = enc["embedder"]["max_n_bins"]
+    emb = enc.get("embedder", {})
+    if "max_n_bins" in emb:
+        c["max_n_bins"] = emb["max_n_bins"]
+    if enc.get("embed_region", False):       # (every fixture config states embed_region; configs/itransformer.yaml's default is true)
+        c["n_regions"] = len(enc["regions"])
+    c["embed_depth"] = bool(enc.get("embed_depth", False))
+    if emb.get("mode", "mlp") == "transformer":   # configs/itransformer.yaml:21-27 defaults: 128 x 4 heads x 4 layers
+        c.update(embedder_mode="transformer", emb_hidden=emb.get("hidden_size", 128), emb_heads=emb.get("n_heads", 4),
+                 emb_layers=emb.get("n_layers", 4), emb_act=emb.get("activation", "relu"))
     return OI.make_config(**c)
 
 
+def itr_regions(fx):
+    over = json.loads(str(fx["config_json"]))
+    return over.get("encoder", {}).get("regions") if over.get("encoder", {}).get("embed_region", False) else None
+
+
 def itr_batch(fx):
-    return {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
+    b = {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
+    regs = itr_regions(fx)
+    if regs is not None:       # the reference's region_to_indx (itransformer.py:136,196): position in config.regions
+        lut = {r: i for i, r in enumerate(regs)}
+        b["region_idx"] = np.vectorize(lut.__getitem__)(b["neuron_regions"]).astype(np.int64)
+    return b
 
 
 def masked_of(spikes, mask):
@@ -39,14 +56,25 @@ def masked_of(spikes, mask):
     return out
 
 
-@pytest.mark.parametrize("name", ["g_itr_tiny", "g_itr_tiny_ss", "g_itr_tiny_rate", "g_itr_tiny_mse"])
+TINY = ["g_itr_tiny", "g_itr_tiny_ss", "g_itr_tiny_rate", "g_itr_tiny_mse",
+        "g_itr_tiny_region", "g_itr_tiny_region_depth", "g_itr_tiny_depth",      # embed_region (the shipped default) / embed_depth
+        "g_itr_tiny_uni", "g_itr_tiny_uni_all"]                                  # embedder.mode: transformer (UnivariateTransformer)
+
+
+@pytest.mark.parametrize("name", TINY)
 def test_itr_tiny_forward_backward_adamw(name):
     fx = load(name)
     cfg = itr_cfg(fx)
     p = {k[3:]: fx[k] for k in fx.files if k.startswith("w0:")}
+    assert set(p) == set(OI.init_params(cfg)), set(p) ^ set(OI.init_params(cfg))     # the oracle knows every tensor of the reference's state dict
     batch = itr_batch(fx)
     m = fx["eval_raw_mask"]
     out, _ = OI.forward(cfg, p, batch, masked_of(batch["spikes"], m), m, train=False)
+    if cfg["embedder_mode"] == "transformer":
+        for l in range(cfg["emb_layers"]):
+            np.testing.assert_allclose(out["emb_layer_out"][l], fx[f"emb_layer{l}_out"], atol=5e-5)
+        np.testing.assert_allclose(out["emb_out"], fx["emb_out"], atol=5e-5)
+        np.testing.assert_allclose(out["emb_out"][:, 0, :].reshape(fx["emb_cls"].shape), fx["emb_cls"], atol=5e-5)
     np.testing.assert_allclose(out["embed"], fx["embed"], atol=2e-5)
     np.testing.assert_allclose(out["tokens"], fx["tokens"], atol=2e-5)
     for l in range(cfg["n_layers"]):
@@ -79,15 +107,20 @@ def test_itr_tiny_forward_backward_adamw(name):
         assert np.mean(d > 2e-5) < 0.02 and d.max() < 5e-4, (k, d.max())
 
 
-@pytest.mark.parametrize("name", ["g_itr_c3", "g_itr_c3w"])   # 64 channels x 4 samples; the recipe's 668 channels x 2 samples
+# 64 channels x 4 samples; the recipe's 668 channels x 2 samples, without and WITH region embeddings (the shipped default); the shipped
+# UnivariateTransformer embedder widths (128 x 4 heads x 4 layers over 101 tokens) under the shipped encoder
+@pytest.mark.parametrize("name", ["g_itr_c3", "g_itr_c3w", "g_itr_c3w_region", "g_itr_uni_c3"])
 def test_itr_c3_real_shapes(name):
     fx = load(name)
     cfg = itr_cfg(fx)
     import torch
     from llm_bci_amd.itransformer import reference_order_init   # host-side init (pure torch CPU): bit-equal to the reference
+    emb = dict(h=cfg["emb_hidden"], nh=cfg["emb_heads"], L=cfg["emb_layers"]) if cfg["embedder_mode"] == "transformer" else None
     p = reference_order_init(cfg_shapes=dict(T=cfg["max_n_bins"], H=cfg["hidden"], L=cfg["n_layers"], nh=cfg["n_heads"],
-                                             C=cfg["max_n_channels"], use_cls=True, mlp_decoder=True), seed=1)
+                                             C=cfg["max_n_channels"], use_cls=True, mlp_decoder=True), seed=1, n_regions=cfg["n_regions"],
+                             embed_depth=cfg["embed_depth"], embedder=emb)
     p = {k: v.numpy() for k, v in p.items()}
+    assert set(p) == {k[6:] for k in fx.files if k.startswith("w0idx:")}
     for k in p:
         idx = fx["w0idx:" + k]
         assert np.array_equal(p[k].reshape(-1)[idx], fx["w0val:" + k]), k

