@@ -917,5 +917,69 @@ def ckpt_cases():
     print("reverse:", reverse)
 
 
+def ckpt_itr_cases():
+    """iTransformer checkpoints with every optional table / the other embedder (round 4): region + depth embeddings under the mlp embedder,
+    and the UnivariateTransformer embedder. Forward: written by the REFERENCE's save_checkpoint into tests/golden/ckpt_itransformer_{full,uni}/
+    with an eval forward (mask replayed) recorded; reverse: a native checkpoint loaded by the reference's from_pt, tensors equal - the record
+    is merged into ckpt_reverse_check.json."""
+    import shutil
+    import tempfile
+    REPO = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, REPO)
+    _install_torchvision_mlp()
+    from models.itransformer import iTransformer
+    from llm_bci_amd.itransformer import iTransformer as NITR
+    rec = json.load(open(os.path.join(OUT, "ckpt_reverse_check.json")))
+    emb = {"mode": "transformer", "max_n_bins": 12, "dropout": 0.0, "hidden_size": 16, "n_heads": 2, "n_layers": 2, "activation": "relu"}
+    cases = {"ckpt_itransformer_full": itr_tiny(embed_region=True, regions=["CA1", "DG", "LP", "PO"], embed_depth=True),
+             "ckpt_itransformer_uni": itr_tiny(embedder=emb, embed_region=True, regions=["CA1", "DG"], embed_depth=False)}
+    for dname, iover in cases.items():
+        icfg = update_config("configs/itransformer.yaml", iover)
+        torch.manual_seed(7)
+        iref = iTransformer(icfg, method_name="mlm", log_input=True, loss="poisson_nll")
+        d = os.path.join(OUT, dname)
+        shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        iref.save_checkpoint(d)
+        g = np.random.default_rng(3)
+        B, N, T = 3, 10, 12
+        spikes = g.poisson(0.5, (B, T, N)).astype(np.float32)
+        regs = list(iover["encoder"]["regions"])
+        nr = np.array(regs)[g.integers(0, len(regs), (B, N))]
+        batch = {"spikes": torch.from_numpy(spikes), "spikes_mask": torch.ones(B, T, dtype=torch.int64),
+                 "spikes_timestamp": torch.arange(T).repeat(B, 1), "neuron_regions": nr}
+        fx = {"in_spikes": spikes, "in_spikes_mask": np.ones((B, T), np.int64), "in_spikes_timestamp": np.tile(np.arange(T), (B, 1)),
+              "in_neuron_regions": nr.astype("U16")}
+        if iover["encoder"].get("embed_depth"):
+            nd = g.uniform(0, 3.84, (B, N)).astype(np.float32)
+            batch["neuron_depths"] = torch.from_numpy(nd); fx["in_neuron_depths"] = nd
+        masks = []
+        for mk in iref.masker.values():
+            mk.register_forward_hook(lambda mod, inp, out: masks.append(out[1].numpy().copy()))
+        iref.eval()
+        with torch.no_grad():
+            out = iref(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        fx.update(raw_mask=masks[-1], preds=out.preds.numpy(), loss=out.loss.numpy(), n_examples=out.n_examples.numpy(),
+                  config_json=np.array(json.dumps(iover)),
+                  state_json=np.array(json.dumps(_sd_summary({k: v for k, v in iref.state_dict().items() if not k.startswith("masker")}))))
+        np.savez_compressed(os.path.join(d, "expected.npz"), **fx)
+        torch.manual_seed(11)
+        inat = NITR(json.loads(json.dumps(iover)), method_name="mlm", log_input=True, loss="poisson_nll", compute_dtype="fp32")
+        with tempfile.TemporaryDirectory() as td:
+            inat.save_checkpoint(td)
+            o2 = json.loads(json.dumps(iover)); o2["encoder"]["from_pt"] = td; o2.setdefault("decoder", {})["from_pt"] = td
+            r2 = iTransformer(update_config("configs/itransformer.yaml", o2), method_name="mlm", log_input=True, loss="poisson_nll")   # itransformer.py:226-250
+            a = {k: v for k, v in inat.state_dict().items()}
+            b = {k: v for k, v in r2.state_dict().items() if not k.startswith("masker")}
+            assert a.keys() == b.keys(), sorted(a.keys() ^ b.keys())
+            for k in a:
+                assert torch.equal(a[k].float().cpu(), b[k].float().cpu()), k
+        rec["native_checkpoint_loaded_by_reference"]["iTransformer_" + dname.rsplit("_", 1)[1]] = {"reference_from_pt_equal_tensors": len(a)}
+        print(dname, sorted(os.listdir(d)), "reverse tensors", len(a), "loss", float(out.loss))
+    json.dump(rec, open(os.path.join(OUT, "ckpt_reverse_check.json"), "w"), indent=2, sort_keys=True)
+
+
+if __name__ == "__main__" and "--ckpt-itr" in sys.argv:
+    ckpt_itr_cases()
+
 if __name__ == "__main__" and "--ckpt" in sys.argv:
     ckpt_cases()

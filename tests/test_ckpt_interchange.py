@@ -64,6 +64,27 @@ def test_itransformer_reads_the_reference_checkpoint():
     _check_state(m2.state_dict(), json.loads(str(fx["state_json"])), skip=("masker",))
 
 
+@pytest.mark.parametrize("dname", ["ckpt_itransformer_full", "ckpt_itransformer_uni"])
+def test_itransformer_reads_reference_checkpoints_with_region_depth_tables_and_the_transformer_embedder(dname):
+    """round 4: region + depth embedding tables (`_full`) and the UnivariateTransformer embedder + embed_proj (`_uni`) - every tensor of the
+    reference-written files lands in the native state dict (make_golden.py --ckpt-itr)."""
+    from llm_bci_amd.itransformer import iTransformer
+    d = os.path.join(GOLD, dname)
+    fx = _expected(dname)
+    over = json.loads(str(fx["config_json"]))
+    o2 = json.loads(json.dumps(over)); o2["encoder"]["from_pt"] = d; o2.setdefault("decoder", {})["from_pt"] = d
+    torch.manual_seed(123)
+    m = iTransformer(o2, method_name="mlm", log_input=True, loss="poisson_nll", compute_dtype="fp32")
+    summary = json.loads(str(fx["state_json"]))
+    _check_state(m.state_dict(), summary, skip=("masker",))
+    assert any(k.startswith("encoder.region_embeddings.") for k in summary)
+    assert any(k.startswith("encoder.depth_embeddings." if dname.endswith("full") else "encoder.embed.transformer.layers.1.") for k in summary)
+    torch.manual_seed(5)
+    m2 = iTransformer(over, method_name="mlm", log_input=True, loss="poisson_nll", compute_dtype="fp32")
+    m2.load_checkpoint(d)
+    _check_state(m2.state_dict(), summary, skip=("masker",))
+
+
 def test_patchtst_reads_the_reference_checkpoint():
     from llm_bci_amd.patchtst import PatchTSTForSpikingActivity
     d = os.path.join(GOLD, "ckpt_patchtst")
@@ -104,6 +125,7 @@ def test_the_reverse_direction_was_asserted_against_the_reference():
     assert r["NDT1"]["reference_from_pt_equal_tensors"] >= 41 and r["NDT1"]["reference_load_checkpoint"] == "equal"
     assert r["iTransformer"]["reference_from_pt_equal_tensors"] > 0 and r["PatchTST"]["reference_load_checkpoint_equal_tensors"] > 0
     assert r["BCI"]["reference_from_pt_equal_tensors"] > 0
+    assert r["iTransformer_full"]["reference_from_pt_equal_tensors"] == 49 and r["iTransformer_uni"]["reference_from_pt_equal_tensors"] == 73
 
 
 @pytest.mark.gpu
@@ -137,3 +159,23 @@ def test_patchtst_loaded_from_the_reference_checkpoint_predicts_what_the_referen
     torch.cuda.synchronize()
     assert np.abs(out.preds.cpu().numpy() - fx["preds"]).max() <= 1e-3
     np.testing.assert_allclose(float(out.loss), float(fx["loss"]), rtol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dname", ["ckpt_itransformer_full", "ckpt_itransformer_uni"])
+def test_itransformer_loaded_from_the_reference_checkpoint_predicts_what_the_reference_predicted(dname):
+    from llm_bci_amd.itransformer import iTransformer
+    d = os.path.join(GOLD, dname)
+    fx = _expected(dname)
+    torch.manual_seed(123)
+    m = iTransformer(json.loads(str(fx["config_json"])), method_name="mlm", log_input=True, loss="poisson_nll", compute_dtype="fp32").to("cuda")
+    m.load_checkpoint(d)
+    m.eval()
+    m.mask_override = torch.from_numpy(fx["raw_mask"])
+    b = {k[3:]: (fx[k] if k == "in_neuron_regions" else torch.from_numpy(fx[k]).to("cuda")) for k in fx.files if k.startswith("in_")}
+    with torch.no_grad():
+        out = m(**b)
+    torch.cuda.synchronize()
+    assert np.abs(out.preds.cpu().numpy() - fx["preds"]).max() <= 1e-3
+    np.testing.assert_allclose(float(out.loss), float(fx["loss"]), rtol=2e-4)
+    assert int(out.n_examples) == int(fx["n_examples"])
