@@ -102,23 +102,30 @@ def kernel_table(l, nsteps, peak_tflops=PEAK_BF16_TFLOPS):
     return rows
 
 
-def pmc_traffic(symbol):
-    """HBM-side bytes per launch of `symbol` from the committed counter passes of this round (profiles/r03_pmc_kernels.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, KiB -> bytes), or None."""
-    for nm in ("r03_pmc_kernels.json",):
-        f = os.path.join(ROOT, "profiles", nm)
-        if os.path.exists(f):
-            try:
-                t = json.load(open(f)).get("hbm_bytes_per_launch", {})
-                for k, v in t.items():
-                    if k.replace(" ", "") == symbol.replace(" ", ""):
-                        return v
-            except Exception:
-                pass
-    return None
+def pmc_traffic(symbol, run_cfg):
+    """(bytes, source): HBM-side bytes per launch of `symbol` from the newest committed counter passes (profiles/r*_pmc_kernels.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction, KiB -> bytes) - OFFLINE-profiled,
+    not measured in this run - and only when those passes ran THIS run's configuration (batch, shapes, dtypes); otherwise (None, why)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")))
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        cfg = j.get("config")
+        if not cfg:
+            continue
+        if any(str(cfg.get(k)) != str(v) for k, v in run_cfg.items() if k in cfg):
+            return None, f"offline counters ({os.path.basename(f)}) were taken for {cfg}, this run is {run_cfg}: not reported"
+        for k, v in j.get("hbm_bytes_per_launch", {}).items():
+            if k.replace(" ", "") == symbol.replace(" ", ""):
+                return v, f"offline-profiled: {os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same configuration, side stream off)"
+        return None, f"{os.path.basename(f)} has no entry for this symbol"
+    return None, "no committed counter pass carries its configuration"
 
 
-def roofline_from_profile(l, nsteps):
+def roofline_from_profile(l, nsteps, run_cfg=None):
     rows = kernel_table(l, nsteps)
     if not rows:
         return None
@@ -128,7 +135,7 @@ def roofline_from_profile(l, nsteps):
     mf = top["bound"] == "mfma" or "tflops" in top
     roof = {"bound": "mfma" if mf else "hbm", "achieved": top["tflops"] if mf else top["gbytes_per_s"],
             "peak": PEAK_BF16_TFLOPS if mf else 8000.0, "unit": "TFLOP/s" if mf else "GB/s",
-            "frac": top["frac_mfma"] if mf else top["frac_hbm"], "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"],
+            "frac": top["frac_mfma"] if mf else top["frac_hbm"], "traffic": None, "kernel": top["kernel"],
             "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
             "flop_per_launch": top.get("gflop_per_launch"), "algorithmic_mbytes_per_launch": top.get("mbytes_per_launch"),
             "frac_hbm_of_the_same_kernel": top.get("frac_hbm"), "intensity_flop_per_byte": top.get("flop_per_byte"),
@@ -138,6 +145,7 @@ def roofline_from_profile(l, nsteps):
                                      max(1e-9, sum(r["ms_per_step"] for r in gemm)), 1),
             "timing": "HIP events around every launch on its own stream, 3 steps after the timed windows, everything on ONE stream "
                       "(the timed windows overlap the weight gradients / AdamW on a second stream: NativeTrainer side_stream)", "per_kernel": rows}
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(top["kernel"], run_cfg or {})
     return roof
 
 
@@ -245,43 +253,63 @@ def other_model_points(l, dev, steps, residual_dtype="bf16"):
     return out
 
 
+def cpu_child(threads, B, timed, T=600, N=256, S=60):
+    """ONE point of the CPU baseline, run in a fresh CPU-only process (`python bench.py --cpu-child threads B steps`, started by
+    cpu_baseline() with OMP_NUM_THREADS / OMP_PROC_BIND=close / OMP_PLACES=cores in its environment): prints one JSON line."""
+    from oracle import torch_step as TS
+    from llm_bci_amd.ndt1 import NDT1
+    torch.set_num_threads(threads)
+    torch.manual_seed(1)
+    m = NDT1({}, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="fp32")   # CPU construction only: the reference-order init
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    tr = TS.TorchCpuTrainer(p0, total_steps=1000)
+    _, batch = make_batch(B, T, N, S, 41, "cpu", 0)
+    tr.step(batch, train=True)                       # warm-up (thread pool, allocator, oneDNN primitives)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        tr.step(batch, train=True)
+    el = time.perf_counter() - t0
+    fps, _ = fwd_flops_per_sample(T, N)
+    print(json.dumps({"samples_per_s": round(B * timed / el, 3), "steps": timed, "seconds": round(el, 2), "threads": threads, "batch": B,
+                      "gflops_per_s": round(3 * fps * B * timed / el / 1e9, 1), "torch_threads": torch.get_num_threads()}), flush=True)
+
+
 def cpu_baseline(T=600, N=256, S=60):
     """The reference's train step on the host cores: the reference itself cannot travel to this box, so the timed
     thing is oracle/torch_step.py - a PyTorch-CPU restatement of the identical step (forward -> CTC sum -> autograd backward ->
     torch.optim.AdamW + OneCycleLR, fp32, dropout / noise ON as in the recipe), pinned to the reference's outputs by
-    tests/test_oracle_torch_step.py. Intra-op threads are SWEPT ({16, 32, 64, all physical cores}: one thread per core of a
-    two-socket box is oversubscribed for these GEMM sizes) on B = 8 steps (1 warm-up + 2 timed each); the recipe's B = 64 then runs
-    at the best count for 1 warm-up + 3 timed steps. `value` = the best samples/s seen, `cores` = the threads that gave it. Bounded:
-    about a minute of CPU work."""
+    tests/test_oracle_torch_step.py. Every point runs in a FRESH CPU-only child process (subprocess, never exec) with its OpenMP threads
+    pinned (OMP_PROC_BIND=close, OMP_PLACES=cores, OMP_NUM_THREADS = the count): thread counts {16, 32, one socket's cores} at B = 8
+    and at the recipe's B = 64 (1 warm-up + 2 timed steps each). (Measured on the 2 x 64-core EPYC 9575F box: 16 and 32 pinned threads tie,
+    a whole socket is SLOWER - these GEMMs have 1 144 .. 9 152 rows and the step is full of small ops; more threads only add synchronisation.) `value` = the best samples/s seen,
+    `cores` = the threads that gave it; every point carries the GFLOP/s it reached. Bounded: about a minute of CPU work."""
+    import subprocess
     from oracle import torch_step as TS
-    from llm_bci_amd.ndt1 import NDT1
     host = TS.host_cpu_description()
     cores = int(host["physical_cores"])
-    torch.manual_seed(1)
-    m = NDT1({}, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="fp32")   # CPU construction only: the reference-order init
-    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    per_socket = max(1, cores // max(1, int(host["sockets"])))
 
     def run(B, threads, timed):
-        torch.set_num_threads(threads)
-        tr = TS.TorchCpuTrainer(p0, total_steps=1000)
-        _, batch = make_batch(B, T, N, S, 41, "cpu", 0)
-        tr.step(batch, train=True)                       # warm-up (thread pool, allocator, oneDNN primitives)
-        t0 = time.perf_counter()
-        for _ in range(timed):
-            tr.step(batch, train=True)
-        el = time.perf_counter() - t0
-        return {"samples_per_s": round(B * timed / el, 3), "steps": timed, "seconds": round(el, 2), "threads": threads}
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", str(threads), str(B), str(timed)], env=env,
+                             capture_output=True, text=True, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            return {"error": (out.stderr or out.stdout)[-300:], "threads": threads, "samples_per_s": 0.0}
+        return json.loads(line[-1])
 
-    cands = sorted({t for t in (16, 32, 64, cores) if 1 <= t <= cores} or {cores})
+    cands = sorted({t for t in (16, 32, per_socket) if 1 <= t <= cores} or {cores})
     sweep = {f"B8_t{t}": run(8, t, 2) for t in cands}
-    best_t = max(sweep.values(), key=lambda r: r["samples_per_s"])["threads"]
-    b64 = run(64, best_t, 3)
-    points = dict(sweep, **{f"B64_t{best_t}": b64})
+    sweep.update({f"B64_t{t}": run(64, t, 2) for t in cands})      # the recipe's batch at every count too: more rows per GEMM scale further
+    best_t = max((v for k, v in sweep.items() if k.startswith("B64")), key=lambda r: r["samples_per_s"])["threads"]
+    b64 = sweep[f"B64_t{best_t}"]
+    points = sweep
     best = max(points.values(), key=lambda r: r["samples_per_s"])
-    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port", "gflops_per_s": best.get("gflops_per_s"),
             "sample": f"PyTorch-CPU restatement of the reference step (oracle/torch_step.py: fwd + CTC sum + autograd bwd + AdamW/OneCycle, fp32, "
-                      f"dropout/noise on), {T} bins x {N} ch, 5-layer NDT1, torch {torch.__version__}; intra-op threads swept over {cands} at B=8 "
-                      f"(2 timed steps each), B=64 at the best count ({best_t}) for 3 timed steps; best of all points",
+                      f"dropout/noise on), {T} bins x {N} ch, 5-layer NDT1, torch {torch.__version__}; one fresh CPU-only process per point, OpenMP threads "
+                      f"pinned (OMP_PROC_BIND=close, OMP_PLACES=cores); threads swept over {cands} at B=8 and B=64 (2 timed steps each); best of all points",
             "host_cpu": host, "points": points, "recipe_batch_64": b64,
             "reference_eager_8vcpu_build_container": 5.2}
 
@@ -369,7 +397,11 @@ def main():
     ap.add_argument("--no-extra-points", action="store_true", help="skip the B=8 / ragged / other-model points (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-child", nargs=3, type=int, metavar=("THREADS", "BATCH", "STEPS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_child:          # a point of cpu_baseline(), in its own CPU-only process (nothing below runs)
+        cpu_child(*args.cpu_child)
+        return
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -449,7 +481,28 @@ def main():
 
     windows = measure(batch, 1000, args.repeats)
     el = windows[len(windows) // 2]                          # the median window is the reported one
-    stats = tr.read_stats()
+    stats = tr.read_stats()                                  # (raises if a balanced grouped weight-gradient launch timed out: NativeTrainer.check_kernels)
+
+    # The same step with the OTHER storage of the residual / gradient streams (NDT1(residual_dtype=...)), same run, every rank: "fp32" is
+    # what the reference's bf16 autocast keeps in f32 (ndt1.py:325,328) - the reference-equivalent precision -, "bf16" the opt-in narrower
+    # storage. Whichever `value` is, the other one is a top-level key of the line (value_reference_precision / value_bf16_streams).
+    other_streams = None
+    if args.dtype == "bf16":
+        other_rd = "fp32" if args.residual_dtype == "bf16" else "bf16"
+        torch.manual_seed(1)
+        m2 = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="bf16", residual_dtype=other_rd).to(dev)
+        tr2 = NativeTrainer(m2, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0, div_factor=25,
+                            comm_dtype=args.comm_dtype, side_stream={"auto": "auto", "on": True, "off": False}[args.side_stream])
+        tr_main, tr = tr, tr2
+        for i in range(3):
+            tr.train_step(batch, seed=i + 100003 * rank)
+        w2 = measure(batch, 12000, 5)
+        tr.read_stats()
+        tr = tr_main
+        e2 = w2[len(w2) // 2]
+        other_streams = {"residual_dtype": other_rd, "ms_per_step": round(1e3 * e2 / args.steps, 3),
+                         "value": round(per_gpu[args.scaling] * world * args.steps / e2, 2)}
+        del m2, tr2
 
     other = dp = None
     if world > 1:
@@ -496,7 +549,8 @@ def main():
         tr.side_stream = side
     if rank == 0 and not args.no_roofline:
         check(l.nbci_profile_enable(0), "profile_enable")
-        roof = roofline_from_profile(l, nprof)
+        roof = roofline_from_profile(l, nprof, {"batch": per_gpu[args.scaling], "bins": args.bins, "channels": args.channels, "dtype": args.dtype,
+                                                "residual_dtype": args.residual_dtype})
     extra = None
     if world == 1 and not args.no_extra_points:
         # Two more points of the same binary (not bench lines): SURVEY's small batch B = 8 (launch-latency bound) and the recipe
@@ -518,19 +572,6 @@ def main():
         fed["vs_resident_ragged"] = round(fed["ms_per_step"] / rs, 3)
         extra[f"B{args.batch}_ragged_fed_from_host"] = fed
         tr.read_stats()
-        if args.dtype == "bf16":   # the same step with the OTHER storage of the residual / gradient streams (NDT1(residual_dtype=...))
-            other_rd = "fp32" if args.residual_dtype == "bf16" else "bf16"
-            torch.manual_seed(1)
-            m2 = NDT1(over, method_name="ctc", vocab_size=41, blank_id=0, zero_infinity=True, compute_dtype="bf16", residual_dtype=other_rd).to(dev)
-            tr_main, tr = tr, NativeTrainer(m2, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1_000_000, warmup_pct=0.0, div_factor=25,
-                                            side_stream={"auto": "auto", "on": True, "off": False}[args.side_stream])
-            for i in range(3):
-                tr.train_step(batch, seed=i)
-            w = measure(batch, 12000, 5)[2]
-            extra[f"B{args.batch}_{other_rd}_streams"] = {"ms_per_step": round(1e3 * w / args.steps, 3), "samples_per_s": round(args.batch * args.steps / w, 1)}
-            tr.read_stats()
-            tr = tr_main
-            del m2
         extra["other_models"] = other_model_points(lib(), dev, max(5, args.steps // 2), args.residual_dtype)
     if world > 1:
         dist.barrier()
@@ -554,6 +595,14 @@ def main():
             "train_loss_per_example": round(stats["loss"], 4), "train_PER": stats["PER"],
             "roofline": roof, "extra_points": extra, "other_scaling": other, "dp": dp,
         }
+        # both stream storages at the top level: the reference-equivalent precision (f32 streams) and the opt-in bf16 streams
+        if args.dtype == "bf16":
+            mine = {"residual_dtype": args.residual_dtype, "ms_per_step": res["ms_per_step"], "value": res["value"]}
+            f32s, b16s = (mine, other_streams) if args.residual_dtype == "fp32" else (other_streams, mine)
+            res["value_reference_precision"] = f32s["value"]; res["ms_per_step_reference_precision"] = f32s["ms_per_step"]
+            res["value_bf16_streams"] = b16s["value"]; res["ms_per_step_bf16_streams"] = b16s["ms_per_step"]
+            res["precision_note"] = ("value = residual_dtype " + args.residual_dtype + "; value_reference_precision = the f32 residual / gradient streams "
+                                     "the reference's bf16 autocast keeps (ndt1.py:325,328); both measured in this run, same batch and seeds")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)   # a reported ratio, not a quality measure (see roofline)

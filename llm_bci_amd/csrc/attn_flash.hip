@@ -862,13 +862,19 @@ int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S
 int fattn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* L, float* Dsum, void* dqkv, int NS, int nh, int S, int H,
                      float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
     NBCI_REQUIRE(fattn_eligible(NBCI_BF16, S, H, nh), NBCI_ESHAPE, "flash attention: bf16, head size 32 / 64 / 96 / 128");
-    ProfScope ps("fa_bwd_kernels (dq + dk/dv)", 10.0 * S * S * H * NS, 2.0 * NS * S * 8 * H, s);   // q, k, v, out, d out in; dq, dk, dv out
     FAArgs a{};
     int rc = fa_args(a, NS, nh, S, H, drop_p, seed, site);
     if (rc != NBCI_OK) return rc;
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.dout = (const bf16_t*)dout; a.L = (float*)L; a.Dsum = Dsum; a.dqkv = (bf16_t*)dqkv;
-    rc = fa_dispatch(1, a, s);
+    // ONE profiling scope per launch (the per-kernel table is keyed by rocprof symbol: a scope over both launches filed their sum under
+    // the second kernel's name). Algorithmic work of the backward = 10 S^2 H per sequence (S recomputed once, dP, dQ, dK, dV): the dq launch
+    // carries S, dP, dQ (6), the dk / dv launch dK, dV (4; ITS recomputation of S and dP is not algorithmic work).
+    {
+        ProfScope ps("fa_bwd_q_kernel", 6.0 * S * S * H * NS, 2.0 * NS * S * 6 * H, s);    // q, k, v, out, d out in; dq out
+        rc = fa_dispatch(1, a, s);
+    }
     if (rc != NBCI_OK) return rc;
+    ProfScope ps("fa_bwd_kv_kernel", 4.0 * S * S * H * NS, 2.0 * NS * S * 6 * H, s);       // q, k, v, d out in; dk, dv out
     return fa_dispatch(2, a, s);
 }
 
@@ -901,8 +907,12 @@ int fattn_masked_bwd_launch(const void* qkv, const int32_t* tmask, const void* o
     if (rc != NBCI_OK) return rc;
     fa_mask_args(a, tmask, cf, cb, drop_p, seed, 0);
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.dout = (const bf16_t*)dout; a.L = (float*)L; a.Dsum = Dsum; a.dqkv = (bf16_t*)dqkv;
-    rc = fa_dispatch(1, a, s);
+    {
+        ProfScope ps("fa_bwd_q_kernel", 6.0 * S * S * H * NS, 2.0 * NS * S * 6 * H, s);
+        rc = fa_dispatch(1, a, s);
+    }
     if (rc != NBCI_OK) return rc;
+    ProfScope ps("fa_bwd_kv_kernel", 4.0 * S * S * H * NS, 2.0 * NS * S * 6 * H, s);
     return fa_dispatch(2, a, s);
 }
 

@@ -18,6 +18,17 @@ def test_two_rank_native_trainer_equals_single_process():
     assert r.returncode == 0 and "DP_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_rccl_comes_up_and_carries_the_data_parallel_code_path():
+    """tools/rccl_smoke.py in its own process (a tool the driver never ran): the process group comes up on backend "nccl"
+    (= RCCL; needs librccl and HSA_ENABLE_IPC_MODE_LEGACY=0), a 164 MB async all-reduce completes, and NativeTrainer's world > 1 path
+    (per-segment backward on two streams, bucketed async all-reduce, per-bucket AdamW) runs over it with fp32 and bf16 buckets; its
+    losses equal the one-stream run's. One rank: the 8-GPU run is the driver's - this catches bring-up bugs before it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_SMOKE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl all_reduce 164 MB" in r.stdout and "comm bf16" in r.stdout
+
+
 def _bench(args, env_extra=None, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
@@ -40,13 +51,16 @@ def test_bench_self_launches_its_ranks_and_reports_both_scaling_modes():
     """gloo rehearsal on the one GPU: bench.py starts its own two ranks, prints n_gpus 2, the weak-scaling value, the strong-scaling
     point (global batch split over the ranks: trainer.py:77-80) and the exchange bookkeeping."""
     import json
-    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", "8", "--global-batch", "8", "--no-roofline"],
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-roofline"],      # the shipped defaults: 64 per rank (weak), global 64 (strong)
                {"NBCI_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["per_gpu_batch"] == 8
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128 and d["config"]["per_gpu_batch"] == 64
     o = d["other_scaling"]
-    assert o["scaling"] == "strong" and o["global_batch"] == 8 and o["per_gpu_batch"] == 4 and o["value"] > 0
+    assert o["scaling"] == "strong" and o["global_batch"] == 64 and o["per_gpu_batch"] == 32 and o["value"] > 0
     assert d["dp"]["ranks"] == 2 and d["dp"]["allreduce_bytes_per_step"] == 4 * d["config"]["params_padded"]
     assert d["dp"]["buckets_per_step"] >= 2 and "exposed_comm_ms" in d["dp"]["weak"] and "exposed_comm_ms" in d["dp"]["strong"]
+    # both stream storages are top-level keys of the line (VERDICT r3 #3)
+    assert d["config"]["residual_dtype"] == "bf16" and d["value"] == d["value_bf16_streams"] and d["value_reference_precision"] > 0
+    assert d["ms_per_step_reference_precision"] > 0 and d["cpu_baseline"] is None

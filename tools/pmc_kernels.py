@@ -34,9 +34,12 @@ def table(db, counter):
 ap = argparse.ArgumentParser()
 ap.add_argument("--fetch", required=True); ap.add_argument("--write", required=True); ap.add_argument("--out", required=True)
 ap.add_argument("--note", default="")
+ap.add_argument("--config", default="", help="JSON of the bench.py configuration the counter passes ran (batch, bins, channels, dtype, residual_dtype, side_stream): "
+                "bench.py reports roofline.traffic only for a run of the same configuration")
 a = ap.parse_args()
 f, w = table(a.fetch, "FETCH_SIZE"), table(a.write, "WRITE_SIZE")
 out = {"note": a.note or "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) of bench.py; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 bytes, mean per launch",
+       "config": json.loads(a.config) if a.config else None,
        "hbm_bytes_per_launch": {}, "fetch_bytes_per_launch": {}, "write_bytes_per_launch": {}, "launches_seen": {}}
 for k in sorted(set(f) | set(w)):
     fb = f.get(k, (0.0, 0))[0] * 2 * 1024

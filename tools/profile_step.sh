@@ -21,7 +21,8 @@ cd "$R"
 db() { find "$out/$1" -name '*.db' | head -1; }
 python3 tools/db_stats.py "$(db trace)" > "$out/kernel_stats.csv"
 python3 tools/db_stats.py "$(db trace1)" > "$out/kernel_stats_one_stream.csv"
-python3 tools/pmc_kernels.py --fetch "$(db pmc_fetch)" --write "$(db pmc_write)" --out "$out/pmc_kernels.json" > "$out/pmc_kernels.txt"
+python3 tools/pmc_kernels.py --fetch "$(db pmc_fetch)" --write "$(db pmc_write)" --out "$out/pmc_kernels.json" \
+  --config '{"batch": 64, "bins": 600, "channels": 256, "dtype": "bf16", "residual_dtype": "bf16", "side_stream": "off"}' > "$out/pmc_kernels.txt"
 for v in 64 8 8s; do
   python3 tools/seq_step.py "$out/csv$v" > "$out/b${v}_step_sequence.txt"
   python3 tools/prof_step.py "$out/csv$v" 60 > "$out/b${v}_step_breakdown.txt"
