@@ -432,15 +432,28 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         // cost model: (rounds) x (rows per tile) / (relative main-loop speed). The 3-stage 288-row kernel
         // runs one workgroup per CU (rounds of 256 tiles) but streams ~1.5x faster per row.
         double best = -1;
-        const int cands[4] = {128, 144, 160, 288};  // (160 rows: two-chunk epilogue, 208 VGPRs; 192 rows spill accumulators with hipcc 7.2: not offered)
+        const int cands[5] = {128, 144, 160, 288, 80};  // (160 rows: two-chunk epilogue, 208 VGPRs; 192 rows spill accumulators with hipcc 7.2: not offered)
         static const bool g3_off = measure_env("NBCI_GEMM3", 0) != 1;  // opt-in: measured no faster than the 2-stage kernel
+        // 80-row tiles (MI = 5): 52 KB of LDS per workgroup -> THREE workgroups per CU, whose fills / epilogues overlap each other's K loops.
+        // NBCI_GEMM_BM80 (measurement builds): 0 never, 1 by the cost model below (default), 2 whenever eligible
+        static const int bm80 = measure_env("NBCI_GEMM_BM80", 1);
+        static const double bm80_pen = (double)measure_env("NBCI_GEMM_BM80_PEN", 135) / 100.0;   // K-loop cost per row relative to the 144-row tile (49 vs 68 FLOP per staged byte)
         for (int c : cands) {
             if (c == 288 && (g3_off || d.K < 192 || glds_view(d))) continue;
             if (c == 160 && glds_view(d)) continue;   // (view launches pick their own 160-row case below)
+            if (c == 80 && (bm80 == 0 || glds_view(d))) continue;
             const long tiles = (long)((d.M + c - 1) / c) * k.tiles_n * batch;
             if (c == 288 && tiles < 192) continue;   // one workgroup per CU: only worth it when the chip fills
-            const long s1 = avail, s2 = 2 * avail;   // workgroup slots per round (one / two workgroups per CU)
-            const double cost = c == 288 ? (double)((tiles + s1 - 1) / s1) * c / 2.0 / 1.5 : (double)((tiles + s2 - 1) / s2) * c;
+            const long s1 = avail, s2 = 2 * avail, s3 = 3 * avail;   // workgroup slots per round (one / two / three workgroups per CU)
+            double cost = c == 288 ? (double)((tiles + s1 - 1) / s1) * c / 2.0 / 1.5 : (double)((tiles + s2 - 1) / s2) * c;
+            if (c == 80) {   // measured (profiles/r04_gemm_bm80_shapes.txt): a gain only where the 80-row tiles fit ONE round of at most two per CU
+                             // (M = 4576 / 2288 x N = 1024: 0.86 of the 128-row launch); equal or slower with more tiles or rounds
+                // and not below the grid sizes the multi-stage small-grid kernels take (128-row tiles <= one per CU: B = 16 equal, B = 8 / 4
+                // 13 - 18 % slower per step with the 80-row kernel, profiles/r04_gemm_bm80_steps.txt)
+                const long tiles128 = (long)((d.M + 127) / 128) * k.tiles_n * batch;
+                if (bm80 != 2 && (tiles > s2 || tiles128 <= s1)) continue;
+                cost = bm80 == 2 ? 0.0 : (double)c * bm80_pen;
+            }
             if (best < 0 || cost < best) { best = cost; bm = c; }
         }
     }
@@ -484,6 +497,7 @@ int gemm_glds_launch(const nbci_gemm_desc& d, GemmK k, hipStream_t stream) {
         return launch_ms<false, false, 2, 2, 4, 4, 4>(k, grid, stream);
     }
     switch (bm) {
+        case 80: return launch_glds_layout<1, 4, 5, 2>(k, ak, bk, grid, stream);
         case 144: return launch_glds_layout<1, 4, 9, 2>(k, ak, bk, grid, stream);
         case 160: return launch_glds_layout<1, 4, 10, 2>(k, ak, bk, grid, stream);
         case 288:
