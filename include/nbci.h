@@ -289,6 +289,10 @@ int nbci_profile_enable(int32_t on);
  * 0 = the two-workgroup-per-CU kernels only, 1 = the producer / consumer kernel (144 x 256 tiles, gemm_pc.hip) where the tile
  * cost model prefers it (default), 2 = the producer / consumer kernel whenever eligible. Initial value: NBCI_GEMM_PC. */
 int nbci_debug_gemm_pc(int32_t mode);
+/* prototype (round 4): the MLP half of an encoder layer - up projection (bias + activation, act' copy) and down projection (bias / dropout /
+ * residual), reference models/ndt1.py:224-227,328 - in ONE launch with the row strip resident on its CU; same results as the two nbci_gemm calls.
+ * bf16, k-major operands, up.K % 64 == 0, up.N % 128 == 0 (<= 1024), down.N % 128 == 0, at most 40 rows per CU. csrc/mlp_strip.hip */
+int nbci_debug_mlp_strip(const nbci_gemm_desc* up, const nbci_gemm_desc* down, nbci_stream_t stream);
 /* Measurement / test aid: how nbci_gemm_grouped launches a group of direct-to-LDS problems (K % 64 == 0): 0 = one workgroup per
  * 128 x 128 output tile, 1 = deal the K tiles of all output tiles out evenly over the chip's workgroup slots when one workgroup
  * per tile would leave more than 12 % of the slot-rounds empty (default; gemm_streamk.hip: partial tiles go through a scratch buffer

@@ -156,7 +156,7 @@ static int launch_layout(const GemmK& k, bool ak, bool bk, dim3 grid, hipStream_
     return launch_inst<T, false, false>(k, grid, s);
 }
 
-static int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {
+int build_gemmk(const nbci_gemm_desc& d, GemmK& k) {   // (also used by mlp_strip.hip)
     NBCI_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, NBCI_ESHAPE, "gemm: M,N,K must be positive");
     NBCI_REQUIRE(d.A.ptr && d.B.ptr && d.C, NBCI_EINVAL, "gemm: null operand");
     NBCI_REQUIRE(d.in_dtype == NBCI_F32 || d.in_dtype == NBCI_BF16, NBCI_EINVAL, "gemm: bad in_dtype");

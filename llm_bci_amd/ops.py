@@ -33,10 +33,10 @@ def operand(t, ld, kmajor, rpb=0, gstride=0, zs1=0, zs2=0, offset=0):
     return Operand(t.data_ptr() + offset * t.element_size(), ld, 1 if kmajor else 0, rpb, gstride, zs1, zs2)
 
 
-def gemm(M, N, K, A, B, Cout, ldc, *, in_dtype, c_dtype, C2=None, czs1=0, czs2=0, batch=1, zdiv=1,
-         splitk=1, alpha=1.0, beta=0.0, bias=None, act=0, drop_p=0.0, seed=0, site=0,
-         residual=None, ldr=0, c_offset=0, c2_grad=0, gate=None, ldg=0, gate_act=0, colsum=None):
-    """C = alpha * A . B^T with the fused epilogue of include/nbci.h (nbci_gemm)."""
+def gemm_desc(M, N, K, A, B, Cout, ldc, *, in_dtype, c_dtype, C2=None, czs1=0, czs2=0, batch=1, zdiv=1,
+              splitk=1, alpha=1.0, beta=0.0, bias=None, act=0, drop_p=0.0, seed=0, site=0,
+              residual=None, ldr=0, c_offset=0, c2_grad=0, gate=None, ldg=0, gate_act=0, colsum=None):
+    """the nbci_gemm_desc of C = alpha * A . B^T with the fused epilogue of include/nbci.h"""
     d = GemmDesc()
     d.M, d.N, d.K, d.in_dtype = M, N, K, in_dtype
     d.A, d.B = A, B
@@ -55,6 +55,12 @@ def gemm(M, N, K, A, B, Cout, ldc, *, in_dtype, c_dtype, C2=None, czs1=0, czs2=0
         d.gate, d.ldg, d.gate_act = gate.data_ptr(), ldg, gate_act
     if colsum is not None:  # f32 [N] += column sums of the stored C (bias gradient fused into the GEMM producing the activation gradient)
         d.colsum = colsum.data_ptr()
+    return d
+
+
+def gemm(M, N, K, A, B, Cout, ldc, **kw):
+    """C = alpha * A . B^T with the fused epilogue of include/nbci.h (nbci_gemm)."""
+    d = gemm_desc(M, N, K, A, B, Cout, ldc, **kw)
     check(lib().nbci_gemm(C.byref(d), _stream()), "nbci_gemm")
 
 

@@ -372,3 +372,34 @@ def test_phase_layout_plain_operands_match_the_views(shape):
              in_dtype=ops.NBCI_BF16, c_dtype=ops.NBCI_F32, beta=1.0)
     torch.cuda.synchronize()
     assert torch.equal(dW.double().cpu(), refw.cpu())
+
+
+@pytest.mark.parametrize("M,residual", [(9152, torch.bfloat16), (2000, torch.float32), (37, torch.bfloat16)])
+def test_mlp_strip_prototype_equals_the_two_gemm_launches(M, residual):
+    """csrc/mlp_strip.hip (round 4 prototype, nbci_debug_mlp_strip): up projection + GELU (+ act' copy) and down projection + dropout + residual of
+    models/ndt1.py:224-227,328 in ONE launch with the row strip resident on its CU - bit-equal to the two nbci_gemm launches it would replace
+    (same K order, same rounding of g, same dropout counters). It is slower than they are (profiles/r04_mlp_strip_*.txt) and not on the step's path."""
+    import ctypes as C
+    from llm_bci_amd._lib import check, lib
+    ops = _ops()
+    H = I = 1024
+    torch.manual_seed(3)
+    h = torch.randn(M, H, device=DEV).bfloat16(); x = torch.randn(M, H, device=DEV).to(residual)
+    Wu = (torch.randn(I, H, device=DEV) / 32).bfloat16(); bu = torch.randn(I, device=DEV) * 0.1
+    Wd = (torch.randn(H, I, device=DEV) / 32).bfloat16(); bd = torch.randn(H, device=DEV) * 0.1
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for fused in (False, True):
+        g = torch.zeros(M, I, device=DEV, dtype=torch.bfloat16); da = torch.zeros_like(g); y = torch.zeros(M, H, device=DEV, dtype=residual)
+        up = ops.gemm_desc(M, I, H, ops.operand(h, H, True), ops.operand(Wu, H, True), g, I, in_dtype=1, c_dtype=1, bias=bu, act=2, C2=da, c2_grad=1)
+        dn = ops.gemm_desc(M, H, I, ops.operand(g, I, True), ops.operand(Wd, I, True), y, H, in_dtype=1, c_dtype=0 if residual == torch.float32 else 1,
+                           bias=bd, drop_p=0.4, seed=7, site=19, residual=x, ldr=H)
+        if fused:
+            check(lib().nbci_debug_mlp_strip(C.byref(up), C.byref(dn), st), "mlp_strip")
+        else:
+            check(lib().nbci_gemm(C.byref(up), st), "up"); check(lib().nbci_gemm(C.byref(dn), st), "down")
+        torch.cuda.synchronize()
+        outs.append((g, da, y))
+    for a, b, nm in zip(outs[0], outs[1], ("g", "act'", "y")):
+        assert torch.equal(a, b), nm
+    assert outs[0][2].abs().sum() > 0
