@@ -305,6 +305,11 @@ int nbci_debug_gemm_streamk(int32_t mode);
  * problem, scheme (0 contiguous runs, 1 owner + helper "aligned", 2 block per XCD), workgroups, owner K tiles, remainder K tiles, scratch
  * slots of 64 KB, output tiles, K tiles per output tile of problem 0}. The pointers in the descriptors are only checked for alignment. */
 int nbci_debug_gemm_grouped_plan(const nbci_gemm_desc* descs, int32_t n, int32_t* out8);
+/* Everything queued on `before` so far happens-before what is queued on `after` from here on: an event record + stream wait whose event carries
+ * no system-scope fence (both streams are on the calling thread's current device; kernel boundaries publish at agent scope). The reference's
+ * counterpart is implicit (one stream); torch's Stream.wait_stream records a fenced event, whose cache write-back sits between two kernels
+ * of the main stream every time. Host visibility still needs a stream / device synchronisation. */
+int nbci_stream_order(nbci_stream_t before, nbci_stream_t after);
 /* Frees the scratch buffers the library allocated on its own (the grouped GEMM's partial tiles). Call with the streams idle. */
 int nbci_release_scratch(void);
 /* The balanced grouped launch's owners wait for other workgroups' partial tiles with a BOUNDED spin; *out = how many gave up since the

@@ -163,6 +163,7 @@ _SIGNATURES = {
     "nbci_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "nbci_streamk_timeouts": (C.c_int, [C.POINTER(C.c_int64)]),
+    "nbci_stream_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nbci_debug_mlp_strip": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), C.c_void_p]),
     "nbci_profile_collect_text": (C.c_int, [C.c_char_p, C.c_int64]),
     "nbci_adamw_lp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

@@ -150,6 +150,16 @@ int nbci_debug_gemm_streamk(int32_t mode) {
     nbci::gemm_streamk_set_mode(mode);
     return NBCI_OK;
 }
+int nbci_stream_order(nbci_stream_t before, nbci_stream_t after) {
+    static thread_local hipEvent_t ev[16] = {};
+    int dev = 0;
+    NBCI_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return nbci::fail(NBCI_EINVAL, "stream_order: device index out of range");
+    if (!ev[dev]) NBCI_CHECK_HIP(hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming | hipEventDisableSystemFence));
+    NBCI_CHECK_HIP(hipEventRecord(ev[dev], (hipStream_t)before));
+    NBCI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)after, ev[dev], 0));   // (the wait captures this record; the event may be re-recorded at once)
+    return NBCI_OK;
+}
 int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
 int nbci_streamk_timeouts(int64_t* out) {
     if (!out) return nbci::fail(NBCI_EINVAL, "streamk_timeouts: null output");

@@ -497,9 +497,11 @@ int ndt1_backward(const Plan& p, const float* params, const void* params_lp, con
     const bool two = aux != s;
     hipStream_t wgs = aux;
     if (two && !p.ev_main) {
-        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_main, hipEventDisableTiming));
-        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[0], hipEventDisableTiming));
-        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[1], hipEventDisableTiming));
+        // (no system-scope fence on the fork event: its only waiter is the aux stream of the SAME device - kernel boundaries already publish at agent
+        //  scope - and the system fence's cache write-back / invalidate sits between two kernels of the chain every time the event is recorded)
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_main, hipEventDisableTiming | hipEventDisableSystemFence));
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[0], hipEventDisableTiming | hipEventDisableSystemFence));
+        NBCI_CHECK_HIP(hipEventCreateWithFlags(&p.ev_wg[1], hipEventDisableTiming | hipEventDisableSystemFence));
     }
     auto fork = [&]() -> int {   // everything queued on the main stream so far happens-before what is queued on the aux stream from here on
         if (!two) return NBCI_OK;

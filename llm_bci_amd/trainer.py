@@ -31,6 +31,11 @@ def register_into(reference_trainer_module):
     reference_trainer_module.NAME2MODEL["PatchTST"] = PatchTSTForSpikingActivity
 
 
+def _order(before, after):
+    """`after` waits for what `before` holds now (Stream.wait_stream without the recorded event's system-scope fence: nbci_stream_order)."""
+    check(lib().nbci_stream_order(C.c_void_p(before.cuda_stream), C.c_void_p(after.cuda_stream)), "nbci_stream_order")
+
+
 class NativeTrainer:
     def __init__(self, model, lr=1e-3, wd=5e-5, eps=1e-8, scheduler="cosine", total_steps=1000, warmup_pct=0.0,
                  div_factor=25.0, gamma=0.95, gradient_accumulation_steps=1, betas=(0.9, 0.999), group=None,
@@ -119,7 +124,7 @@ class NativeTrainer:
             if self._aux is None:
                 self._aux = torch.cuda.Stream(device=self.stats.device)
             aux = self._aux
-            aux.wait_stream(main)
+            _order(main, aux)
             for seg in range(nseg - 1, 0 if split is not None else -1, -1):
                 m._run_backward(self.grads, seg, seg, aux=aux)
                 with torch.cuda.stream(aux):
@@ -180,14 +185,14 @@ class NativeTrainer:
         if self._aux is None:
             self._aux = torch.cuda.Stream(device=self.stats.device)
         aux = self._aux
-        aux.wait_stream(main)     # (first use; afterwards every step ends with main waiting for aux)
+        _order(main, aux)     # (first use; afterwards every step ends with main waiting for aux)
         for seg in range(len(m._segments) - 1, -1, -1):
             m._run_backward(self.grads, seg, seg, aux=aux)
             if sync:
                 b, e = m._segments[seg]
                 with torch.cuda.stream(aux):   # (256 workgroups: one per CU leaves the chain's workgroups their wave slots; A/B 256 / 512 / 1024)
                     self._adamw(b, e, zero=True, max_blocks=256)
-        main.wait_stream(aux)     # the next forward reads the updated weights and reuses the activations the weight gradients read
+        _order(aux, main)     # the next forward reads the updated weights and reuses the activations the weight gradients read
         return sync
     def train_step(self, batch, seed=None):
         """One micro-batch: forward, backward (+ overlapped all-reduce), and — on the steps the
@@ -198,11 +203,11 @@ class NativeTrainer:
         main = torch.cuda.current_stream()
         if self._mstream is None:
             self._mstream = torch.cuda.Stream(device=self.stats.device)
-        main.wait_stream(self._mstream)   # the previous step's metric has read its inputs before their memory is recycled
+        _order(self._mstream, main)   # the previous step's metric has read its inputs before their memory is recycled
         loss_vec, preds = m._run_forward(batch, want_grad=True, seed=seed, grad_scale=1.0 / self.ga)
         # The reference computes its metric every step (trainer.py:359-362): greedy decode + PER and the loss bookkeeping read
         # forward outputs only, so they run on a second stream BESIDE the backward (two latency-bound launches, ~40 us).
-        self._mstream.wait_stream(main)
+        _order(main, self._mstream)
         with torch.cuda.stream(self._mstream):
             err = None
             if self.compute_per and batch.get("targets") is not None and hasattr(m, "last_argmax"):
@@ -234,7 +239,7 @@ class NativeTrainer:
                     self.grads.zero_()
             if done != m._total:
                 raise RuntimeError("gradient buckets do not cover the flat parameter buffer")
-            main.wait_stream(self._aux)
+            _order(self._aux, main)
             self.opt_step += 1
         elif sync and stepped:
             self.opt_step += 1
