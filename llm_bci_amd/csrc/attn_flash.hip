@@ -771,6 +771,180 @@ __global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn2_bwd
         }
 }
 
+
+// =================================================================================================================================
+// Round 4: 32 x 32 score tiles. The kernels above give a wave 16 x 32 score tiles from 16x16x32 MFMAs: four lanes share a query (two
+// cross-lane exchanges per 16-query tile and step for the running maximum), every MFMA blocks the SIMD's vector issue for 8 of its 16
+// cycles, and a wave carries two query tiles (212+ registers: two waves per SIMD). Here a wave owns 32 queries and computes
+// S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (8 of 32 cycles): lane (q = lane % 32, hi = lane / 32) holds the 16 scores of query q
+// against keys {4 hi + (r & 3) + 8 (r >> 2)} of the 32-key step - ONE exchange (v_permlane32_swap) per step for the row maximum, and the
+// scores, packed to bf16 in register order, ARE the B operand of O^T += V^T . P^T (two k = 16 slabs) once V's transposed fragment takes
+// its keys in the same order. ~150 registers at head 96: three waves per SIMD, so one wave's softmax runs beside the others' MFMAs.
+// The dropout scale 1 / (1 - p) is applied once, with 1 / l, at the end (the kept probabilities enter P.V unscaled).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float fa3_swap32(float x) {   // the value the lane 32 away holds
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(threadIdx.x & 32 ? r[0] : r[1]);
+#else
+    return __shfl_xor(x, 32, 64);
+#endif
+}
+
+// transposed fragment read as inline asm: through the builtin (fa_tr) hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of every step -
+// it cannot tell the read from the LDS-DMA of the NEXT stage still in flight - and the prefetch stops overlapping the step (gemm_glds.h has the
+// same note). The compiler neither counts nor waits for an asm read: fa3_lgkm0() before the first use.
+__device__ __forceinline__ s16x4 fa3_tr_half(const char* img, int row, int col) {
+    s16x4 r;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(img + fa_off(row, col >> 3) + (col & 7) * 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+struct Fa3V { s16x4 h[4]; };   // V^T fragments of one 32-column block: keys {4 hi .. +3, 8 + 4 hi .. +3} (slab 0) and the same + 16 (slab 1)
+__device__ __forceinline__ void fa3_read_v(Fa3V& v, const char* vimg, int db, int lane) {
+    const int hi = lane >> 5, i16 = lane & 15, d16 = (lane >> 4) & 1;
+    const int q = i16 >> 2, col = 32 * db + 16 * d16 + 4 * (i16 & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.h[j] = fa3_tr_half(vimg, 8 * j + 4 * hi + q, col);
+}
+__device__ __forceinline__ void fa3_lgkm0() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 fa3_join(const s16x4& a, const s16x4& b) {
+    union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
+    u.p2.a = a; u.p2.b = b;
+    return u.v;
+}
+
+template <int HD, bool TAIL, bool MASK, bool DROP>
+__device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const char* kimg, const char* vimg, int k0, const bf16x8 (&qf)[HD / 16],
+                                             f32x16 (&o)[HD / 32], float& m, float& l, float c, unsigned rbase, int qidx, int sq, int lane) {
+    const int q32 = lane & 31, hi = lane >> 5;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) {
+        const bf16x8 kf = *(const bf16x8*)(kimg + fa_off(q32, 2 * kk + hi));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+    }
+    Fa3V vf;
+    fa3_read_v(vf, vimg, 0, lane);   // in flight under the softmax
+    unsigned vb = 0u;
+    if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
+    if constexpr (TAIL || MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kofs = 4 * hi + (r & 3) + 8 * (r >> 2), key = k0 + kofs;
+            bool ok = !TAIL || key < a.S;
+            if constexpr (MASK) ok = ok && (key == qidx || (fa_ctx(qidx, key, a.cf, a.cb) && ((vb >> kofs) & 1u)));
+            if (!ok) s[r] = -INFINITY;
+        }
+    }
+    float cm = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) cm = fmaxf(fmaxf(cm, s[r]), s[r + 1]);   // (v_max3_f32)
+    cm = fmaxf(cm, fa3_swap32(cm));
+    if (__builtin_amdgcn_ballot_w64(cm > m) != 0ull) {   // some row's maximum moved (wave-uniform; rare after the first steps)
+        const float mn = fmaxf(m, cm);
+        const float corr = (m == mn) ? 1.0f : __builtin_amdgcn_exp2f((m - mn) * c);   // (MASK: a row with no visible key yet keeps -inf)
+        m = mn;
+        l *= corr;
+#pragma unroll
+        for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= corr;
+    }
+    const float mc = (MASK && m == -INFINITY) ? 0.f : m * c;   // (all of this row's scores are -inf so far: exp2(-inf - 0) = 0)
+    float ps = 0.f;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (DROP) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), 1.0f, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * r4 + e], c, -mc));
+            ps += p;
+            s[4 * r4 + e] = DROP ? p * keep[e] : p;
+        }
+    }
+    l += ps;
+    const bf16x8 p0 = {f2bf(s[0]), f2bf(s[1]), f2bf(s[2]), f2bf(s[3]), f2bf(s[4]), f2bf(s[5]), f2bf(s[6]), f2bf(s[7])};
+    const bf16x8 p1 = {f2bf(s[8]), f2bf(s[9]), f2bf(s[10]), f2bf(s[11]), f2bf(s[12]), f2bf(s[13]), f2bf(s[14]), f2bf(s[15])};
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db) {
+        fa3_lgkm0();
+        const bf16x8 v0 = fa3_join(vf.h[0], vf.h[1]), v1 = fa3_join(vf.h[2], vf.h[3]);
+        if (db + 1 < HD / 32) fa3_read_v(vf, vimg, db + 1, lane);   // the next block's reads fly under this block's MFMAs
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, o[db], 0, 0, 0);
+    }
+}
+
+#ifndef FA3_W96
+#define FA3_W96 2
+#endif
+template <int HD, bool MASK, bool DROP>
+__global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fattn3_fwd_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q32 = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.y * 4 + wave) * 32;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const int nsteps = (a.S + 31) / 32, nfull = a.S / 32;   // (the last step is ragged iff nfull < nsteps)
+    fa2_stage<HD>(smem, base + a.H, ld, base + 2 * a.H, ld, 0, a.S, wave, lane);
+    __syncthreads();
+    if (q0 >= a.S) {   // a wave past the end of the sequence: its share of the loads and the barriers, nothing else
+        for (int st = 0; st < nfull; ++st) {
+            if (st + 1 < nsteps) fa2_stage<HD>(smem + ((st + 1) & 1) * FA2_STAGE, base + a.H, ld, base + 2 * a.H, ld, 32 * (st + 1), a.S, wave, lane);
+            __syncthreads();
+        }
+        return;
+    }
+    const int query = q0 + q32, qrow = query < a.S ? query : a.S - 1;
+    bf16x8 qf[HD / 16];
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) qf[kk] = *(const bf16x8*)(base + (long long)qrow * ld + 16 * kk + 8 * hi);
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float c = a.scale * 1.44269504088896341f;
+    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    for (int st = 0; st < nfull; ++st) {
+        const char* cur = smem + (st & 1) * FA2_STAGE;
+        if (st + 1 < nsteps) fa2_stage<HD>(smem + ((st + 1) & 1) * FA2_STAGE, base + a.H, ld, base + 2 * a.H, ld, 32 * (st + 1), a.S, wave, lane);
+        fa3_fwd_step<HD, false, MASK, DROP>(a, cur, cur + FA_IMG, 32 * st, qf, o, m, l, c, rbase, qrow, sq, lane);
+        __syncthreads();   // the next stage has landed (hipcc drains the LDS-DMA ahead of the barrier); everyone is done with `cur`
+    }
+    if (nfull < nsteps) {
+        const char* cur = smem + (nfull & 1) * FA2_STAGE;
+        fa3_fwd_step<HD, true, MASK, DROP>(a, cur, cur + FA_IMG, 32 * nfull, qf, o, m, l, c, rbase, qrow, sq, lane);
+    }
+    const float lt = l + fa3_swap32(l);
+    if (query < a.S) {
+        const float inv = a.dscale / lt;
+        const long long obase = ((long long)sq * a.S + query) * a.H + h * HD;
+#pragma unroll
+        for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = 32 * db + 8 * r4 + 4 * hi;
+                float v[4] = {o[db][4 * r4] * inv, o[db][4 * r4 + 1] * inv, o[db][4 * r4 + 2] * inv, o[db][4 * r4 + 3] * inv};
+                if (MASK && a.thr_out) drop4(a.key_out, a.thr_out, (unsigned)(obase + d), a.oscale, v);   // ndt1.py:292
+                const bf16x4 ov = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)(a.out + obase + d) = ov;
+            }
+        if (hi == 0) a.L[(long long)unit * a.S + query] = m * a.scale + __logf(lt);
+    }
+}
+
 bool fattn_eligible(int dtype, int S, int H, int nh) {
     const char* e = measure_env_str("NBCI_FLASH_ATTN");   // (measurement builds; the NDT1 plan has its own switch, read at plan creation)
     const bool off = e && e[0] == '0';
@@ -793,6 +967,14 @@ template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
     static const int shared = measure_env("NBCI_FA_SHARED", 1);   // measurement: 0 = the wave-private streaming kernels above
+    static const int tiles32 = measure_env("NBCI_FA_TILES32", 1);  // measurement: 0 = the 16 x 32 score-tile kernels
+    if (tiles32 && which == 0) {
+        if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
+        const dim3 g3(a.NS * a.nh, (a.S + 127) / 128);
+        if (a.thr) hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+        else hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+        return check_launch("flash attention forward (32 x 32 tiles)");
+    }
     if (shared && (HD < 128 || which == 0)) {   // the four waves of a workgroup share every streamed tile through LDS (two stages of two 8 KB images);
                                                   // head 128 backward: the shared dk/dv kernel spills (35 registers) and runs 27 % slower: wave-private kernels
         if (prof_on()) prof_note_symbol(which == 0 ? "fattn2_fwd_kernel" : which == 1 ? "fattn2_bwd_q_kernel" : "fattn2_bwd_kv_kernel");

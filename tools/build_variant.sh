@@ -1,16 +1,11 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> [extra hipcc flags...]: a MEASUREMENT build of the library into build/<name>/libnbci.so
-# (e.g. tools/build_variant.sh stamps -DNBCI_STAMPS); load it with NBCI_LIB=build/<name>/libnbci.so. build/ is git-ignored
-# but travels to the GPU box with gpurun.
+# build/<name>/libnbci.so = the library with one source rebuilt under extra flags:  tools/build_variant.sh NAME FILE.hip -DFLAG=1 ...
 set -e
-name=$1; shift
-root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/build/$name
-mkdir -p "$out"
-cd "$root/llm_bci_amd/csrc"
-for f in *.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=200000 "$@" -c "$f" -o "$out/${f%.hip}.o" &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libnbci.so" "$out"/*.o
-echo "built $out/libnbci.so"
+name=$1; src=$2; shift 2
+cd "$(dirname "$0")/../llm_bci_amd/csrc"
+mkdir -p ../../build/$name
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=200000 -DNBCI_MEASURE "$@" -c $src -o ../../build/$name/${src%.hip}.o
+objs=""
+for o in *.o; do if [ "$o" = "${src%.hip}.o" ]; then objs="$objs ../../build/$name/$o"; else objs="$objs $o"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/$name/libnbci.so $objs
+echo "build/$name/libnbci.so"
