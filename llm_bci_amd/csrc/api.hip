@@ -160,7 +160,11 @@ int nbci_stream_order(nbci_stream_t before, nbci_stream_t after) {
     NBCI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)after, ev[dev], 0));   // (the wait captures this record; the event may be re-recorded at once)
     return NBCI_OK;
 }
-int nbci_release_scratch(void) { return nbci::gemm_streamk_release(); }
+int nbci_release_scratch(void) {
+    const int rc = nbci::gemm_streamk_release();
+    const int rc2 = nbci::fattn_release();
+    return rc != NBCI_OK ? rc : rc2;
+}
 int nbci_streamk_timeouts(int64_t* out) {
     if (!out) return nbci::fail(NBCI_EINVAL, "streamk_timeouts: null output");
     long long n = 0;

@@ -14,6 +14,8 @@
 // Dropout bits = the counter stream of the unfused softmax kernel (index ((unit*S + query)*S + key)): both paths and the
 // oracle draw identical masks.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "kernels.h"
 
@@ -35,6 +37,9 @@ struct FAArgs {
     int NS, nh, S, H;
     float scale;
     unsigned thr; float dscale; uint32_t key;
+    // 32 x 32-tile backward with dropout: the dq kernel leaves the keep bits of every (32 queries x 32 keys) tile here for the dk/dv kernel:
+    // 32 words per tile, tile (unit, key block kb, query block qb) at ((unit * nblk + kb) * nblk + qb) * 32; word k = key k, bit q = query q kept
+    uint32_t* keepbits; int nblk;
     // MASK kernels (NDT1: models/ndt1.py:30-41,435-437): key j is visible to query i iff j == i, or the context span allows
     // (i, j) AND token j is valid. tmask (NS, S) int32; cf / cb = context.forward / backward (-2 = unbounded).
     const int32_t* tmask; int cf, cb;
@@ -88,6 +93,19 @@ __device__ __forceinline__ void fa_keep4(uint32_t key, uint32_t thr, uint32_t id
     const uint32_t e2 = odd ? (h1 >> 16) : (h1 & 0xFFFFu);
     const uint32_t e3 = odd ? (hd & 0xFFFFu) : (hd >> 16);
     k[0] = e0 >= thr ? scale : 0.f; k[1] = e1 >= thr ? scale : 0.f; k[2] = e2 >= thr ? scale : 0.f; k[3] = e3 >= thr ? scale : 0.f;
+}
+
+// the same four draws as fa_keep4, as booleans
+__device__ __forceinline__ void fa_keep4_bits(uint32_t key, uint32_t thr, uint32_t idx0, bool (&k)[4]) {
+    const uint32_t p0 = idx0 >> 1;
+    const uint32_t h0 = mix32(p0 ^ key), h1 = mix32((p0 + 1u) ^ key), h2 = mix32((p0 + 2u) ^ key);
+    const bool odd = (idx0 & 1u) != 0u;
+    const uint32_t hb = odd ? h1 : h0, hd = odd ? h2 : h1;
+    const uint32_t e0 = odd ? (h0 >> 16) : (h0 & 0xFFFFu);
+    const uint32_t e1 = odd ? (hb & 0xFFFFu) : (hb >> 16);
+    const uint32_t e2 = odd ? (h1 >> 16) : (h1 & 0xFFFFu);
+    const uint32_t e3 = odd ? (hd & 0xFFFFu) : (hd >> 16);
+    k[0] = e0 >= thr; k[1] = e1 >= thr; k[2] = e2 >= thr; k[3] = e3 >= thr;
 }
 
 // One step's operands: two row-fragment sets (16 rows x 32 k per (t, ks); lane = row i16, 16-byte chunk g) of two strided
@@ -779,8 +797,20 @@ __global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn2_bwd
 // S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (8 of 32 cycles): lane (q = lane % 32, hi = lane / 32) holds the 16 scores of query q
 // against keys {4 hi + (r & 3) + 8 (r >> 2)} of the 32-key step - ONE exchange (v_permlane32_swap) per step for the row maximum, and the
 // scores, packed to bf16 in register order, ARE the B operand of O^T += V^T . P^T (two k = 16 slabs) once V's transposed fragment takes
-// its keys in the same order. ~150 registers at head 96: three waves per SIMD, so one wave's softmax runs beside the others' MFMAs.
-// The dropout scale 1 / (1 - p) is applied once, with 1 / l, at the end (the kept probabilities enter P.V unscaled).
+// its keys in the same order. The dropout scale 1 / (1 - p) is applied once, with 1 / l, at the end (the kept probabilities enter P.V
+// unscaled).
+// Backward on the same tiles. dq kernel: a wave owns 32 queries (lane = query), streams K / V: S^T and dPd^T = V . dO^T come out with the keys
+// of a step in a lane's registers, so dS packs straight into the B operand of dQ^T += K^T . dS^T. dk/dv kernel: a wave owns 32 keys (lane = key),
+// streams Q / dO (+ the row statistics): S = Q . K^T and dPd = dO . V^T with the step's queries in registers, P and dS pack into the B operands of
+// dV^T += dO^T . P and dK^T += Q^T . dS.
+// Plumbing shared by the three kernels:
+//   * every LDS read is inline asm. Through C++ reads / the transposed-read builtin hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of
+//     every step - it cannot tell the read from the LDS-DMA of the NEXT stage still in flight - and the prefetch stops overlapping the step
+//     (gemm_glds.h has the same note). The compiler neither counts nor waits for an asm read: fa3_lgkm<N>() before the first use;
+//   * a lane's LDS addresses are ONE set of stage-relative byte offsets computed before the loop (Fa3Lane); stage (0 / 1) and image (X / Y /
+//     statistics) are the instruction's immediate offset, the loop is unrolled over the two stages. (Left to the compiler, every address of both
+//     stages became a loop-invariant register: ~90 VGPRs, spills in the dk/dv kernel at head 96.);
+//   * the staging pointers advance by 32 rows per step (Fa3Stager); only the one ragged stage at the end of the sequence is clamped.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float fa3_swap32(float x) {   // the value the lane 32 away holds
@@ -792,46 +822,161 @@ __device__ __forceinline__ float fa3_swap32(float x) {   // the value the lane 3
 #endif
 }
 
-// transposed fragment read as inline asm: through the builtin (fa_tr) hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of every step -
-// it cannot tell the read from the LDS-DMA of the NEXT stage still in flight - and the prefetch stops overlapping the step (gemm_glds.h has the
-// same note). The compiler neither counts nor waits for an asm read: fa3_lgkm0() before the first use.
-__device__ __forceinline__ s16x4 fa3_tr_half(const char* img, int row, int col) {
-    s16x4 r;
-    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(img + fa_off(row, col >> 3) + (col & 7) * 2);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+template <int IMM> __device__ __forceinline__ bf16x8 fa3_row(unsigned off) {   // 16 bytes at stage-relative offset off + IMM
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(off), "n"(IMM));
     return r;
 }
-struct Fa3V { s16x4 h[4]; };   // V^T fragments of one 32-column block: keys {4 hi .. +3, 8 + 4 hi .. +3} (slab 0) and the same + 16 (slab 1)
-__device__ __forceinline__ void fa3_read_v(Fa3V& v, const char* vimg, int db, int lane) {
-    const int hi = lane >> 5, i16 = lane & 15, d16 = (lane >> 4) & 1;
-    const int q = i16 >> 2, col = 32 * db + 16 * d16 + 4 * (i16 & 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v.h[j] = fa3_tr_half(vimg, 8 * j + 4 * hi + q, col);
+template <int IMM> __device__ __forceinline__ float4 fa3_f4(unsigned off) {
+    float4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(off), "n"(IMM));
+    return r;
 }
-__device__ __forceinline__ void fa3_lgkm0() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+template <int IMM> __device__ __forceinline__ s16x4 fa3_tr(unsigned off) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(off), "n"(IMM));
+    return r;
+}
+// at most N of this wave's LDS reads still outstanding (LDS returns in order; any other lgkm traffic only makes the wait more conservative)
+template <int N> __device__ __forceinline__ void fa3_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+// end of a step: this wave's share of the next stage has landed, then everyone's has (and everyone is done with the current stage)
+__device__ __forceinline__ void fa3_stage_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 __device__ __forceinline__ bf16x8 fa3_join(const s16x4& a, const s16x4& b) {
     union { struct { s16x4 a, b; } p2; bf16x8 v; } u;
     u.p2.a = a; u.p2.b = b;
     return u.v;
 }
+__device__ __forceinline__ bf16x8 fa3_pack8(const f32x16& s, int o) {
+    const bf16x8 r = {f2bf(s[o]), f2bf(s[o + 1]), f2bf(s[o + 2]), f2bf(s[o + 3]), f2bf(s[o + 4]), f2bf(s[o + 5]), f2bf(s[o + 6]), f2bf(s[o + 7])};
+    return r;
+}
 
-template <int HD, bool TAIL, bool MASK, bool DROP>
-__device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const char* kimg, const char* vimg, int k0, const bf16x8 (&qf)[HD / 16],
-                                             f32x16 (&o)[HD / 32], float& m, float& l, float c, unsigned rbase, int qidx, int sq, int lane) {
-    const int q32 = lane & 31, hi = lane >> 5;
+template <int HD> struct Fa3Lane {
+    unsigned row0;             // row fragment 0 (16 bytes: columns 8 hi ..) of row lane % 32 of an image; fragment kk (columns 16 kk + 8 hi ..) = row0 ^ (kk << 5):
+                               // the chunk index 2 kk + hi meets the swizzle by XOR and stays below 16
+    __device__ __forceinline__ unsigned row(int kk) const { return row0 ^ (unsigned)(kk << 5); }
+    unsigned tr[4];            // transposed fragments of column block 0: rows {8 j + 4 hi + (lane % 16) / 4}, see Fa3T; block db = tr[j] ^ (db << 6)
+                               // (the block index only meets the swizzle's upper two bits: chunk = ((db ^ q) << 2) | ..; smem is 256-byte aligned)
+    unsigned stat;             // this lane's first staged statistic (hi selects the second group of four)
+    __device__ __forceinline__ void init(const char* smem, int lane) {
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+        const int q32 = lane & 31, hi = lane >> 5, i16 = lane & 15, d16 = (lane >> 4) & 1;
+        row0 = base + fa_off(q32, hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 16 * d16 + 4 * (i16 & 3);
+            tr[j] = base + fa_off(8 * j + 4 * hi + (i16 >> 2), col >> 3) + (col & 7) * 2;
+        }
+        stat = base + 16 * hi;
+    }
+};
+// X^T fragments of one 32-column block for the two k = 16 slabs of a step: rows {4 hi .. +3, 8 + 4 hi .. +3} (slab 0) and the same + 16 (slab 1)
+struct Fa3T { s16x4 h[4]; };
+template <int HD, int IMM> __device__ __forceinline__ void fa3_read_t(Fa3T& v, const Fa3Lane<HD>& ln, int db) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.h[j] = fa3_tr<IMM>(ln.tr[j] ^ (unsigned)(db << 6));
+}
+
+// this wave's share of a stage: pieces w and w + 4 (4 rows x 256 B each) of the X image and of the Y image, 16 bytes per lane by LDS-DMA, the
+// image's XOR swizzle applied to the per-lane SOURCE chunk. Addresses = a wave-uniform base that advances 32 rows per step (scalar registers) + a
+// constant 32-bit byte offset per lane and piece (the launcher checks S x row pitch < 4 GB).
+template <int HD> struct Fa3Stager {
+    const char* xb;     // row 0 of the next step to stage (uniform)
+    const char* yb;
+    const char* x0;     // row 0 of the sequence (uniform; the clamped stage)
+    const char* y0;
+    unsigned px, py;    // row pitches in bytes
+    unsigned xo[2], yo[2];
+    __device__ __forceinline__ void init(const bf16_t* xp, long long ldx, const bf16_t* yp, long long ldy, int w, int lane) {
+        xb = x0 = (const char*)xp; yb = y0 = (const char*)yp;
+        px = (unsigned)(2 * ldx); py = (unsigned)(2 * ldy);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 4 * (w + 4 * j) + (lane >> 4);
+            xo[j] = (unsigned)r * px + chunk_bytes(r, lane);
+            yo[j] = (unsigned)r * py + chunk_bytes(r, lane);
+        }
+    }
+    static __device__ __forceinline__ unsigned chunk_bytes(int r, int lane) {
+        int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));   // the chunk whose home is this 16-byte slot (fa_off is an involution per row)
+        if (ch >= HD / 8) ch = 0;                                    // (slots no fragment read touches: any valid address)
+        return (unsigned)ch * 16u;
+    }
+    // CLAMP: rows past the end of the sequence read row S - 1 (they only ever meet zero probabilities); r0 = first row of the step being staged
+    template <bool CLAMP> __device__ __forceinline__ void issue(char* stage, int w, int lane, int r0, int S) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* xs;
+            const char* ys;
+            if constexpr (CLAMP) {
+                const int r = 4 * (w + 4 * j) + (lane >> 4);
+                int gr = r0 + r;
+                if (gr > S - 1) gr = S - 1;
+                xs = x0 + ((unsigned)gr * px + chunk_bytes(r, lane));
+                ys = y0 + ((unsigned)gr * py + chunk_bytes(r, lane));
+            } else {
+                xs = xb + xo[j];
+                ys = yb + yo[j];
+            }
+            __builtin_amdgcn_global_load_lds((fa_gvoid*)xs, (fa_lvoid*)(stage + (w + 4 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fa_gvoid*)ys, (fa_lvoid*)(stage + FA_IMG + (w + 4 * j) * 1024), 16, 0, 0);
+        }
+        xb += 32u * px; yb += 32u * py;
+    }
+};
+
+// The loop the three kernels share. `st` stages ahead; STEP(stage, tail, k0) computes one step out of stage `stage` (compile-time 0 / 1).
+#define FA3_LOOP(ACTIVE, STAGE_EXTRA, STEP)                                                                           \
+    {                                                                                                                 \
+        const int nsteps = (a.S + 31) / 32, nfull = a.S / 32;                                                         \
+        if (nsteps > 1 || nfull == 1) stg.template issue<false>(smem, wave, lane, 0, a.S); else stg.template issue<true>(smem, wave, lane, 0, a.S); \
+        STAGE_EXTRA(smem, 0);                                                                                         \
+        fa3_stage_barrier();                                                                                          \
+        for (int st = 0; st < nfull; st += 2) {                                                                       \
+            if (st + 1 < nsteps) {                                                                                    \
+                if (st + 1 < nfull) stg.template issue<false>(smem + FA2_STAGE, wave, lane, 32 * (st + 1), a.S);            \
+                else stg.template issue<true>(smem + FA2_STAGE, wave, lane, 32 * (st + 1), a.S);                            \
+                STAGE_EXTRA(smem + FA2_STAGE, 32 * (st + 1));                                                         \
+            }                                                                                                         \
+            if (ACTIVE) STEP(0, false, 32 * st);                                                                      \
+            fa3_stage_barrier();                                                                                      \
+            if (st + 1 >= nfull) break;                                                                               \
+            if (st + 2 < nsteps) {                                                                                    \
+                if (st + 2 < nfull) stg.template issue<false>(smem, wave, lane, 32 * (st + 2), a.S);                        \
+                else stg.template issue<true>(smem, wave, lane, 32 * (st + 2), a.S);                                        \
+                STAGE_EXTRA(smem, 32 * (st + 2));                                                                     \
+            }                                                                                                         \
+            if (ACTIVE) STEP(1, false, 32 * (st + 1));                                                                \
+            fa3_stage_barrier();                                                                                      \
+        }                                                                                                             \
+        if ((ACTIVE) && nfull < nsteps) {                                                                             \
+            if (nfull & 1) STEP(1, true, 32 * nfull); else STEP(0, true, 32 * nfull);                                 \
+        }                                                                                                             \
+    }
+#define FA3_NOEXTRA(ST, R0) do { } while (0)
+
+template <int HD, int STG, bool TAIL, bool MASK, bool DROP>
+__device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>& ln, int k0, const bf16x8 (&qf)[HD / 16], f32x16 (&o)[HD / 32],
+                                             float& m, float& l, float c, unsigned rbase, int qidx, int sq, int lane) {
+    constexpr int KK = HD / 16, XI = STG * FA2_STAGE, YI = XI + FA_IMG;   // X = K rows, Y = V rows
+    const int hi = lane >> 5;
+    bf16x8 kr[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) kr[kk] = fa3_row<XI>(ln.row(kk));
+    Fa3T vf;
+    fa3_read_t<HD, YI>(vf, ln, 0);   // in flight under the softmax
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    fa3_lgkm<4>();
 #pragma unroll
-    for (int kk = 0; kk < HD / 16; ++kk) {
-        const bf16x8 kf = *(const bf16x8*)(kimg + fa_off(q32, 2 * kk + hi));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
-    }
-    Fa3V vf;
-    fa3_read_v(vf, vimg, 0, lane);   // in flight under the softmax
+    for (int kk = 0; kk < KK; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[kk], qf[kk], s, 0, 0, 0);
     unsigned vb = 0u;
     if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
     if constexpr (TAIL || MASK) {
@@ -871,13 +1016,12 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const char* kimg, 
         }
     }
     l += ps;
-    const bf16x8 p0 = {f2bf(s[0]), f2bf(s[1]), f2bf(s[2]), f2bf(s[3]), f2bf(s[4]), f2bf(s[5]), f2bf(s[6]), f2bf(s[7])};
-    const bf16x8 p1 = {f2bf(s[8]), f2bf(s[9]), f2bf(s[10]), f2bf(s[11]), f2bf(s[12]), f2bf(s[13]), f2bf(s[14]), f2bf(s[15])};
+    const bf16x8 p0 = fa3_pack8(s, 0), p1 = fa3_pack8(s, 8);
 #pragma unroll
     for (int db = 0; db < HD / 32; ++db) {
-        fa3_lgkm0();
+        fa3_lgkm<0>();
         const bf16x8 v0 = fa3_join(vf.h[0], vf.h[1]), v1 = fa3_join(vf.h[2], vf.h[3]);
-        if (db + 1 < HD / 32) fa3_read_v(vf, vimg, db + 1, lane);   // the next block's reads fly under this block's MFMAs
+        if (db + 1 < HD / 32) fa3_read_t<HD, YI>(vf, ln, db + 1);   // the next block's reads fly under this block's MFMAs
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, o[db], 0, 0, 0);
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, o[db], 0, 0, 0);
     }
@@ -888,23 +1032,18 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const char* kimg, 
 #endif
 template <int HD, bool MASK, bool DROP>
 __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fattn3_fwd_kernel(FAArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q32 = lane & 31, hi = lane >> 5;
     const int q0 = (blockIdx.y * 4 + wave) * 32;
     const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
-    const int nsteps = (a.S + 31) / 32, nfull = a.S / 32;   // (the last step is ragged iff nfull < nsteps)
-    fa2_stage<HD>(smem, base + a.H, ld, base + 2 * a.H, ld, 0, a.S, wave, lane);
-    __syncthreads();
-    if (q0 >= a.S) {   // a wave past the end of the sequence: its share of the loads and the barriers, nothing else
-        for (int st = 0; st < nfull; ++st) {
-            if (st + 1 < nsteps) fa2_stage<HD>(smem + ((st + 1) & 1) * FA2_STAGE, base + a.H, ld, base + 2 * a.H, ld, 32 * (st + 1), a.S, wave, lane);
-            __syncthreads();
-        }
-        return;
-    }
+    const bool active = q0 < a.S;   // a wave past the end of the sequence: its share of the loads and the barriers, nothing else
+    Fa3Stager<HD> stg;
+    stg.init(base + a.H, ld, base + 2 * a.H, ld, wave, lane);
+    Fa3Lane<HD> ln;
+    ln.init(smem, lane);
     const int query = q0 + q32, qrow = query < a.S ? query : a.S - 1;
     bf16x8 qf[HD / 16];
 #pragma unroll
@@ -917,16 +1056,10 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fa
     float m = -INFINITY, l = 0.f;
     const float c = a.scale * 1.44269504088896341f;
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-    for (int st = 0; st < nfull; ++st) {
-        const char* cur = smem + (st & 1) * FA2_STAGE;
-        if (st + 1 < nsteps) fa2_stage<HD>(smem + ((st + 1) & 1) * FA2_STAGE, base + a.H, ld, base + 2 * a.H, ld, 32 * (st + 1), a.S, wave, lane);
-        fa3_fwd_step<HD, false, MASK, DROP>(a, cur, cur + FA_IMG, 32 * st, qf, o, m, l, c, rbase, qrow, sq, lane);
-        __syncthreads();   // the next stage has landed (hipcc drains the LDS-DMA ahead of the barrier); everyone is done with `cur`
-    }
-    if (nfull < nsteps) {
-        const char* cur = smem + (nfull & 1) * FA2_STAGE;
-        fa3_fwd_step<HD, true, MASK, DROP>(a, cur, cur + FA_IMG, 32 * nfull, qf, o, m, l, c, rbase, qrow, sq, lane);
-    }
+#define F3_STEP(STG, T, K0) fa3_fwd_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, o, m, l, c, rbase, qrow, sq, lane)
+    FA3_LOOP(active, FA3_NOEXTRA, F3_STEP)
+#undef F3_STEP
+    if (!active) return;
     const float lt = l + fa3_swap32(l);
     if (query < a.S) {
         const float inv = a.dscale / lt;
@@ -945,6 +1078,283 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fa
     }
 }
 
+template <int HD, int STG, bool TAIL, bool MASK, bool DROP>
+__device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>& ln, int k0, const bf16x8 (&qf)[HD / 16], const bf16x8 (&df)[HD / 16],
+                                              f32x16 (&dq)[HD / 32], float L2, float D, float c, unsigned rbase, int qidx, int sq, int lane,
+                                              uint32_t* kw) {
+    constexpr int KK = HD / 16, XI = STG * FA2_STAGE, YI = XI + FA_IMG;   // X = K rows, Y = V rows
+    const int hi = lane >> 5;
+    bf16x8 kr[KK], vr[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) kr[kk] = fa3_row<XI>(ln.row(kk));
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) vr[kk] = fa3_row<YI>(ln.row(kk));
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    fa3_lgkm<KK>();
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[kk], qf[kk], s, 0, 0, 0);
+    fa3_lgkm<0>();
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[kk], df[kk], dp, 0, 0, 0);   // dPd[key][query] = v . dO
+    Fa3T kt;
+    fa3_read_t<HD, XI>(kt, ln, 0);
+    unsigned vb = 0u;
+    if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
+    unsigned kword = 0u;   // DROP: lane k < 32 collects the word of key k0 + k (bit q = query q of this wave keeps it)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        bool keep[4] = {true, true, true, true};
+        if constexpr (DROP) fa_keep4_bits(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e, kofs = 8 * r4 + 4 * hi + e, key = k0 + kofs;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L2));
+            bool ok = !TAIL || key < a.S;
+            if constexpr (MASK) ok = ok && (key == qidx || (fa_ctx(qidx, key, a.cf, a.cb) && ((vb >> kofs) & 1u)));
+            if (TAIL || MASK) p = ok ? p : 0.f;
+            float t = dp[r];
+            if constexpr (DROP) {
+                t = keep[e] ? t * a.dscale : 0.f;
+                // the compare's lane mask IS the pair of words of keys 8 r4 + e (lanes 0..31 = the 32 queries) and 8 r4 + 4 + e (lanes 32..63)
+                const uint64_t b = __builtin_amdgcn_ballot_w64(keep[e]);
+                // (s_nop: a VALU-written SGPR is not safe to read in the very next v_writelane - hipcc's hazard recognizer does not look into asm;
+                // without it a few keys per tile carried the previous compare's bits)
+                asm("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                    : "+v"(kword) : "s"((unsigned)b), "s"((unsigned)(b >> 32)), "n"(8 * r4 + e), "n"(8 * r4 + 4 + e));
+            }
+            s[r] = p * (t - D);   // dS / scale (the scale goes into the output)
+        }
+    }
+    if constexpr (DROP) {
+        if (lane < 32) kw[lane] = kword;
+    }
+    const bf16x8 d0 = fa3_pack8(s, 0), d1 = fa3_pack8(s, 8);
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db) {
+        fa3_lgkm<0>();
+        const bf16x8 k0f = fa3_join(kt.h[0], kt.h[1]), k1f = fa3_join(kt.h[2], kt.h[3]);
+        if (db + 1 < HD / 32) fa3_read_t<HD, XI>(kt, ln, db + 1);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, d0, dq[db], 0, 0, 0);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, d1, dq[db], 0, 0, 0);
+    }
+}
+
+template <int HD, bool MASK, bool DROP>
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q32 = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.y * 4 + wave) * 32;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const bool active = q0 < a.S;
+    Fa3Stager<HD> stg;
+    stg.init(base + a.H, ld, base + 2 * a.H, ld, wave, lane);
+    Fa3Lane<HD> ln;
+    ln.init(smem, lane);
+    const int query = q0 + q32, qrow = query < a.S ? query : a.S - 1;
+    const bf16_t* dop = a.dout + ((long long)sq * a.S + qrow) * a.H + h * HD;
+    const bf16_t* op = a.out + ((long long)sq * a.S + qrow) * a.H + h * HD;
+    bf16x8 qf[HD / 16], df[HD / 16];
+    float D = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) {
+        qf[kk] = *(const bf16x8*)(base + (long long)qrow * ld + 16 * kk + 8 * hi);
+        df[kk] = *(const bf16x8*)(dop + 16 * kk + 8 * hi);
+        const bf16x8 of = *(const bf16x8*)(op + 16 * kk + 8 * hi);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D += bf2f(df[kk][e]) * bf2f(of[e]);
+    }
+    D += fa3_swap32(D);
+    // with the output dropout fused into the forward both factors carry keep * scale: dO . O_pre = (dO_masked . O_stored) / scale
+    if (MASK && a.thr_out) D *= 1.0f / a.oscale;
+    const float L2 = a.L[(long long)unit * a.S + qrow] * 1.44269504088896341f;
+    f32x16 dq[HD / 32];
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    const float c = a.scale * 1.44269504088896341f;
+    const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
+    uint32_t* kwq = nullptr;   // the 32 words of tile (unit, key block 0, this wave's query block)
+    if constexpr (DROP) kwq = a.keepbits + ((long long)unit * a.nblk * a.nblk + (q0 >> 5)) * 32;
+#define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32)
+    FA3_LOOP(active, FA3_NOEXTRA, BQ3_STEP)
+#undef BQ3_STEP
+    if (!active || query >= a.S) return;
+    const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = 32 * db + 8 * r4 + 4 * hi;
+            const bf16x4 ov = {f2bf(dq[db][4 * r4] * a.scale), f2bf(dq[db][4 * r4 + 1] * a.scale), f2bf(dq[db][4 * r4 + 2] * a.scale),
+                               f2bf(dq[db][4 * r4 + 3] * a.scale)};
+            *(bf16x4*)(a.dqkv + obase + d) = ov;
+        }
+    if (hi == 0) a.Dsum[(long long)unit * a.S + query] = D;
+}
+
+// dk/dv kernel, head 96: 144 stationary registers + the step's working set sit a few registers above the 256 of two waves per SIMD, and what hipcc spills
+// (V fragments) comes back from scratch behind `s_waitcnt vmcnt(0)`, which drains the stage prefetch. The last NL of a wave's KK stationary V fragments
+// therefore live in a wave-private LDS slot (1 KB each) and are read with the step's dO rows.
+__host__ __device__ constexpr int fa3_kv_lds_frags(int hd) { return hd == 96 ? 2 : 0; }
+
+template <int HD, int STG, bool TAIL, bool MASK, bool DROP>
+__device__ __forceinline__ void fa3_bwdkv_step(const FAArgs& a, const Fa3Lane<HD>& ln, int q0, const bf16x8 (&kf)[HD / 16], const bf16x8 (&vf)[HD / 16],
+                                               f32x16 (&dk)[HD / 32], f32x16 (&dv)[HD / 32], float c, int krow, bool key_valid, int lane,
+                                               unsigned& kwv, const char* kw_next, unsigned vsl) {
+    constexpr int KK = HD / 16, XI = STG * FA2_STAGE, YI = XI + FA_IMG, SI = XI + 2 * FA_IMG, NL = fa3_kv_lds_frags(HD);   // X = Q rows, Y = dO rows, [32 L | 32 D]
+    const int hi = lane >> 5;
+    // DROP: kwv = the keep word of this lane's key for this step's 32 queries (bit q), fetched one step ahead; a lane's queries are {8 r4 + 4 hi + e}
+    unsigned kwn = 0u;
+    if constexpr (DROP) { if (kw_next) kwn = *(const uint32_t*)(kw_next + (unsigned)(4 * (lane & 31))); }   // (kw_next is wave-uniform)
+    const unsigned kws = kwv >> (4 * hi);
+    // register budget (head 96: 144 stationary + 32 scores at two waves per SIMD): the dO rows take the Q rows' registers once S is issued, the row
+    // statistics arrive four queries at a time, one group ahead of their use
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+    {
+        bf16x8 qr[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qr[kk] = fa3_row<XI>(ln.row(kk));
+        fa3_lgkm<0>();
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[kk], kf[kk], st, 0, 0, 0);     // S[query][key]
+        asm volatile("" : "+v"(st));   // (pins the products above the next reads: they are pure, the selection DAG would sink them past the asm)
+    }
+    {
+        bf16x8 dr[KK], vl[NL > 0 ? NL : 1];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) dr[kk] = fa3_row<YI>(ln.row(kk));
+#pragma unroll
+        for (int j = 0; j < NL; ++j) vl[j] = j == 0 ? fa3_row<0>(vsl) : j == 1 ? fa3_row<1024>(vsl) : fa3_row<2048>(vsl);   // (the V fragments parked in LDS)
+        fa3_lgkm<0>();
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[kk], kk < KK - NL ? vf[kk] : vl[kk - (KK - NL)], dpt, 0, 0, 0);   // dPd[query][key] = dO . v
+        asm volatile("" : "+v"(dpt));
+    }
+    Fa3T dt, qt;
+    fa3_read_t<HD, YI>(dt, ln, 0);
+    fa3_read_t<HD, XI>(qt, ln, 0);
+    float4 Ln = fa3_f4<SI>(ln.stat), Dn = fa3_f4<SI + 128>(ln.stat);   // log-sum-exps / dO.O sums of queries {4 hi .. + 3}; next: + 8
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 Lc = Ln, Dc = Dn;
+        if (r4 == 0) { Ln = fa3_f4<SI + 32>(ln.stat); Dn = fa3_f4<SI + 160>(ln.stat); }
+        if (r4 == 1) { Ln = fa3_f4<SI + 64>(ln.stat); Dn = fa3_f4<SI + 192>(ln.stat); }
+        if (r4 == 2) { Ln = fa3_f4<SI + 96>(ln.stat); Dn = fa3_f4<SI + 224>(ln.stat); }
+        if (r4 < 3) fa3_lgkm<2>(); else fa3_lgkm<0>();
+        const float Lv[4] = {Lc.x, Lc.y, Lc.z, Lc.w}, Dv[4] = {Dc.x, Dc.y, Dc.z, Dc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e, q = q0 + 8 * r4 + 4 * hi + e;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, -1.44269504088896341f * Lv[e]));
+            bool ok = !TAIL || q < a.S;
+            if constexpr (MASK) ok = ok && (q == krow || (fa_ctx(q, krow, a.cf, a.cb) && key_valid));
+            if (TAIL || MASK) p = ok ? p : 0.f;
+            float t = dpt[r], pk = p;
+            if constexpr (DROP) {   // all-ones / zero from the query's bit; 1 / (1 - p) reaches dV at the end
+                const unsigned km = (unsigned)__builtin_amdgcn_sbfe((int)kws, 8 * r4 + e, 1);
+                t = __uint_as_float(__float_as_uint(t) & km) * a.dscale;
+                pk = __uint_as_float(__float_as_uint(pk) & km);
+            }
+            dpt[r] = pk;                          // the dropped probability takes dPd's register
+            st[r] = p * (t - Dv[e]) * a.scale;   // dS
+        }
+    }
+    const bf16x8 p0 = fa3_pack8(dpt, 0), p1 = fa3_pack8(dpt, 8), s0 = fa3_pack8(st, 0), s1 = fa3_pack8(st, 8);
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db) {
+        fa3_lgkm<0>();
+        const bf16x8 d0f = fa3_join(dt.h[0], dt.h[1]), d1f = fa3_join(dt.h[2], dt.h[3]);
+        const bf16x8 q0f = fa3_join(qt.h[0], qt.h[1]), q1f = fa3_join(qt.h[2], qt.h[3]);
+        if (db + 1 < HD / 32) { fa3_read_t<HD, YI>(dt, ln, db + 1); fa3_read_t<HD, XI>(qt, ln, db + 1); }
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0f, p0, dv[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1f, p1, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, s0, dk[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1f, s1, dk[db], 0, 0, 0);
+    }
+    if constexpr (DROP) kwv = kwn;
+}
+
+template <int HD, bool MASK, bool DROP>
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_kv_kernel(FAArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q32 = lane & 31, hi = lane >> 5;
+    const int k0 = (blockIdx.y * 4 + wave) * 32;
+    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    const long long ld = 3LL * a.H;
+    const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
+    const bf16_t* dob = a.dout + (long long)sq * a.S * a.H + h * HD;
+    const float* Lu = a.L + (long long)unit * a.S;
+    const float* Du = a.Dsum + (long long)unit * a.S;
+    const bool active = k0 < a.S;
+    Fa3Stager<HD> stg;
+    stg.init(base, ld, dob, (long long)a.H, wave, lane);
+    Fa3Lane<HD> ln;
+    ln.init(smem, lane);
+    const int key = k0 + q32, krow = key < a.S ? key : a.S - 1;
+    const bool key_valid = MASK ? a.tmask[(long long)sq * a.S + krow] != 0 : true;
+    bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) {
+        kf[kk] = *(const bf16x8*)(base + a.H + (long long)krow * ld + 16 * kk + 8 * hi);
+        vf[kk] = *(const bf16x8*)(base + 2 * a.H + (long long)krow * ld + 16 * kk + 8 * hi);
+    }
+    constexpr int NL = fa3_kv_lds_frags(HD), KKR = HD / 16 - NL;
+    char* vslot = smem + 2 * FA2_STAGE + wave * (NL * 1024) + lane * 16;
+    const unsigned vsl = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)vslot;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) *(bf16x8*)(vslot + j * 1024) = vf[KKR + j];   // (wave-private: no barrier; LDS executes a wave's operations in order)
+    f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    const float c = a.scale * 1.44269504088896341f;
+    // one 4-byte LDS-DMA instruction per step of wave 0 (the row log-sum-exps of queries R0 .. R0 + 31) and of wave 1 (their dO.O sums), lanes 0..31
+    const float* statp = wave == 0 ? Lu : Du;   // (uniform)
+#define BK3_EXTRA(ST, R0)                                                                                                  \
+    do {                                                                                                                   \
+        if (wave < 2 && lane < 32) {                                                                                       \
+            int qq = (R0) + lane;                                                                                          \
+            if (qq > a.S - 1) qq = a.S - 1;                                                                                \
+            __builtin_amdgcn_global_load_lds((fa_gvoid*)((const char*)statp + (unsigned)(4 * qq)), (fa_lvoid*)((ST) + 2 * FA_IMG + 128 * wave), 4, 0, 0); \
+        }                                                                                                                  \
+    } while (0)
+    const char* kwk = nullptr;   // (uniform) the tiles of this wave's key block, query block 0; a lane's key's word at + 4 (lane % 32)
+    unsigned kwv = 0u;
+    if constexpr (DROP) {
+        kwk = (const char*)(a.keepbits + ((long long)unit * a.nblk + (k0 >> 5)) * a.nblk * 32);
+        if (active) kwv = *(const uint32_t*)(kwk + (unsigned)(4 * q32));
+    }
+#define BK3_STEP(STG, T, Q0) fa3_bwdkv_step<HD, STG, T, MASK, DROP>(a, ln, Q0, kf, vf, dk, dv, c, krow, key_valid, lane, kwv, \
+                                                                    (DROP && (Q0) + 32 < a.S) ? kwk + (((Q0) >> 5) + 1) * 128 : nullptr, vsl)
+    FA3_LOOP(active, BK3_EXTRA, BK3_STEP)
+#undef BK3_STEP
+#undef BK3_EXTRA
+    if (!active || key >= a.S) return;
+    const long long obase = ((long long)sq * a.S + key) * ld + h * HD;
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = 32 * db + 8 * r4 + 4 * hi;
+            const bf16x4 kv = {f2bf(dk[db][4 * r4]), f2bf(dk[db][4 * r4 + 1]), f2bf(dk[db][4 * r4 + 2]), f2bf(dk[db][4 * r4 + 3])};
+            const float ds = DROP ? a.dscale : 1.0f;
+            const bf16x4 vv = {f2bf(dv[db][4 * r4] * ds), f2bf(dv[db][4 * r4 + 1] * ds), f2bf(dv[db][4 * r4 + 2] * ds), f2bf(dv[db][4 * r4 + 3] * ds)};
+            *(bf16x4*)(a.dqkv + obase + a.H + d) = kv;
+            *(bf16x4*)(a.dqkv + obase + 2 * a.H + d) = vv;
+        }
+}
+
 bool fattn_eligible(int dtype, int S, int H, int nh) {
     const char* e = measure_env_str("NBCI_FLASH_ATTN");   // (measurement builds; the NDT1 plan has its own switch, read at plan creation)
     const bool off = e && e[0] == '0';
@@ -955,6 +1365,7 @@ bool fattn_eligible(int dtype, int S, int H, int nh) {
 
 static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site) {
     NBCI_REQUIRE((long long)NS * nh * S * (long long)S < (1ll << 32), NBCI_ESHAPE, "flash attention: too large for the 32-bit dropout counter");
+    NBCI_REQUIRE((long long)S * 6 * H < (1ll << 32), NBCI_ESHAPE, "flash attention: one sequence of qkv rows must stay below 4 GB (32-bit staging offsets)");
     a.NS = NS; a.nh = nh; a.S = S; a.H = H;
     a.scale = 1.0f / sqrtf((float)(H / nh));
     a.thr = drop_threshold(drop_p);
@@ -963,17 +1374,69 @@ static int fa_args(FAArgs& a, int NS, int nh, int S, int H, float drop_p, uint32
     return NBCI_OK;
 }
 
+// keep-bit scratch of the 32 x 32-tile backward, one buffer per (device, stream), grown on demand, freed by nbci_release_scratch
+struct FaScratch { uint32_t* p; size_t bytes; };
+static std::mutex g_fa_mu;
+static std::map<std::pair<int, hipStream_t>, FaScratch> g_fa_scratch;
+static int fa_keepbits(hipStream_t stream, size_t bytes, uint32_t** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(NBCI_EHIP, "flash attention scratch: hipGetDevice");
+    std::lock_guard<std::mutex> lk(g_fa_mu);
+    const auto key = std::make_pair(dev, stream);
+    auto it = g_fa_scratch.find(key);
+    if (it != g_fa_scratch.end() && it->second.bytes >= bytes) { *out = it->second.p; return NBCI_OK; }
+    if (it != g_fa_scratch.end()) {   // an earlier launch on this stream may still be using the old buffer
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail(NBCI_EHIP, "flash attention scratch: sync");
+        (void)hipFree(it->second.p);
+        g_fa_scratch.erase(it);
+    }
+    FaScratch sc{nullptr, bytes};
+    if (hipMalloc((void**)&sc.p, bytes) != hipSuccess) return fail(NBCI_EHIP, "flash attention scratch: hipMalloc");
+    g_fa_scratch[key] = sc;
+    *out = sc.p;
+    return NBCI_OK;
+}
+int fattn_release() {
+    std::lock_guard<std::mutex> lk(g_fa_mu);
+    for (auto& kv : g_fa_scratch) (void)hipFree(kv.second.p);
+    g_fa_scratch.clear();
+    return NBCI_OK;
+}
+
 template <int HD, bool MASK>
-static int fa_launch(int which, const FAArgs& a, hipStream_t s) {
+static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
+    FAArgs a = a0;
     dim3 g(a.NS * a.nh, (a.S + 64 * NQ - 1) / (64 * NQ));
     static const int shared = measure_env("NBCI_FA_SHARED", 1);   // measurement: 0 = the wave-private streaming kernels above
     static const int tiles32 = measure_env("NBCI_FA_TILES32", 1);  // measurement: 0 = the 16 x 32 score-tile kernels
-    if (tiles32 && which == 0) {
-        if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
+    static const int tiles32b = measure_env("NBCI_FA_TILES32_BWD", 1);   // measurement: 0 = the 16 x 32 backward kernels
+    if (tiles32 && (which == 0 || (tiles32b && HD <= 96))) {
         const dim3 g3(a.NS * a.nh, (a.S + 127) / 128);
-        if (a.thr) hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
-        else hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
-        return check_launch("flash attention forward (32 x 32 tiles)");
+        if (which == 0) {
+            if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
+            if (a.thr) hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+            else hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+        } else if (which == 1) {
+            if (a.thr) {
+                a.nblk = (a.S + 31) / 32;
+                const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
+                if (rc != NBCI_OK) return rc;
+            }
+            if (prof_on()) prof_note_symbol("fattn3_bwd_q_kernel");
+            if (a.thr) hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+            else hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+        } else {
+            if (a.thr) {   // (the buffer the dq launch on this stream just filled)
+                a.nblk = (a.S + 31) / 32;
+                const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
+                if (rc != NBCI_OK) return rc;
+            }
+            if (prof_on()) prof_note_symbol("fattn3_bwd_kv_kernel");
+            constexpr int lds = 2 * FA2_STAGE + 4 * 1024 * fa3_kv_lds_frags(HD);
+            if (a.thr) hipLaunchKernelGGL((fattn3_bwd_kv_kernel<HD, MASK, true>), g3, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((fattn3_bwd_kv_kernel<HD, MASK, false>), g3, dim3(256), lds, s, a);
+        }
+        return check_launch("flash attention (32 x 32 tiles)");
     }
     if (shared && (HD < 128 || which == 0)) {   // the four waves of a workgroup share every streamed tile through LDS (two stages of two 8 KB images);
                                                   // head 128 backward: the shared dk/dv kernel spills (35 registers) and runs 27 % slower: wave-private kernels

@@ -179,6 +179,7 @@ int mx_quantize_launch(const void* x, int dtype, long long ldx, void* q, void* s
 int gemm_fp8_launch(const void* A8, const void* sA, const void* W8, const void* sW, const float* bias, void* C, int c_dtype, long long M, int N, int K,
                     long long ldc, hipStream_t s);
 bool fattn_eligible(int dtype, int S, int H, int nh);
+int fattn_release();                   // frees the per-stream keep-bit scratch of the streaming attention backward (nbci_release_scratch)
 // NDT1's masked attention (key validity + context span + self, ndt1.py:30-41,435-437) on the streaming kernels, any length;
 // the output dropout of ndt1.py:292 is fused into the forward's store (site_out)
 int fattn_masked_fwd_launch(const void* qkv, const int32_t* tmask, void* out, float* L, int NS, int nh, int S, int H, int cf, int cb,
