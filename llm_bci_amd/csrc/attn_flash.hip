@@ -13,9 +13,13 @@
 //     the transposed operand's rows are taken in the order pi(g, j) = {4g + j | 16 + 4g + (j - 4)}.
 // Dropout bits = the counter stream of the unfused softmax kernel (index ((unit*S + query)*S + key)): both paths and the
 // oracle draw identical masks.
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
@@ -51,6 +55,9 @@ __device__ __forceinline__ bool fa_ctx(int i, int j, int f, int bk) {   // creat
     if (f >= -1 && j - i > f) return false;
     if (bk >= -1 && i - j > bk) return false;
     return true;
+}
+__device__ __forceinline__ bool fa_ctx_nb(int i, int j, int f, int bk) {   // the same, without short-circuit control flow
+    return ((f < -1) | (j - i <= f)) & ((bk < -1) | (i - j <= bk));
 }
 // validity bits of keys k0 .. k0+31 of sequence `sq` (bit b = key k0 + b valid and inside the sequence)
 __device__ __forceinline__ unsigned fa_valid_bits(const FAArgs& a, int sq, int k0, int lane) {
@@ -980,12 +987,15 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
     unsigned vb = 0u;
     if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
     if constexpr (TAIL || MASK) {
+        // branch-free on purpose: with `if (!ok) s[r] = -INFINITY` under the short-circuit form hipcc (ROCm 7.2) hoisted the -inf into the new
+        // vector's register, then overwrote it with the whole-vector copy of the divergent element insert - the mask never applied
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kofs = 4 * hi + (r & 3) + 8 * (r >> 2), key = k0 + kofs;
             bool ok = !TAIL || key < a.S;
-            if constexpr (MASK) ok = ok && (key == qidx || (fa_ctx(qidx, key, a.cf, a.cb) && ((vb >> kofs) & 1u)));
-            if (!ok) s[r] = -INFINITY;
+            if constexpr (MASK) ok = ok & ((key == qidx) | (fa_ctx_nb(qidx, key, a.cf, a.cb) & (((vb >> kofs) & 1u) != 0u)));
+            const float sv = s[r];
+            s[r] = ok ? sv : -INFINITY;
         }
     }
     float cm = fmaxf(s[0], s[1]);
@@ -1112,7 +1122,7 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
             const int r = 4 * r4 + e, kofs = 8 * r4 + 4 * hi + e, key = k0 + kofs;
             float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L2));
             bool ok = !TAIL || key < a.S;
-            if constexpr (MASK) ok = ok && (key == qidx || (fa_ctx(qidx, key, a.cf, a.cb) && ((vb >> kofs) & 1u)));
+            if constexpr (MASK) ok = ok & ((key == qidx) | (fa_ctx_nb(qidx, key, a.cf, a.cb) & (((vb >> kofs) & 1u) != 0u)));
             if (TAIL || MASK) p = ok ? p : 0.f;
             float t = dp[r];
             if constexpr (DROP) {
@@ -1256,7 +1266,7 @@ __device__ __forceinline__ void fa3_bwdkv_step(const FAArgs& a, const Fa3Lane<HD
             const int r = 4 * r4 + e, q = q0 + 8 * r4 + 4 * hi + e;
             float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, -1.44269504088896341f * Lv[e]));
             bool ok = !TAIL || q < a.S;
-            if constexpr (MASK) ok = ok && (q == krow || (fa_ctx(q, krow, a.cf, a.cb) && key_valid));
+            if constexpr (MASK) ok = ok & ((q == krow) | (fa_ctx_nb(q, krow, a.cf, a.cb) & key_valid));
             if (TAIL || MASK) p = ok ? p : 0.f;
             float t = dpt[r], pk = p;
             if constexpr (DROP) {   // all-ones / zero from the query's bit; 1 / (1 - p) reaches dV at the end
@@ -1403,6 +1413,8 @@ int fattn_release() {
     return NBCI_OK;
 }
 
+static int g_fa_force16 = 0;   // (measurement: fa_dispatch's comparison run)
+
 template <int HD, bool MASK>
 static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     FAArgs a = a0;
@@ -1410,7 +1422,7 @@ static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     static const int shared = measure_env("NBCI_FA_SHARED", 1);   // measurement: 0 = the wave-private streaming kernels above
     static const int tiles32 = measure_env("NBCI_FA_TILES32", 1);  // measurement: 0 = the 16 x 32 score-tile kernels
     static const int tiles32b = measure_env("NBCI_FA_TILES32_BWD", 1);   // measurement: 0 = the 16 x 32 backward kernels
-    if (tiles32 && (which == 0 || (tiles32b && HD <= 96))) {
+    if (tiles32 && !g_fa_force16 && (which == 0 || (tiles32b && HD <= 96))) {
         const dim3 g3(a.NS * a.nh, (a.S + 127) / 128);
         if (which == 0) {
             if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
@@ -1477,7 +1489,7 @@ static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     return check_launch("flash attention");
 }
 
-static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
+static int fa_dispatch_raw(int which, const FAArgs& a, hipStream_t s) {
     if (a.tmask) {
         switch (a.H / a.nh) {
             case 32: return fa_launch<32, true>(which, a, s);
@@ -1492,6 +1504,59 @@ static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
         case 96: return fa_launch<96, false>(which, a, s);
         default: return fa_launch<128, false>(which, a, s);
     }
+}
+
+#ifdef NBCI_MEASURE
+static void fa_checksum(const char* what, const FAArgs& a, hipStream_t s) {
+    const size_t no = (size_t)a.NS * a.S * a.H, nl = (size_t)a.NS * a.nh * a.S, nq = 3 * no;
+    (void)hipStreamSynchronize(s);
+    std::vector<uint16_t> h(no), q(nq);
+    std::vector<uint32_t> L(nl);
+    (void)hipMemcpy(h.data(), a.out, no * 2, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(q.data(), a.qkv, nq * 2, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(L.data(), a.L, nl * 4, hipMemcpyDeviceToHost);
+    uint64_t co = 0, cl = 0, cq = 0;
+    for (size_t i = 0; i < no; ++i) co = co * 1315423911ull + h[i];
+    for (size_t i = 0; i < nq; ++i) cq = cq * 1315423911ull + q[i];
+    for (size_t i = 0; i < nl; ++i) cl = cl * 1315423911ull + L[i];
+    fprintf(stderr, "[fa_sum] %s NS %d S %d H %d out@%p %016llx lse@%p %016llx qkv %016llx\n", what, a.NS, a.S, a.H, (void*)a.out, (unsigned long long)co, (void*)a.L,
+            (unsigned long long)cl, (unsigned long long)cq);
+}
+#endif
+
+static int fa_dispatch(int which, const FAArgs& a, hipStream_t s) {
+#ifdef NBCI_MEASURE
+    if (measure_env("NBCI_FA_CHECK", 0) && which == 1) fa_checksum("bwd", a, s);
+    // NBCI_FA_CHECK=1 (measurement builds): every forward also runs the 16 x 32-tile kernels into scratch and reports the largest differences
+    static const int chk = measure_env("NBCI_FA_CHECK", 0);
+    if (chk && which == 0) {
+        const size_t no = (size_t)a.NS * a.S * a.H, nl = (size_t)a.NS * a.nh * a.S;
+        bf16_t* o2 = nullptr; float* l2 = nullptr;
+        if (hipMalloc((void**)&o2, no * 2) != hipSuccess || hipMalloc((void**)&l2, nl * 4) != hipSuccess) return fail(NBCI_EHIP, "fa check: hipMalloc");
+        FAArgs b = a; b.out = o2; b.L = l2;
+        g_fa_force16 = chk == 2 ? 0 : 1;   // (2: the other way round - the 32 x 32 kernel writes the scratch, the 16 x 32 one the real buffers)
+        int rc = fa_dispatch_raw(0, b, s);
+        g_fa_force16 = chk == 2 ? 1 : 0;
+        if (rc == NBCI_OK) rc = fa_dispatch_raw(0, a, s);
+        g_fa_force16 = 0;
+        (void)hipStreamSynchronize(s);
+        std::vector<uint16_t> h1(no), h2(no);
+        std::vector<float> L1(nl), L2(nl);
+        (void)hipMemcpy(h1.data(), a.out, no * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(h2.data(), o2, no * 2, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(L1.data(), a.L, nl * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(L2.data(), l2, nl * 4, hipMemcpyDeviceToHost);
+        auto f = [](uint16_t v) { uint32_t u = (uint32_t)v << 16; float x; memcpy(&x, &u, 4); return x; };
+        double mo = 0, ml = 0, so = 0, sr = 0; size_t wo = 0, wl = 0, nbad = 0;
+        for (size_t i = 0; i < no; ++i) { const double d = fabs((double)f(h1[i]) - f(h2[i])); so += d; sr += fabs((double)f(h2[i])); if (d > mo) { mo = d; wo = i; } if (d > 0.02 * (fabs((double)f(h2[i])) + 0.01)) ++nbad; }
+        for (size_t i = 0; i < nl; ++i) { const double d = fabs((double)L1[i] - L2[i]); if (d > ml) { ml = d; wl = i; } }
+        fprintf(stderr, "[fa_check] NS %d nh %d S %d H %d mask %d thr %u thr_out %u cf %d cb %d: out l1rel %.3e, %zu elements off by > 2 %%, max diff %.3e at row %zu col %zu (%g vs %g); lse max diff %.3e at unit %zu query %zu (%g vs %g)\n",
+                a.NS, a.nh, a.S, a.H, a.tmask != nullptr, a.thr, a.thr_out, a.cf, a.cb, so / (sr + 1e-30), nbad, mo, wo / a.H, wo % a.H, f(h1[wo]), f(h2[wo]), ml, wl / a.S, wl % a.S,
+                L1[wl], L2[wl]);
+        (void)hipFree(o2); (void)hipFree(l2);
+        fa_checksum("fwd", a, s);
+        return rc;
+    }
+#endif
+    return fa_dispatch_raw(which, a, s);
 }
 
 int fattn_fwd_launch(const void* qkv, void* out, float* L, int NS, int nh, int S, int H, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {

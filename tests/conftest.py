@@ -42,6 +42,9 @@ def measured(tag, value, bound=None):
         bound = 0.1 if (os.environ.get("NBCI_BF16_PROVISIONAL") and tag not in BF16_BOUNDS) else BF16_BOUNDS[tag]
     e = _MEASURED.setdefault(tag, [0.0, bound, 0])
     e[0] = max(e[0], value); e[1] = bound; e[2] += 1
+    if os.environ.get("NBCI_BF16_MEASURE"):   # a measuring run after a kernel change: record, assert only a gross 0.25 (the output feeds make_bf16_bounds.py)
+        assert value <= 0.25, (tag, value)
+        return value
     assert value <= bound, (tag, value, bound)
     return value
 

@@ -10,10 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llm_bci_amd._lib import check, lib  # noqa: E402
 
 NS, nh, S, H = (int(x) for x in sys.argv[1:5])
+SCALE = float(sys.argv[5]) if len(sys.argv) > 5 else 0.7   # standard deviation of q, k, v
+MEAN = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 hd = H // nh
 dev = "cuda"
 torch.manual_seed(0)
-qkv = (torch.randn(NS * S, 3 * H, device=dev) * 0.7).bfloat16()
+qkv = (torch.randn(NS * S, 3 * H, device=dev) * SCALE + MEAN).bfloat16()
 dout = torch.randn(NS * S, H, device=dev).bfloat16()
 out = torch.empty(NS * S, H, dtype=torch.bfloat16, device=dev)
 lse = torch.empty(NS * nh * S, device=dev); dsum = torch.empty_like(lse); dqkv = torch.zeros_like(qkv)
@@ -38,7 +40,7 @@ def err(a, b):
     return f"max {float((a - b).abs().max()):.3e}  l1rel {float((a - b).abs().sum() / b.abs().sum()):.3e}"
 
 
-print(f"NS={NS} nh={nh} S={S} H={H} (head {hd}): out {err(out.float(), o2.detach())} | lse {err(lse.view(NS, nh, S), ref_l.detach())}")
+print(f"NS={NS} nh={nh} S={S} H={H} (head {hd}) std {SCALE} mean {MEAN}: out {err(out.float(), o2.detach())} | lse {err(lse.view(NS, nh, S), ref_l.detach())}")
 for i, n in enumerate("qkv"):
     print(f"    d{n}: {err(dqkv.float()[:, i * H:(i + 1) * H], gref[:, i * H:(i + 1) * H])}")
 print(f"    finite: out {bool(torch.isfinite(out.float()).all())} dqkv {bool(torch.isfinite(dqkv.float()).all())}", flush=True)

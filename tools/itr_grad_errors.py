@@ -19,8 +19,12 @@ res = {}
 for dt in ("fp32", "bf16"):
     m = _model(fx, dtype=dt, **({"residual_dtype": streams} if dt == "bf16" else {})).to("cuda")
     m.mask_override = torch.from_numpy(fx["raw_mask_step0"])
-    res[dt] = _grads_of(m, batch)[2]
+    loss, preds, res[dt] = _grads_of(m, batch)
+    res[dt]["__preds"] = preds.float().cpu().numpy()
+    res[dt]["__loss"] = np.asarray(loss.float().cpu().numpy())
 rows = sorted(((np.abs(res["bf16"][k] - res["fp32"][k]).sum() / (np.abs(res["fp32"][k]).sum() + 1e-6), k, res["fp32"][k].size,
                float(np.abs(res["fp32"][k]).sum())) for k in res["fp32"]), reverse=True)
 for r in rows[:8]:
     print(f"{r[0]:.4f}  {r[1]}  n={r[2]}  sum|g|={r[3]:.3e}")
+if len(sys.argv) > 3:   # save both gradient sets for an offline diff of two runs
+    np.savez(sys.argv[3], **{"bf16:" + k: v for k, v in res["bf16"].items()}, **{"fp32:" + k: v for k, v in res["fp32"].items()})
