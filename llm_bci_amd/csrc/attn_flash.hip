@@ -88,31 +88,22 @@ __device__ __forceinline__ bf16x8 fa_pack(const f32x4& lo, const f32x4& hi) {
     return o;
 }
 
-// keep multipliers (scale or 0) for the 4 consecutive dropout counters idx0 .. idx0+3 (any parity): the counters pair up
-// two to a 32-bit hash (nbci_common.h drop_pair), so 3 hashes cover them instead of 4 element-wise drop_keep calls
-__device__ __forceinline__ void fa_keep4(uint32_t key, uint32_t thr, uint32_t idx0, float scale, float (&k)[4]) {
-    const uint32_t p0 = idx0 >> 1;
-    const uint32_t h0 = mix32(p0 ^ key), h1 = mix32((p0 + 1u) ^ key), h2 = mix32((p0 + 2u) ^ key);
-    const bool odd = (idx0 & 1u) != 0u;
-    const uint32_t hb = odd ? h1 : h0, hd = odd ? h2 : h1;
-    const uint32_t e0 = odd ? (h0 >> 16) : (h0 & 0xFFFFu);
-    const uint32_t e1 = odd ? (hb & 0xFFFFu) : (hb >> 16);
-    const uint32_t e2 = odd ? (h1 >> 16) : (h1 & 0xFFFFu);
-    const uint32_t e3 = odd ? (hd & 0xFFFFu) : (hd >> 16);
-    k[0] = e0 >= thr ? scale : 0.f; k[1] = e1 >= thr ? scale : 0.f; k[2] = e2 >= thr ? scale : 0.f; k[3] = e3 >= thr ? scale : 0.f;
-}
-
-// the same four draws as fa_keep4, as booleans
+// the keep decisions of the 4 consecutive dropout counters idx0 .. idx0+3 (any parity): the counters pair up two to a 32-bit hash (nbci_common.h
+// drop_pair), so 3 hashes cover them instead of 4 element-wise drop_keep calls. The four 16-bit draws are the 64-bit window at half-word offset
+// (idx0 & 1) of h0 | h1 | h2: two funnel shifts; a high half is compared in place (hi >= thr <=> word >= thr << 16).
 __device__ __forceinline__ void fa_keep4_bits(uint32_t key, uint32_t thr, uint32_t idx0, bool (&k)[4]) {
     const uint32_t p0 = idx0 >> 1;
     const uint32_t h0 = mix32(p0 ^ key), h1 = mix32((p0 + 1u) ^ key), h2 = mix32((p0 + 2u) ^ key);
-    const bool odd = (idx0 & 1u) != 0u;
-    const uint32_t hb = odd ? h1 : h0, hd = odd ? h2 : h1;
-    const uint32_t e0 = odd ? (h0 >> 16) : (h0 & 0xFFFFu);
-    const uint32_t e1 = odd ? (hb & 0xFFFFu) : (hb >> 16);
-    const uint32_t e2 = odd ? (h1 >> 16) : (h1 & 0xFFFFu);
-    const uint32_t e3 = odd ? (hd & 0xFFFFu) : (hd >> 16);
-    k[0] = e0 >= thr; k[1] = e1 >= thr; k[2] = e2 >= thr; k[3] = e3 >= thr;
+    const uint32_t sh = (idx0 & 1u) << 4;
+    const uint32_t w0 = __builtin_amdgcn_alignbit(h1, h0, sh), w1 = __builtin_amdgcn_alignbit(h2, h1, sh);
+    const uint32_t thr_hi = thr << 16;
+    k[0] = (w0 & 0xFFFFu) >= thr; k[1] = w0 >= thr_hi; k[2] = (w1 & 0xFFFFu) >= thr; k[3] = w1 >= thr_hi;
+}
+// ... as multipliers (scale or 0)
+__device__ __forceinline__ void fa_keep4(uint32_t key, uint32_t thr, uint32_t idx0, float scale, float (&k)[4]) {
+    bool b[4];
+    fa_keep4_bits(key, thr, idx0, b);
+    k[0] = b[0] ? scale : 0.f; k[1] = b[1] ? scale : 0.f; k[2] = b[2] ? scale : 0.f; k[3] = b[3] ? scale : 0.f;
 }
 
 // One step's operands: two row-fragment sets (16 rows x 32 k per (t, ks); lane = row i16, 16-byte chunk g) of two strided
