@@ -810,6 +810,7 @@ __global__ __launch_bounds__(256, (NQ == 1 && HD <= 96) ? 2 : 1) void fattn2_bwd
 //     stages became a loop-invariant register: ~90 VGPRs, spills in the dk/dv kernel at head 96.);
 //   * the staging pointers advance by 32 rows per step (Fa3Stager); only the one ragged stage at the end of the sequence is clamped.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ float fa3_swap32(float x) {   // the value the lane 32 away holds
 #if __has_builtin(__builtin_amdgcn_permlane32_swap)
@@ -854,6 +855,19 @@ __device__ __forceinline__ bf16x8 fa3_pack8(const f32x16& s, int o) {
     const bf16x8 r = {f2bf(s[o]), f2bf(s[o + 1]), f2bf(s[o + 2]), f2bf(s[o + 3]), f2bf(s[o + 4]), f2bf(s[o + 5]), f2bf(s[o + 6]), f2bf(s[o + 7])};
     return r;
 }
+
+// Workgroup -> (unit = sequence x head, block of 128 stationary rows). Every workgroup of a unit streams that unit's whole other axis (576 KB of K / V at
+// 1501 tokens x head 96), so the workgroups of one unit must run on ONE XCD at about the same time for its 4 MB L2 to serve all but the first read:
+// the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so XCD x = id % 8 takes the units x, x + 8, .. and walks each unit's blocks
+// consecutively. (With id = block x units + unit the 512 resident workgroups touched every unit at once - 9 MB per XCD - and the forward ran at the
+// 5.2 TB/s the fabric behind the L2 delivers: 885 MB per launch at 1501 x 96 x 128 units.) Returns false for the few ids past the last unit.
+__device__ __forceinline__ bool fa3_unit_block(int nunits, int nblocks, int& unit, int& blk) {
+    const int id = blockIdx.x, x = id & 7, j = id >> 3;
+    unit = x + 8 * (j / nblocks);
+    blk = j % nblocks;
+    return unit < nunits;
+}
+__host__ inline int fa3_grid(int nunits, int nblocks) { return 8 * ((nunits + 7) / 8) * nblocks; }
 
 template <int HD> struct Fa3Lane {
     unsigned row0;             // row fragment 0 (16 bytes: columns 8 hi ..) of row lane % 32 of an image; fragment kk (columns 16 kk + 8 hi ..) = row0 ^ (kk << 5):
@@ -989,9 +1003,12 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
             s[r] = ok ? sv : -INFINITY;
         }
     }
-    float cm = fmaxf(s[0], s[1]);
+    // (asm: through fmaxf hipcc first canonicalises every MFMA result - v_max_f32 x, x - before the v_max3_f32; the scores are never signalling NaNs)
+    float cm;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) cm = fmaxf(fmaxf(cm, s[r]), s[r + 1]);   // (v_max3_f32)
+    for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(cm), "v"(s[r]), "v"(s[r + 1]));
+    cm = fmaxf(cm, s[15]);
     cm = fmaxf(cm, fa3_swap32(cm));
     if (__builtin_amdgcn_ballot_w64(cm > m) != 0ull) {   // some row's maximum moved (wave-uniform; rare after the first steps)
         const float mn = fmaxf(m, cm);
@@ -1004,19 +1021,20 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
             for (int r = 0; r < 16; ++r) o[db][r] *= corr;
     }
     const float mc = (MASK && m == -INFINITY) ? 0.f : m * c;   // (all of this row's scores are -inf so far: exp2(-inf - 0) = 0)
-    float ps = 0.f;
+    f32x2 ps2 = {0.f, 0.f};   // (two running sums: v_pk_add_f32)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
-        float keep[4] = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (DROP) fa_keep4(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), 1.0f, keep);
+        bool keep[4] = {true, true, true, true};
+        if constexpr (DROP) fa_keep4_bits(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), keep);
+        float p[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * r4 + e], c, -mc));
-            ps += p;
-            s[4 * r4 + e] = DROP ? p * keep[e] : p;
-        }
+        for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * r4 + e], c, -mc));
+        ps2 += (f32x2){p[0], p[1]};
+        ps2 += (f32x2){p[2], p[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * r4 + e] = (DROP && !keep[e]) ? 0.f : p[e];
     }
-    l += ps;
+    l += ps2[0] + ps2[1];
     const bf16x8 p0 = fa3_pack8(s, 0), p1 = fa3_pack8(s, 8);
 #pragma unroll
     for (int db = 0; db < HD / 32; ++db) {
@@ -1029,15 +1047,17 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
 }
 
 #ifndef FA3_W96
-#define FA3_W96 2
+#define FA3_W96 3   // head 96 forward: three waves per SIMD (168 registers): 171 -> 164 us without, 262 -> 239 us with dropout at 16 x 8 x 1501 x 96
 #endif
 template <int HD, bool MASK, bool DROP>
 __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fattn3_fwd_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q32 = lane & 31, hi = lane >> 5;
-    const int q0 = (blockIdx.y * 4 + wave) * 32;
-    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    int unit, blk;
+    if (!fa3_unit_block(a.NS * a.nh, (a.S + 127) / 128, unit, blk)) return;
+    const int q0 = (blk * 4 + wave) * 32;
+    const int sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
     const bool active = q0 < a.S;   // a wave past the end of the sequence: its share of the loads and the barriers, nothing else
@@ -1147,8 +1167,10 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAA
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q32 = lane & 31, hi = lane >> 5;
-    const int q0 = (blockIdx.y * 4 + wave) * 32;
-    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    int unit, blk;
+    if (!fa3_unit_block(a.NS * a.nh, (a.S + 127) / 128, unit, blk)) return;
+    const int q0 = (blk * 4 + wave) * 32;
+    const int sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
     const bool active = q0 < a.S;
@@ -1289,8 +1311,10 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_kv_kernel(FA
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q32 = lane & 31, hi = lane >> 5;
-    const int k0 = (blockIdx.y * 4 + wave) * 32;
-    const int unit = blockIdx.x, sq = unit / a.nh, h = unit % a.nh;
+    int unit, blk;
+    if (!fa3_unit_block(a.NS * a.nh, (a.S + 127) / 128, unit, blk)) return;
+    const int k0 = (blk * 4 + wave) * 32;
+    const int sq = unit / a.nh, h = unit % a.nh;
     const long long ld = 3LL * a.H;
     const bf16_t* base = a.qkv + (long long)sq * a.S * ld + h * HD;
     const bf16_t* dob = a.dout + (long long)sq * a.S * a.H + h * HD;
@@ -1414,7 +1438,7 @@ static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     static const int tiles32 = measure_env("NBCI_FA_TILES32", 1);  // measurement: 0 = the 16 x 32 score-tile kernels
     static const int tiles32b = measure_env("NBCI_FA_TILES32_BWD", 1);   // measurement: 0 = the 16 x 32 backward kernels
     if (tiles32 && !g_fa_force16 && (which == 0 || (tiles32b && HD <= 96))) {
-        const dim3 g3(a.NS * a.nh, (a.S + 127) / 128);
+        const dim3 g3(fa3_grid(a.NS * a.nh, (a.S + 127) / 128));
         if (which == 0) {
             if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
             if (a.thr) hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);

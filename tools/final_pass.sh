@@ -19,3 +19,13 @@ PY
 timeout -k 10 300 python tools/ab_side_stream.py --batches 8 16 32 64 > gpurun_out/final/side_stream_ab.txt 2>&1; grep -v amdgpu gpurun_out/final/side_stream_ab.txt
 timeout -k 10 1100 bash tools/profile_step.sh final/prof > gpurun_out/final/profile.log 2>&1 || { tail -20 gpurun_out/final/profile.log; exit 1; }
 tail -12 gpurun_out/final/profile.log
+# the two secondary models: step time + per-kernel rocprofv3 stats
+( cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && \
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/itr -o t -- python3 $R/tools/bench_itr.py --channels 1500 --steps 5 > $R/gpurun_out/final/itr_n1500.log 2>&1 && \
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/ptst -o t -- python3 $R/tools/bench_ptst.py --steps 3 > $R/gpurun_out/final/ptst_c5.log 2>&1 )
+python3 tools/db_stats.py "$(find gpurun_out/final/itr -name '*.db' | head -1)" > gpurun_out/final/itr_n1500_kernel_stats.csv
+python3 tools/db_stats.py "$(find gpurun_out/final/ptst -name '*.db' | head -1)" > gpurun_out/final/ptst_c5_kernel_stats.csv
+rm -rf gpurun_out/final/itr gpurun_out/final/ptst
+for n in 1500 668; do timeout -k 10 200 python tools/bench_itr.py --channels $n 2>&1 | grep -v amdgpu; done | tee gpurun_out/final/itr_steps.txt
+timeout -k 10 200 python tools/bench_ptst.py 2>&1 | grep -v amdgpu | tee gpurun_out/final/ptst_step.txt
+head -8 gpurun_out/final/itr_n1500_kernel_stats.csv
