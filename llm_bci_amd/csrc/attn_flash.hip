@@ -1437,7 +1437,8 @@ static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     static const int shared = measure_env("NBCI_FA_SHARED", 1);   // measurement: 0 = the wave-private streaming kernels above
     static const int tiles32 = measure_env("NBCI_FA_TILES32", 1);  // measurement: 0 = the 16 x 32 score-tile kernels
     static const int tiles32b = measure_env("NBCI_FA_TILES32_BWD", 1);   // measurement: 0 = the 16 x 32 backward kernels
-    if (tiles32 && !g_fa_force16 && (which == 0 || (tiles32b && HD <= 96))) {
+    // (head 128: the backward kernels take 316 - 416 registers, one wave per SIMD, and still beat the 16 x 32 pair: 1119 -> 730 us at 64 x 8 x 593 x 128)
+    if (tiles32 && !g_fa_force16 && (which == 0 || tiles32b)) {
         const dim3 g3(fa3_grid(a.NS * a.nh, (a.S + 127) / 128));
         if (which == 0) {
             if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
