@@ -869,6 +869,13 @@ __device__ __forceinline__ bool fa3_unit_block(int nunits, int nblocks, int& uni
 }
 __host__ inline int fa3_grid(int nunits, int nblocks) { return 8 * ((nunits + 7) / 8) * nblocks; }
 
+#ifndef FA3_SSTORE
+#define FA3_SSTORE 1   // the dq kernel writes the keep words with scalar stores (0: v_writelane + one vector store)
+#endif
+// dword slot of key k (0..31) inside a tile's 32 keep words: the dq kernel's compare for register 4 r4 + e yields the words of keys 8 r4 + e and 8 r4 + 4 + e
+// as one 64-bit lane mask, stored as one unit
+__device__ __forceinline__ int fa3_kslot(int k) { return 2 * (4 * (k >> 3) + (k & 3)) + ((k >> 2) & 1); }
+
 template <int HD> struct Fa3Lane {
     unsigned row0;             // row fragment 0 (16 bytes: columns 8 hi ..) of row lane % 32 of an image; fragment kk (columns 16 kk + 8 hi ..) = row0 ^ (kk << 5):
                                // the chunk index 2 kk + hi meets the swizzle by XOR and stays below 16
@@ -1123,7 +1130,8 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
     fa3_read_t<HD, XI>(kt, ln, 0);
     unsigned vb = 0u;
     if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
-    unsigned kword = 0u;   // DROP: lane k < 32 collects the word of key k0 + k (bit q = query q of this wave keeps it)
+    unsigned kword = 0u;   // DROP, FA3_SSTORE == 0: lane k < 32 collects the word of key k0 + k (bit q = query q of this wave keeps it)
+    uint64_t kb[16];       // DROP, FA3_SSTORE == 1: the compares' lane masks: kb[4 r4 + e] = words of keys 8 r4 + e (low half) and 8 r4 + 4 + e (high half)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         bool keep[4] = {true, true, true, true};
@@ -1140,16 +1148,33 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
                 t = keep[e] ? t * a.dscale : 0.f;
                 // the compare's lane mask IS the pair of words of keys 8 r4 + e (lanes 0..31 = the 32 queries) and 8 r4 + 4 + e (lanes 32..63)
                 const uint64_t b = __builtin_amdgcn_ballot_w64(keep[e]);
+#if FA3_SSTORE
+                kb[r] = b;
+#else
                 // (s_nop: a VALU-written SGPR is not safe to read in the very next v_writelane - hipcc's hazard recognizer does not look into asm;
                 // without it a few keys per tile carried the previous compare's bits)
                 asm("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
                     : "+v"(kword) : "s"((unsigned)b), "s"((unsigned)(b >> 32)), "n"(8 * r4 + e), "n"(8 * r4 + 4 + e));
+#endif
             }
             s[r] = p * (t - D);   // dS / scale (the scale goes into the output)
         }
     }
     if constexpr (DROP) {
-        if (lane < 32) kw[lane] = kword;
+#if FA3_SSTORE
+        // the 16 lane masks ARE the tile's 32 words: sixteen scalar 8-byte stores, no vector instruction (slot 2 (4 r4 + e) + half; fa3_kslot is the
+        // reader's side). One s_nop for the last compare -> first store distance; the kernel ends with s_dcache_wb.
+        asm volatile("s_nop 4\n\t"
+                     "s_store_dwordx2 %0, %16, 0x0\n\ts_store_dwordx2 %1, %16, 0x8\n\ts_store_dwordx2 %2, %16, 0x10\n\ts_store_dwordx2 %3, %16, 0x18\n\t"
+                     "s_store_dwordx2 %4, %16, 0x20\n\ts_store_dwordx2 %5, %16, 0x28\n\ts_store_dwordx2 %6, %16, 0x30\n\ts_store_dwordx2 %7, %16, 0x38\n\t"
+                     "s_store_dwordx2 %8, %16, 0x40\n\ts_store_dwordx2 %9, %16, 0x48\n\ts_store_dwordx2 %10, %16, 0x50\n\ts_store_dwordx2 %11, %16, 0x58\n\t"
+                     "s_store_dwordx2 %12, %16, 0x60\n\ts_store_dwordx2 %13, %16, 0x68\n\ts_store_dwordx2 %14, %16, 0x70\n\ts_store_dwordx2 %15, %16, 0x78"
+                     :: "s"(kb[0]), "s"(kb[1]), "s"(kb[2]), "s"(kb[3]), "s"(kb[4]), "s"(kb[5]), "s"(kb[6]), "s"(kb[7]), "s"(kb[8]), "s"(kb[9]), "s"(kb[10]),
+                        "s"(kb[11]), "s"(kb[12]), "s"(kb[13]), "s"(kb[14]), "s"(kb[15]), "s"(kw)
+                     : "memory");
+#else
+        if (lane < 32) kw[fa3_kslot(lane)] = kword;
+#endif
     }
     const bf16x8 d0 = fa3_pack8(s, 0), d1 = fa3_pack8(s, 8);
 #pragma unroll
@@ -1208,6 +1233,9 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAA
 #define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32)
     FA3_LOOP(active, FA3_NOEXTRA, BQ3_STEP)
 #undef BQ3_STEP
+#if FA3_SSTORE
+    if constexpr (DROP) asm volatile("s_dcache_wb" ::: "memory");   // the scalar stores of the keep words leave the scalar data cache
+#endif
     if (!active || query >= a.S) return;
     const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
 #pragma unroll
@@ -1235,7 +1263,7 @@ __device__ __forceinline__ void fa3_bwdkv_step(const FAArgs& a, const Fa3Lane<HD
     const int hi = lane >> 5;
     // DROP: kwv = the keep word of this lane's key for this step's 32 queries (bit q), fetched one step ahead; a lane's queries are {8 r4 + 4 hi + e}
     unsigned kwn = 0u;
-    if constexpr (DROP) { if (kw_next) kwn = *(const uint32_t*)(kw_next + (unsigned)(4 * (lane & 31))); }   // (kw_next is wave-uniform)
+    if constexpr (DROP) { if (kw_next) kwn = *(const uint32_t*)(kw_next + (unsigned)(4 * fa3_kslot(lane & 31))); }   // (kw_next is wave-uniform)
     const unsigned kws = kwv >> (4 * hi);
     // register budget (head 96: 144 stationary + 32 scores at two waves per SIMD): the dO rows take the Q rows' registers once S is issued, the row
     // statistics arrive four queries at a time, one group ahead of their use
@@ -1359,7 +1387,7 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_kv_kernel(FA
     unsigned kwv = 0u;
     if constexpr (DROP) {
         kwk = (const char*)(a.keepbits + ((long long)unit * a.nblk + (k0 >> 5)) * a.nblk * 32);
-        if (active) kwv = *(const uint32_t*)(kwk + (unsigned)(4 * q32));
+        if (active) kwv = *(const uint32_t*)(kwk + (unsigned)(4 * fa3_kslot(q32)));
     }
 #define BK3_STEP(STG, T, Q0) fa3_bwdkv_step<HD, STG, T, MASK, DROP>(a, ln, Q0, kf, vf, dk, dv, c, krow, key_valid, lane, kwv, \
                                                                     (DROP && (Q0) + 32 < a.S) ? kwk + (((Q0) >> 5) + 1) * 128 : nullptr, vsl)
