@@ -912,6 +912,8 @@ template <int HD> struct Fa3Stager {
     const char* y0;
     unsigned px, py;    // row pitches in bytes
     unsigned xo[2], yo[2];
+    bool live[2];       // this lane's 16-byte slot of piece j holds a chunk of the head (heads below 128 fill 4 / 8 / 12 of a row's 16 slots): the other lanes
+                        // sit the LDS-DMA out (EXEC) instead of fetching filler - at head 32 that was 3/4 of the L2 -> LDS traffic (3.7 GB per launch at PatchTST's shape)
     __device__ __forceinline__ void init(const bf16_t* xp, long long ldx, const bf16_t* yp, long long ldy, int w, int lane) {
         xb = x0 = (const char*)xp; yb = y0 = (const char*)yp;
         px = (unsigned)(2 * ldx); py = (unsigned)(2 * ldy);
@@ -920,12 +922,15 @@ template <int HD> struct Fa3Stager {
             const int r = 4 * (w + 4 * j) + (lane >> 4);
             xo[j] = (unsigned)r * px + chunk_bytes(r, lane);
             yo[j] = (unsigned)r * py + chunk_bytes(r, lane);
+            live[j] = chunk_of(r, lane) < HD / 8;
         }
     }
+    static __device__ __forceinline__ int chunk_of(int r, int lane) {   // the chunk whose home is this lane's 16-byte slot (fa_off is an involution per row)
+        return (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    }
     static __device__ __forceinline__ unsigned chunk_bytes(int r, int lane) {
-        int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));   // the chunk whose home is this 16-byte slot (fa_off is an involution per row)
-        if (ch >= HD / 8) ch = 0;                                    // (slots no fragment read touches: any valid address)
-        return (unsigned)ch * 16u;
+        const int ch = chunk_of(r, lane);
+        return (unsigned)(ch < HD / 8 ? ch : 0) * 16u;
     }
     // CLAMP: rows past the end of the sequence read row S - 1 (they only ever meet zero probabilities); r0 = first row of the step being staged
     template <bool CLAMP> __device__ __forceinline__ void issue(char* stage, int w, int lane, int r0, int S) {
@@ -943,8 +948,10 @@ template <int HD> struct Fa3Stager {
                 xs = xb + xo[j];
                 ys = yb + yo[j];
             }
-            __builtin_amdgcn_global_load_lds((fa_gvoid*)xs, (fa_lvoid*)(stage + (w + 4 * j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((fa_gvoid*)ys, (fa_lvoid*)(stage + FA_IMG + (w + 4 * j) * 1024), 16, 0, 0);
+            if (HD == 128 || live[j]) {
+                __builtin_amdgcn_global_load_lds((fa_gvoid*)xs, (fa_lvoid*)(stage + (w + 4 * j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((fa_gvoid*)ys, (fa_lvoid*)(stage + FA_IMG + (w + 4 * j) * 1024), 16, 0, 0);
+            }
         }
         xb += 32u * px; yb += 32u * py;
     }
