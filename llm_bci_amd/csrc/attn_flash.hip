@@ -44,6 +44,9 @@ struct FAArgs {
     // 32 x 32-tile backward with dropout: the dq kernel leaves the keep bits of every (32 queries x 32 keys) tile here for the dk/dv kernel:
     // 32 words per tile, tile (unit, key block kb, query block qb) at ((unit * nblk + kb) * nblk + qb) * 32; word k = key k, bit q = query q kept
     uint32_t* keepbits; int nblk;
+    // When the FORWARD of this layer ran with dropout it left the same words in a buffer kept per lse pointer (fa_layer_bits): the backward's dq kernel then
+    // takes its lane masks from there (kw_in = 1: no hash, no stores) and the dk/dv kernel reads the same buffer.
+    int kw_in;
     // MASK kernels (NDT1: models/ndt1.py:30-41,435-437): key j is visible to query i iff j == i, or the context span allows
     // (i, j) AND token j is valid. tmask (NS, S) int32; cf / cb = context.forward / backward (-2 = unbounded).
     const int32_t* tmask; int cf, cb;
@@ -872,6 +875,17 @@ __host__ inline int fa3_grid(int nunits, int nblocks) { return 8 * ((nunits + 7)
 #ifndef FA3_SSTORE
 #define FA3_SSTORE 1   // the dq kernel writes the keep words with scalar stores (0: v_writelane + one vector store)
 #endif
+// sixteen scalar 8-byte stores of a step's compare lane masks kb[0..15] to the tile at `kw` (one s_nop: last compare -> first store)
+#define FA3_STORE_MASKS(kb, kw)                                                                                                                     \
+    asm volatile("s_nop 4\n\t"                                                                                                                       \
+                 "s_store_dwordx2 %0, %16, 0x0\n\ts_store_dwordx2 %1, %16, 0x8\n\ts_store_dwordx2 %2, %16, 0x10\n\ts_store_dwordx2 %3, %16, 0x18\n\t"      \
+                 "s_store_dwordx2 %4, %16, 0x20\n\ts_store_dwordx2 %5, %16, 0x28\n\ts_store_dwordx2 %6, %16, 0x30\n\ts_store_dwordx2 %7, %16, 0x38\n\t"    \
+                 "s_store_dwordx2 %8, %16, 0x40\n\ts_store_dwordx2 %9, %16, 0x48\n\ts_store_dwordx2 %10, %16, 0x50\n\ts_store_dwordx2 %11, %16, 0x58\n\t"  \
+                 "s_store_dwordx2 %12, %16, 0x60\n\ts_store_dwordx2 %13, %16, 0x68\n\ts_store_dwordx2 %14, %16, 0x70\n\ts_store_dwordx2 %15, %16, 0x78"    \
+                 ::"s"(kb[0]), "s"(kb[1]), "s"(kb[2]), "s"(kb[3]), "s"(kb[4]), "s"(kb[5]), "s"(kb[6]), "s"(kb[7]), "s"(kb[8]), "s"(kb[9]), "s"(kb[10]),      \
+                 "s"(kb[11]), "s"(kb[12]), "s"(kb[13]), "s"(kb[14]), "s"(kb[15]), "s"(kw)                                                        \
+                 : "memory")
+typedef __attribute__((ext_vector_type(8))) uint64_t u64x8;
 // dword slot of key k (0..31) inside a tile's 32 keep words: the dq kernel's compare for register 4 r4 + e yields the words of keys 8 r4 + e and 8 r4 + 4 + e
 // as one 64-bit lane mask, stored as one unit
 __device__ __forceinline__ int fa3_kslot(int k) { return 2 * (4 * (k >> 3) + (k & 3)) + ((k >> 2) & 1); }
@@ -989,7 +1003,7 @@ template <int HD> struct Fa3Stager {
 
 template <int HD, int STG, bool TAIL, bool MASK, bool DROP>
 __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>& ln, int k0, const bf16x8 (&qf)[HD / 16], f32x16 (&o)[HD / 32],
-                                             float& m, float& l, float c, unsigned rbase, int qidx, int sq, int lane) {
+                                             float& m, float& l, float c, unsigned rbase, int qidx, int sq, int lane, uint32_t* kw) {
     constexpr int KK = HD / 16, XI = STG * FA2_STAGE, YI = XI + FA_IMG;   // X = K rows, Y = V rows
     const int hi = lane >> 5;
     bf16x8 kr[KK];
@@ -1036,6 +1050,7 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
     }
     const float mc = (MASK && m == -INFINITY) ? 0.f : m * c;   // (all of this row's scores are -inf so far: exp2(-inf - 0) = 0)
     f32x2 ps2 = {0.f, 0.f};   // (two running sums: v_pk_add_f32)
+    uint64_t kb[16];
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         bool keep[4] = {true, true, true, true};
@@ -1046,9 +1061,13 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
         ps2 += (f32x2){p[0], p[1]};
         ps2 += (f32x2){p[2], p[3]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * r4 + e] = (DROP && !keep[e]) ? 0.f : p[e];
+        for (int e = 0; e < 4; ++e) {
+            s[4 * r4 + e] = (DROP && !keep[e]) ? 0.f : p[e];
+            if constexpr (DROP) kb[4 * r4 + e] = __builtin_amdgcn_ballot_w64(keep[e]);   // (the compare's lane mask = the words of keys 8 r4 + e, 8 r4 + 4 + e)
+        }
     }
     l += ps2[0] + ps2[1];
+    if constexpr (DROP) { if (kw) FA3_STORE_MASKS(kb, kw); }   // for both backward kernels (fa_layer_bits); wave-uniform pointer
     const bf16x8 p0 = fa3_pack8(s, 0), p1 = fa3_pack8(s, 8);
 #pragma unroll
     for (int db = 0; db < HD / 32; ++db) {
@@ -1091,9 +1110,13 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fa
     float m = -INFINITY, l = 0.f;
     const float c = a.scale * 1.44269504088896341f;
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
-#define F3_STEP(STG, T, K0) fa3_fwd_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, o, m, l, c, rbase, qrow, sq, lane)
+    uint32_t* kwq = nullptr;   // (uniform) the tile (unit, key block 0, this wave's query block) of the layer's keep words, when the launcher provided a buffer
+    if constexpr (DROP) { if (a.keepbits) kwq = a.keepbits + ((long long)unit * a.nblk * a.nblk + (q0 >> 5)) * 32; }
+#define F3_STEP(STG, T, K0) fa3_fwd_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, o, m, l, c, rbase, qrow, sq, lane, \
+                                                                 kwq ? kwq + (long long)((K0) >> 5) * a.nblk * 32 : nullptr)
     FA3_LOOP(active, FA3_NOEXTRA, F3_STEP)
 #undef F3_STEP
+    if constexpr (DROP) asm volatile("s_dcache_wb" ::: "memory");
     if (!active) return;
     const float lt = l + fa3_swap32(l);
     if (query < a.S) {
@@ -1113,7 +1136,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fa
     }
 }
 
-template <int HD, int STG, bool TAIL, bool MASK, bool DROP>
+template <int HD, int STG, bool TAIL, bool MASK, bool DROP, bool KWIN>
 __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>& ln, int k0, const bf16x8 (&qf)[HD / 16], const bf16x8 (&df)[HD / 16],
                                               f32x16 (&dq)[HD / 32], float L2, float D, float c, unsigned rbase, int qidx, int sq, int lane,
                                               uint32_t* kw) {
@@ -1135,6 +1158,10 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
     for (int kk = 0; kk < KK; ++kk) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[kk], df[kk], dp, 0, 0, 0);   // dPd[key][query] = v . dO
     Fa3T kt;
     fa3_read_t<HD, XI>(kt, ln, 0);
+    u64x8 km0, km1;   // KWIN: the step's sixteen lane masks as the forward stored them (km0[r] for r < 8, km1[r - 8]); valid when the asm returns
+    if constexpr (KWIN) {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(km0), "=&s"(km1) : "s"(kw) : "memory");
+    }
     unsigned vb = 0u;
     if constexpr (MASK) vb = fa_valid_bits(a, sq, k0, lane);
     unsigned kword = 0u;   // DROP, FA3_SSTORE == 0: lane k < 32 collects the word of key k0 + k (bit q = query q of this wave keeps it)
@@ -1142,7 +1169,7 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         bool keep[4] = {true, true, true, true};
-        if constexpr (DROP) fa_keep4_bits(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), keep);
+        if constexpr (DROP && !KWIN) fa_keep4_bits(a.key, a.thr, rbase + (unsigned)(k0 + 8 * r4 + 4 * hi), keep);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * r4 + e, kofs = 8 * r4 + 4 * hi + e, key = k0 + kofs;
@@ -1151,7 +1178,12 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
             if constexpr (MASK) ok = ok & ((key == qidx) | (fa_ctx_nb(qidx, key, a.cf, a.cb) & (((vb >> kofs) & 1u) != 0u)));
             if (TAIL || MASK) p = ok ? p : 0.f;
             float t = dp[r];
-            if constexpr (DROP) {
+            if constexpr (KWIN) {
+                const uint64_t mk = r < 8 ? km0[r & 7] : km1[r & 7];
+                float tk;
+                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tk) : "v"(t), "s"(mk));
+                t = tk * a.dscale;
+            } else if constexpr (DROP) {
                 t = keep[e] ? t * a.dscale : 0.f;
                 // the compare's lane mask IS the pair of words of keys 8 r4 + e (lanes 0..31 = the 32 queries) and 8 r4 + 4 + e (lanes 32..63)
                 const uint64_t b = __builtin_amdgcn_ballot_w64(keep[e]);
@@ -1170,15 +1202,8 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
     if constexpr (DROP) {
 #if FA3_SSTORE
         // the 16 lane masks ARE the tile's 32 words: sixteen scalar 8-byte stores, no vector instruction (slot 2 (4 r4 + e) + half; fa3_kslot is the
-        // reader's side). One s_nop for the last compare -> first store distance; the kernel ends with s_dcache_wb.
-        asm volatile("s_nop 4\n\t"
-                     "s_store_dwordx2 %0, %16, 0x0\n\ts_store_dwordx2 %1, %16, 0x8\n\ts_store_dwordx2 %2, %16, 0x10\n\ts_store_dwordx2 %3, %16, 0x18\n\t"
-                     "s_store_dwordx2 %4, %16, 0x20\n\ts_store_dwordx2 %5, %16, 0x28\n\ts_store_dwordx2 %6, %16, 0x30\n\ts_store_dwordx2 %7, %16, 0x38\n\t"
-                     "s_store_dwordx2 %8, %16, 0x40\n\ts_store_dwordx2 %9, %16, 0x48\n\ts_store_dwordx2 %10, %16, 0x50\n\ts_store_dwordx2 %11, %16, 0x58\n\t"
-                     "s_store_dwordx2 %12, %16, 0x60\n\ts_store_dwordx2 %13, %16, 0x68\n\ts_store_dwordx2 %14, %16, 0x70\n\ts_store_dwordx2 %15, %16, 0x78"
-                     :: "s"(kb[0]), "s"(kb[1]), "s"(kb[2]), "s"(kb[3]), "s"(kb[4]), "s"(kb[5]), "s"(kb[6]), "s"(kb[7]), "s"(kb[8]), "s"(kb[9]), "s"(kb[10]),
-                        "s"(kb[11]), "s"(kb[12]), "s"(kb[13]), "s"(kb[14]), "s"(kb[15]), "s"(kw)
-                     : "memory");
+        // reader's side). The kernel ends with s_dcache_wb.
+        if constexpr (!KWIN) FA3_STORE_MASKS(kb, kw);
 #else
         if (lane < 32) kw[fa3_kslot(lane)] = kword;
 #endif
@@ -1194,7 +1219,7 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
     }
 }
 
-template <int HD, bool MASK, bool DROP>
+template <int HD, bool MASK, bool DROP, bool KWIN = false>
 // (more waves per SIMD at heads 32 / 64 - four / three here, three in the dk/dv kernel - measured: within +- 3 % at PatchTST's and the head-64 shapes)
 __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -1237,11 +1262,11 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAA
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
     uint32_t* kwq = nullptr;   // the 32 words of tile (unit, key block 0, this wave's query block)
     if constexpr (DROP) kwq = a.keepbits + ((long long)unit * a.nblk * a.nblk + (q0 >> 5)) * 32;
-#define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32)
+#define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP, KWIN>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32)
     FA3_LOOP(active, FA3_NOEXTRA, BQ3_STEP)
 #undef BQ3_STEP
 #if FA3_SSTORE
-    if constexpr (DROP) asm volatile("s_dcache_wb" ::: "memory");   // the scalar stores of the keep words leave the scalar data cache
+    if constexpr (DROP && !KWIN) asm volatile("s_dcache_wb" ::: "memory");   // the scalar stores of the keep words leave the scalar data cache
 #endif
     if (!active || query >= a.S) return;
     const long long obase = ((long long)sq * a.S + query) * ld + h * HD;
@@ -1457,10 +1482,43 @@ static int fa_keepbits(hipStream_t stream, size_t bytes, uint32_t** out) {
     *out = sc.p;
     return NBCI_OK;
 }
+// keep words of a LAYER, written by its forward and read by both backward kernels: one buffer per (device, lse pointer) - the caller's log-sum-exp buffer
+// identifies the layer -, tagged with what the forward drew them for; a backward whose tag does not match draws them itself (fa_keepbits)
+struct FaLayerBits { uint32_t* p; size_t bytes; uint32_t key; unsigned thr; int NS, nh, S; };
+static std::map<std::pair<int, const void*>, FaLayerBits> g_fa_layer;
+static int fa_layer_bits_for_forward(hipStream_t stream, const FAArgs& a, size_t bytes, uint32_t** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(NBCI_EHIP, "flash attention layer scratch: hipGetDevice");
+    std::lock_guard<std::mutex> lk(g_fa_mu);
+    FaLayerBits& e = g_fa_layer[std::make_pair(dev, (const void*)a.L)];
+    if (e.bytes < bytes) {
+        if (e.p) {   // an earlier launch may still be using the old buffer
+            if (hipStreamSynchronize(stream) != hipSuccess) return fail(NBCI_EHIP, "flash attention layer scratch: sync");
+            (void)hipFree(e.p);
+        }
+        e.p = nullptr; e.bytes = 0;
+        if (hipMalloc((void**)&e.p, bytes) != hipSuccess) { g_fa_layer.erase(std::make_pair(dev, (const void*)a.L)); return fail(NBCI_EHIP, "flash attention layer scratch: hipMalloc"); }
+        e.bytes = bytes;
+    }
+    e.key = a.key; e.thr = a.thr; e.NS = a.NS; e.nh = a.nh; e.S = a.S;
+    *out = e.p;
+    return NBCI_OK;
+}
+static uint32_t* fa_layer_bits_for_backward(const FAArgs& a) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_fa_mu);
+    auto it = g_fa_layer.find(std::make_pair(dev, (const void*)a.L));
+    if (it == g_fa_layer.end()) return nullptr;
+    const FaLayerBits& e = it->second;
+    return (e.key == a.key && e.thr == a.thr && e.NS == a.NS && e.nh == a.nh && e.S == a.S) ? e.p : nullptr;
+}
 int fattn_release() {
     std::lock_guard<std::mutex> lk(g_fa_mu);
     for (auto& kv : g_fa_scratch) (void)hipFree(kv.second.p);
     g_fa_scratch.clear();
+    for (auto& kv : g_fa_layer) (void)hipFree(kv.second.p);
+    g_fa_layer.clear();
     return NBCI_OK;
 }
 
@@ -1476,24 +1534,38 @@ static int fa_launch(int which, const FAArgs& a0, hipStream_t s) {
     // (head 128: the backward kernels take 316 - 416 registers, one wave per SIMD, and still beat the 16 x 32 pair: 1119 -> 730 us at 64 x 8 x 593 x 128)
     if (tiles32 && !g_fa_force16 && (which == 0 || tiles32b)) {
         const dim3 g3(fa3_grid(a.NS * a.nh, (a.S + 127) / 128));
+        static const int fwdbits = measure_env("NBCI_FA_FWD_BITS", 1);   // measurement: 0 = the dq kernel draws the keep bits itself
         if (which == 0) {
             if (prof_on()) prof_note_symbol("fattn3_fwd_kernel");
+            if (a.thr && fwdbits && a.L) {
+                a.nblk = (a.S + 31) / 32;
+                const int rc = fa_layer_bits_for_forward(s, a, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
+                if (rc != NBCI_OK) return rc;
+            }
             if (a.thr) hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
             else hipLaunchKernelGGL((fattn3_fwd_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
         } else if (which == 1) {
             if (a.thr) {
                 a.nblk = (a.S + 31) / 32;
-                const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
-                if (rc != NBCI_OK) return rc;
+                a.keepbits = fwdbits ? fa_layer_bits_for_backward(a) : nullptr;
+                a.kw_in = a.keepbits != nullptr;
+                if (!a.kw_in) {
+                    const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
+                    if (rc != NBCI_OK) return rc;
+                }
             }
             if (prof_on()) prof_note_symbol("fattn3_bwd_q_kernel");
-            if (a.thr) hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+            if (a.thr && a.kw_in) hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, true, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
+            else if (a.thr) hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, true>), g3, dim3(256), 2 * FA2_STAGE, s, a);
             else hipLaunchKernelGGL((fattn3_bwd_q_kernel<HD, MASK, false>), g3, dim3(256), 2 * FA2_STAGE, s, a);
         } else {
-            if (a.thr) {   // (the buffer the dq launch on this stream just filled)
+            if (a.thr) {   // (the layer's buffer the forward filled, else the one the dq launch on this stream just filled)
                 a.nblk = (a.S + 31) / 32;
-                const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
-                if (rc != NBCI_OK) return rc;
+                a.keepbits = fwdbits ? fa_layer_bits_for_backward(a) : nullptr;
+                if (!a.keepbits) {
+                    const int rc = fa_keepbits(s, (size_t)a.NS * a.nh * a.nblk * a.nblk * 128, &a.keepbits);
+                    if (rc != NBCI_OK) return rc;
+                }
             }
             if (prof_on()) prof_note_symbol("fattn3_bwd_kv_kernel");
             constexpr int lds = 2 * FA2_STAGE + 4 * 1024 * fa3_kv_lds_frags(HD);
