@@ -1031,7 +1031,10 @@ __device__ __forceinline__ void fa3_fwd_step(const FAArgs& a, const Fa3Lane<HD>&
             s[r] = ok ? sv : -INFINITY;
         }
     }
-    // (asm: through fmaxf hipcc first canonicalises every MFMA result - v_max_f32 x, x - before the v_max3_f32; the scores are never signalling NaNs)
+    // (asm: through fmaxf hipcc first canonicalises every MFMA result - v_max_f32 x, x - before the v_max3_f32; the scores are never signalling NaNs.
+    // hipcc's hazard recognizer does not look into asm, so the wait states a vector instruction needs behind the matrix pipe's write - 11 for this
+    // 8-pass product - are spelled out: in a plain step nothing else stands between the last S product and the first v_max3)
+    asm volatile("s_nop 15\n\ts_nop 1" : "+v"(s));
     float cm;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
 #pragma unroll
@@ -1179,10 +1182,11 @@ __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>
             if (TAIL || MASK) p = ok ? p : 0.f;
             float t = dp[r];
             if constexpr (KWIN) {
+                // (the multiply first, in C++: hipcc's hazard recognizer does not look into asm, and an asm instruction reading an MFMA result directly
+                // gets none of the wait states the matrix pipe needs - seen: v_cndmask right behind the last dPd product, dq wrong by whole factors)
                 const uint64_t mk = r < 8 ? km0[r & 7] : km1[r & 7];
-                float tk;
-                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tk) : "v"(t), "s"(mk));
-                t = tk * a.dscale;
+                const float td = t * a.dscale;
+                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(t) : "v"(td), "s"(mk));
             } else if constexpr (DROP) {
                 t = keep[e] ? t * a.dscale : 0.f;
                 // the compare's lane mask IS the pair of words of keys 8 r4 + e (lanes 0..31 = the 32 queries) and 8 r4 + 4 + e (lanes 32..63)
