@@ -180,9 +180,11 @@ int nbci_attention_bwd(const void* qkv, const int32_t* token_mask, const void* o
  * models/patchtst.py:176 and models/itransformer.py:158-173 (no attention mask on those paths).
  *   small : head size 16 / 32 / 64, dtype f32 or bf16, one thread per query / key, K/V rows through scalar loads
  *   flash : head size 32 / 64 / 96 / 128, bf16, one wave per 32 queries / keys on MFMA (32 x 32 score tiles)
- * The backward writes dqkv (NS*S, 3H); dsum (NS*n_heads*S) f32 is scratch. With drop_p > 0 the flash backward also keeps one library-owned buffer
- * per (device, stream) - the dropout keep bits its first launch hands to its second, 4 * NS * n_heads * ceil(S / 32)^2 * 32 bytes, allocated on first use,
- * grown on demand (a stream synchronisation then) and freed by nbci_release_scratch(). */
+ * The backward writes dqkv (NS*S, 3H); dsum (NS*n_heads*S) f32 is scratch. With drop_p > 0 the flash kernels keep library-owned buffers of dropout keep
+ * bits, 4 * NS * n_heads * ceil(S / 32)^2 * 32 bytes each: the forward writes one per LAYER, found again by the backward under the same lse pointer (and
+ * only used when seed, site, drop_p and the shape match - otherwise the backward draws the bits itself into one buffer per (device, stream)). Allocated on
+ * first use, grown on demand (a stream synchronisation then), freed by nbci_release_scratch(). lse must therefore be the same buffer in the forward and the
+ * backward of a layer (it has to be anyway: the backward reads it). */
 int nbci_attention_small_fwd(const void* qkv, void* out, float* lse, int32_t dtype, int32_t NS, int32_t n_heads, int32_t S, int32_t H,
                              float drop_p, uint32_t seed, uint32_t site, nbci_stream_t stream);
 int nbci_attention_small_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* dsum, void* dqkv, int32_t dtype,
