@@ -1494,6 +1494,15 @@ static int fa_layer_bits_for_forward(hipStream_t stream, const FAArgs& a, size_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(NBCI_EHIP, "flash attention layer scratch: hipGetDevice");
     std::lock_guard<std::mutex> lk(g_fa_mu);
+    // (a process that builds and drops many models leaves entries behind under lse pointers that are gone: past 4 GB everything is dropped once - the
+    // layers in use re-create theirs on their next forward)
+    size_t total = 0;
+    for (auto& kv : g_fa_layer) total += kv.second.bytes;
+    if (total + bytes > (4ull << 30) && g_fa_layer.find(std::make_pair(dev, (const void*)a.L)) == g_fa_layer.end()) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(NBCI_EHIP, "flash attention layer scratch: sync");
+        for (auto& kv : g_fa_layer) (void)hipFree(kv.second.p);
+        g_fa_layer.clear();
+    }
     FaLayerBits& e = g_fa_layer[std::make_pair(dev, (const void*)a.L)];
     if (e.bytes < bytes) {
         if (e.p) {   // an earlier launch may still be using the old buffer

@@ -143,14 +143,16 @@ __device__ __forceinline__ void drop4(uint32_t key, uint32_t thr16, uint32_t idx
 }
 // 4 consecutive elements starting at ANY idx (the same bits as drop_keep per element): three pair hashes cover both parities
 // (attention probabilities: row base = (row index) * T', odd for odd T'); out[r] = keep ? scale : 0
+// (the four 16-bit draws are the 64-bit window at half-word offset (idx & 1) of ha | hb | hc: two funnel shifts instead of six selects; a high half
+// is compared in place: hi >= thr <=> word >= thr << 16)
 __device__ __forceinline__ void drop4_any(uint32_t key, uint32_t thr16, uint32_t idx, float scale, float (&out)[4]) {
     const uint32_t base = idx >> 1;
     const uint32_t ha = mix32(base ^ key), hb = mix32((base + 1u) ^ key), hc = mix32((base + 2u) ^ key);
-    const bool odd = (idx & 1u) != 0u;
-    const uint32_t b0 = odd ? (ha >> 16) : (ha & 0xFFFFu), b1 = odd ? (hb & 0xFFFFu) : (ha >> 16);
-    const uint32_t b2 = odd ? (hb >> 16) : (hb & 0xFFFFu), b3 = odd ? (hc & 0xFFFFu) : (hb >> 16);
-    out[0] = b0 >= thr16 ? scale : 0.f; out[1] = b1 >= thr16 ? scale : 0.f;
-    out[2] = b2 >= thr16 ? scale : 0.f; out[3] = b3 >= thr16 ? scale : 0.f;
+    const uint32_t sh = (idx & 1u) << 4;
+    const uint32_t w0 = __builtin_amdgcn_alignbit(hb, ha, sh), w1 = __builtin_amdgcn_alignbit(hc, hb, sh);
+    const uint32_t thr_hi = thr16 << 16;
+    out[0] = (w0 & 0xFFFFu) >= thr16 ? scale : 0.f; out[1] = w0 >= thr_hi ? scale : 0.f;
+    out[2] = (w1 & 0xFFFFu) >= thr16 ? scale : 0.f; out[3] = w1 >= thr_hi ? scale : 0.f;
 }
 __device__ __forceinline__ float rng_uniform01(uint32_t u) {  // (0,1]
     return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
