@@ -1142,8 +1142,15 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : HD <= 96 ? FA3_W96 : 2) void fa
 template <int HD, int STG, bool TAIL, bool MASK, bool DROP, bool KWIN>
 __device__ __forceinline__ void fa3_bwdq_step(const FAArgs& a, const Fa3Lane<HD>& ln, int k0, const bf16x8 (&qf)[HD / 16], const bf16x8 (&df)[HD / 16],
                                               f32x16 (&dq)[HD / 32], float L2, float D, float c, unsigned rbase, int qidx, int sq, int lane,
-                                              uint32_t* kw) {
+                                              uint32_t* kw, char* smem) {
     constexpr int KK = HD / 16, XI = STG * FA2_STAGE, YI = XI + FA_IMG;   // X = K rows, Y = V rows
+    if constexpr (KWIN) {
+        // the masks of the step after next: one lane pulls their 128-byte line toward the L2 (a 4-byte LDS-DMA into this stage's unused statistics slot: no
+        // register to keep alive; the step's closing vmcnt(0) covers it). The words were written a whole forward + half a backward ago and are read by ONE
+        // blocking scalar load per step.
+        if (lane == 0 && k0 + 64 < a.S)
+            __builtin_amdgcn_global_load_lds((fa_gvoid*)(kw + 2LL * a.nblk * 32), (fa_lvoid*)(smem + XI + 2 * FA_IMG), 4, 0, 0);
+    }
     const int hi = lane >> 5;
     bf16x8 kr[KK], vr[KK];
 #pragma unroll
@@ -1266,7 +1273,7 @@ __global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void fattn3_bwd_q_kernel(FAA
     const unsigned rbase = (unsigned)(((long long)unit * a.S + qrow) * a.S);
     uint32_t* kwq = nullptr;   // the 32 words of tile (unit, key block 0, this wave's query block)
     if constexpr (DROP) kwq = a.keepbits + ((long long)unit * a.nblk * a.nblk + (q0 >> 5)) * 32;
-#define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP, KWIN>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32)
+#define BQ3_STEP(STG, T, K0) fa3_bwdq_step<HD, STG, T, MASK, DROP, KWIN>(a, ln, K0, qf, df, dq, L2, D, c, rbase, qrow, sq, lane, kwq + (long long)((K0) >> 5) * a.nblk * 32, smem)
     FA3_LOOP(active, FA3_NOEXTRA, BQ3_STEP)
 #undef BQ3_STEP
 #if FA3_SSTORE
